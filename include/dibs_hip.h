@@ -1,0 +1,174 @@
+/*
+ * dibs_hip.h -- C ABI of the MI355X-native DiBS SVGD engine (libdibs_hip.so).
+ *
+ * The reference (larslorch/dibs) has no FFI: its boundary is the Python class API
+ *   MarginalDiBS(...).sample(...)   dibs/inference/svgd.py:60-77, 274-331
+ *   JointDiBS(...).sample(...)      dibs/inference/svgd.py:425-442, 730-795
+ * Each entry point below names the reference interface it replaces.  The Python facade
+ * (dibs_amd/inference/svgd.py) binds these with ctypes; INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions: every function returns 0 on success, non-zero on error; dibs_last_error() gives
+ * the thread-local message.  Host buffers are caller-owned, row-major, float32 / int32 / uint32.
+ * The engine owns all device memory.  A handle is not thread-safe; distinct handles are independent.
+ */
+#ifndef DIBS_HIP_H
+#define DIBS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIBS_ABI_VERSION 1
+#define DIBS_MAX_HIDDEN_LAYERS 4
+
+enum { DIBS_LIK_BGE = 0, DIBS_LIK_LINGAUSS = 1, DIBS_LIK_DENSENN = 2 };
+enum { DIBS_PRIOR_ER = 0, DIBS_PRIOR_SF = 1, DIBS_PRIOR_UNIFORM = 2 };
+enum { DIBS_EST_SCORE = 0, DIBS_EST_REPARAM = 1 };
+enum { DIBS_OPT_GD = 0, DIBS_OPT_RMSPROP = 1 };
+enum { DIBS_RNG_LEGACY = 0, DIBS_RNG_PARTITIONABLE = 1 };
+enum { DIBS_ACT_RELU = 0, DIBS_ACT_TANH = 1, DIBS_ACT_SIGMOID = 2, DIBS_ACT_LEAKYRELU = 3 };
+
+/* POD mirror of the constructor kwargs (svgd.py:60-77 / 425-442) + the sizes sample() fixes
+ * (svgd.py:274) + the hyper-parameters of the recognised model classes. */
+typedef struct dibs_config {
+  int32_t abi_version;      /* DIBS_ABI_VERSION */
+  int32_t n_vars;           /* d   = x.shape[-1]                                   dibs.py:67        */
+  int32_t n_dim;            /* k   = n_dim_particles (default d)                   svgd.py:138-139   */
+  int32_t n_particles;      /* M (global, all ranks)                               svgd.py:274       */
+  int32_t n_observations;   /* N   = x.shape[0]                                                      */
+  int32_t n_grad_mc_samples;        /* S                                            dibs.py:60        */
+  int32_t n_acyclicity_mc_samples;  /* Sa                                           dibs.py:61        */
+  int32_t joint;            /* 0 = MarginalDiBS, 1 = JointDiBS                                       */
+  int32_t likelihood;       /* DIBS_LIK_*                                                            */
+  int32_t graph_prior;      /* DIBS_PRIOR_*                                                          */
+  int32_t grad_estimator_z; /* DIBS_EST_*                                           dibs.py:309-318   */
+  int32_t optimizer;        /* DIBS_OPT_*                                           svgd.py:117-122   */
+  int32_t rng_layout;       /* DIBS_RNG_*  (jax_threefry_partitionable)                              */
+  int32_t logistic_minval_tiny; /* 0: uniform minval = finfo.eps (jax default), 1: finfo.tiny        */
+  int32_t has_interventions;/* 0: interv_mask all zero                              svgd.py:86-87     */
+  int32_t nn_n_hidden;      /* DenseNonlinearGaussian: len(hidden_layers)           nonlinearGaussian.py:105 */
+  int32_t nn_hidden[DIBS_MAX_HIDDEN_LAYERS];
+  int32_t nn_activation;    /* DIBS_ACT_*                                                            */
+  int32_t nn_bias;
+  int32_t rank;             /* particle shard: this engine owns particles                            */
+  int32_t n_ranks;          /*   [rank*M/n_ranks, (rank+1)*M/n_ranks)                                */
+  int32_t device_id;
+  int32_t reserved_i[5];
+
+  double alpha_linear;      /* dibs.py:70 */
+  double beta_linear;       /* dibs.py:71 */
+  double tau;               /* dibs.py:72 */
+  double h_latent;          /* kernel.py:16 / :46  (kernel_param "h" / "h_latent") */
+  double h_theta;           /* kernel.py:46 */
+  double scale_latent;      /* kernel.py:16 / :46 */
+  double scale_theta;
+  double stepsize;          /* optimizer_param["stepsize"]   svgd.py:83 */
+  double score_function_baseline; /* dibs.py:76 */
+  double latent_prior_std;  /* <= 0: default 1/sqrt(k)       svgd.py:142, 301-302 */
+  double graph_prior_edges_per_node; /* graph.py:27-30 */
+  double bge_alpha_mu;      /* linearGaussian.py:44 */
+  double bge_alpha_lambd;   /* <= 0: default d + 2           linearGaussian.py:45 */
+  double lin_obs_noise;     /* linearGaussian.py:190 */
+  double lin_mean_edge;
+  double lin_sig_edge;
+  double lin_min_edge;
+  double nn_obs_noise;      /* nonlinearGaussian.py:105 */
+  double nn_sig_param;
+  double reserved_d[6];
+} dibs_config;
+
+typedef struct dibs_engine dibs_engine;
+
+/* names of device buffers readable through dibs_engine_read_buffer (parity tests / callbacks) */
+enum {
+  DIBS_BUF_Z = 0,          /* f32 [Mloc, d, k, 2]                                 */
+  DIBS_BUF_V_Z = 1,        /* f32 [Mloc, d, k, 2]   rmsprop avg_sq_grad           */
+  DIBS_BUF_THETA = 2,      /* f32 [Mloc, P]         theta leaves concatenated     */
+  DIBS_BUF_V_THETA = 3,
+  DIBS_BUF_SCORES = 4,     /* f32 [Mloc, d, d]      U V^T                          */
+  DIBS_BUF_LOGPROBS_Z = 5, /* f32 [Mloc, S]         l_s of the Z estimator         */
+  DIBS_BUF_W_LIK = 6,      /* f32 [Mloc, d, d]      dl/dscores of the likelihood   */
+  DIBS_BUF_W_ACYC = 7,     /* f32 [Mloc, d, d]      E[dh/dscores]                  */
+  DIBS_BUF_GRAD_Z = 8,     /* f32 [Mloc, d, k, 2]   d/dz log p(z, D)               */
+  DIBS_BUF_GRAD_THETA = 9, /* f32 [Mloc, P]                                        */
+  DIBS_BUF_KXX = 10,       /* f32 [Mloc, M]         kxx[a_local, b_global]         */
+  DIBS_BUF_PHI_Z = 11,     /* f32 [Mloc, d, k, 2]                                  */
+  DIBS_BUF_BASELINE = 12,  /* f32 [Mloc]                                           */
+  DIBS_BUF_NODE_SCORES = 13,/* f32 [Mloc, S, d]     BGe per-node scores            */
+  DIBS_BUF_PARENT_MASKS = 14,/* u64 [Mloc, S, d, W] sampled parent sets (bit i of word i/64 = g[i, j]) */
+  DIBS_BUF_LOGPROBS_THETA = 15, /* f32 [Mloc, S]                                   */
+  DIBS_BUF_PHI_THETA = 16,
+  DIBS_BUF_GATHER = 17,    /* f32 packed all-gather payload        */
+  DIBS_BUF_COUNT
+};
+
+/* kernel ids for dibs_engine_get_timers */
+enum {
+  DIBS_K_EDGE = 0, DIBS_K_BGE_NODES = 1, DIBS_K_LIK_WEIGHTS = 2, DIBS_K_ACYC = 3, DIBS_K_ZGRAD = 4,
+  DIBS_K_KMAT = 5, DIBS_K_PHI_UPDATE = 6, DIBS_K_LIN_THETA = 7, DIBS_K_LIN_Z = 8, DIBS_K_NN_THETA = 9,
+  DIBS_K_NN_Z = 10, DIBS_K_PACK = 11, DIBS_K_COUNT = 16
+};
+
+const char* dibs_last_error(void);
+int dibs_abi_version(void);
+
+/* replaces MarginalDiBS.__init__ / JointDiBS.__init__ (svgd.py:60-122, 425-487): validates the config,
+ * selects the device, allocates all device state.  `stream` is a hipStream_t to launch on (NULL: the
+ * engine creates its own). */
+int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_engine** out);
+int dibs_engine_destroy(dibs_engine* e);
+
+/* x: f32 [N, d]; interv_mask: i32 [N, d] or NULL; bge_mean_obs: f32 [d] or NULL  (svgd.py:61-64, 86-87) */
+int dibs_engine_set_data(dibs_engine* e, const float* x, const int32_t* interv_mask, const float* bge_mean_obs);
+
+/* replaces the prologue of sample() (svgd.py:293-307 / 750-766): key,subk = split(key);
+ * _sample_initial_random_particles(subk); zero optimizer state and baselines; keeps the carry key. */
+int dibs_engine_init_particles(dibs_engine* e, const uint32_t key[2]);
+
+/* checkpoint / resume of the loop carry (svgd.py:315: (opt_state_z[, opt_state_theta], key, sf_baseline));
+ * any pointer may be NULL (left untouched / not returned).  z, v_z: f32 [Mloc, d, k, 2]; theta, v_theta:
+ * f32 [Mloc, P]; key: u32 [2]; baseline: f32 [Mloc]. */
+int dibs_engine_set_state(dibs_engine* e, const float* z, const float* v_z, const float* theta,
+                          const float* v_theta, const uint32_t* key, const float* baseline);
+int dibs_engine_get_state(dibs_engine* e, float* z, float* v_z, float* theta, float* v_theta,
+                          uint32_t* key, float* baseline);
+
+/* replaces _svgd_loop(start, n_steps, carry) (svgd.py:269-272 / 724-727): runs steps t_start ..
+ * t_start+n_steps-1 entirely on the device, blocking until done.  Single-rank engines only. */
+int dibs_engine_run(dibs_engine* e, int32_t t_start, int32_t n_steps);
+
+/* multi-rank split of one _svgd_step (svgd.py:226-267): phase A = per-particle estimators for the local
+ * shard + packing of [z | grad_z (| theta | grad_theta)] into the send buffer; the caller all-gathers
+ * (RCCL, torch.distributed) send -> recv; phase B = kernel matrix slab, phi and optimizer step for the
+ * local shard.  Buffers are device pointers owned by the caller (torch tensors). Asynchronous on the
+ * engine stream. */
+int dibs_engine_step_local(dibs_engine* e, int32_t t, void* send_dev);
+int dibs_engine_step_update(dibs_engine* e, int32_t t, const void* recv_dev);
+int64_t dibs_engine_gather_elems_per_rank(const dibs_engine* e);
+int dibs_engine_sync(dibs_engine* e);
+
+/* debugging / parity: copy a device buffer to the host (nbytes must match); theta size query */
+int dibs_engine_read_buffer(dibs_engine* e, int32_t which, void* host, int64_t nbytes);
+int64_t dibs_engine_buffer_bytes(const dibs_engine* e, int32_t which);
+int64_t dibs_engine_theta_size(const dibs_engine* e);
+
+/* per-kernel HIP-event timers (events recorded on the engine stream).  enable=1 brackets every launch. */
+int dibs_engine_set_profiling(dibs_engine* e, int32_t enable);
+int dibs_engine_get_timers(dibs_engine* e, double* total_ms, int64_t* launches, int32_t n); /* arrays of DIBS_K_COUNT */
+int dibs_engine_reset_timers(dibs_engine* e);
+/* effective (executed) flop / problem-size counters of the BGe node kernel for the roofline */
+int dibs_engine_get_counters(dibs_engine* e, double* out, int32_t n);
+
+/* replaces likelihood_model.interventional_log_marginal_prob / interventional_log_joint_prob evaluated on a
+ * batch of hard graphs (svgd.py:110-113, 370-372, 475-478, 838-841): g: i32 [n, d, d]; theta: f32 [n, P] or
+ * NULL; x_ho: f32 [n_ho, d]; mask_ho: i32 [n_ho, d] or NULL; out: f32 [n]. */
+int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* theta, int32_t n, const float* x_ho,
+                      const int32_t* mask_ho, int32_t n_ho, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIBS_HIP_H */
