@@ -1,0 +1,666 @@
+// libdibs_hip.so -- engine + C ABI (include/dibs_hip.h).  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/dibs_hip.h"
+#include "kernels_marginal.h"
+#include "kernels_joint.h"
+
+#define LDS_LIMIT ((size_t)160 * 1024)
+static thread_local std::string g_err;
+static int fail(const std::string& m) {
+  g_err = m;
+  return 1;
+}
+#define HIP_OK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(_e));              \
+  } while (0)
+
+struct dibs_engine {
+  dibs_config cfg;
+  int d, k, M, Mloc, m0, N, S, Sa, W;
+  int64_t D, P, E;  // z elems / theta elems per particle, packed row stride (floats)
+  int dpad, ldk, acyc_nt, acyc_cpb, acyc_nblk;
+  float sigz;
+  hipStream_t stream;
+  bool own_stream;
+  // state
+  float *z, *vz, *theta, *vtheta, *baseline;
+  Key2 key;
+  // data
+  float* x;
+  int32_t* mask;
+  float* R;
+  double *gam, *Nj;
+  int n_mats;
+  double alpha_lambd;
+  bool has_data;
+  // work
+  float *scores, *w_lik, *acyc_part, *w_acyc, *logprobs_z, *logprobs_th, *pack, *kz, *kt, *phi_z, *phi_th;
+  uint32_t* thr;
+  uint64_t* masks;
+  double* node_scores;
+  unsigned long long* counters;
+  JointWork jw;
+  // profiling
+  bool profiling;
+  hipEvent_t ev0, ev1;
+  double t_ms[DIBS_K_COUNT];
+  int64_t t_n[DIBS_K_COUNT];
+  std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+};
+
+extern "C" const char* dibs_last_error(void) { return g_err.c_str(); }
+extern "C" int dibs_abi_version(void) { return DIBS_ABI_VERSION; }
+
+static int64_t theta_size(const dibs_config& c) {
+  const int d = c.n_vars;
+  if (!c.joint) return 0;
+  if (c.likelihood == DIBS_LIK_LINGAUSS) return (int64_t)d * d;
+  if (c.likelihood == DIBS_LIK_DENSENN) {
+    int64_t p = 0;
+    int in = d;
+    for (int l = 0; l <= c.nn_n_hidden; ++l) {
+      const int out = l < c.nn_n_hidden ? c.nn_hidden[l] : 1;
+      p += (int64_t)d * in * out + (c.nn_bias ? (int64_t)d * out : 0);
+      in = out;
+    }
+    return p;
+  }
+  return 0;
+}
+
+template <typename T>
+static hipError_t dalloc(T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) return hipSuccess;
+  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  if (e == hipSuccess) e = hipMemset(*p, 0, n * sizeof(T));
+  return e;
+}
+
+extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_engine** out) {
+  if (!cfg || !out) return fail("null argument");
+  *out = nullptr;
+  const dibs_config& c = *cfg;
+  if (c.abi_version != DIBS_ABI_VERSION) return fail("dibs_config.abi_version mismatch");
+  if (c.n_vars < 2 || c.n_vars > 128) return fail("n_vars must be in [2, 128]");
+  if (c.n_dim < 1) return fail("n_dim must be >= 1");
+  if (c.n_particles < 1 || c.n_grad_mc_samples < 1 || c.n_acyclicity_mc_samples < 1) return fail("sizes must be >= 1");
+  if (c.n_ranks < 1 || c.rank < 0 || c.rank >= c.n_ranks) return fail("bad rank / n_ranks");
+  if (c.n_particles % c.n_ranks) return fail("n_particles must be divisible by n_ranks");
+  if (c.grad_estimator_z != DIBS_EST_SCORE && c.grad_estimator_z != DIBS_EST_REPARAM)
+    return fail("Unknown gradient estimator");  // dibs.py:318 (ValueError)
+  if (c.optimizer != DIBS_OPT_GD && c.optimizer != DIBS_OPT_RMSPROP) return fail("unknown optimizer");  // svgd.py:122
+  if (c.likelihood < 0 || c.likelihood > 2) return fail("unknown likelihood model");
+  if (c.graph_prior < 0 || c.graph_prior > 2) return fail("unknown graph prior");
+  if (!c.joint && c.likelihood != DIBS_LIK_BGE)
+    return fail("MarginalDiBS needs a marginal likelihood (BGe)");
+  if (c.joint && c.likelihood == DIBS_LIK_BGE)
+    return fail("JointDiBS + BGe is not constructible (BGe has no parameters; linearGaussian.py:53-54)");
+  if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z != DIBS_EST_SCORE)
+    return fail("BGe + reparam estimator not supported yet");
+  if (c.likelihood == DIBS_LIK_DENSENN) return fail("DenseNonlinearGaussian not supported yet");
+  if (c.graph_prior == DIBS_PRIOR_ER) {
+    const double p = c.graph_prior_edges_per_node * c.n_vars / ((c.n_vars * (c.n_vars - 1)) / 2.0);
+    if (!(p > 0.0 && p < 1.0)) return fail("Erdos-Renyi prior: edge probability must be in (0, 1)");
+  }
+  {
+    const size_t D4 = (size_t)c.n_vars * c.n_dim * 2 * 4;
+    if (D4 > LDS_LIMIT - 1024) return fail("n_vars * n_dim too large for the kernel-matrix LDS tile");
+    if ((size_t)2 * 8 * c.n_particles * 4 > LDS_LIMIT) return fail("n_particles too large (kernel rows must fit in LDS)");
+  }
+  int ndev = 0;
+  HIP_OK(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return fail("no HIP device");
+  HIP_OK(hipSetDevice(c.device_id));
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, c.device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(std::string("libdibs_hip is built for gfx950 only; device is ") + prop.gcnArchName);
+
+  dibs_engine* e = new dibs_engine();
+  memset((void*)e, 0, offsetof(dibs_engine, pending));
+  e->cfg = c;
+  e->d = c.n_vars;
+  e->k = c.n_dim;
+  e->M = c.n_particles;
+  e->Mloc = c.n_particles / c.n_ranks;
+  e->m0 = c.rank * e->Mloc;
+  e->N = c.n_observations;
+  e->S = c.n_grad_mc_samples;
+  e->Sa = c.n_acyclicity_mc_samples;
+  e->W = (e->d + 63) / 64;
+  e->D = (int64_t)e->d * e->k * 2;
+  e->P = theta_size(c);
+  e->E = ((2 * e->D + 2 * e->P) + 3) & ~(int64_t)3;
+  e->dpad = (e->d + 15) & ~15;
+  {
+    const int kp = (e->k + 3) & ~3;
+    e->ldk = kp + ((2 - kp) % 32 + 32) % 32;  // ldk == 2 (mod 32): conflict-free MFMA operand reads
+  }
+  e->acyc_nt = e->dpad / 16;
+  e->acyc_cpb = 4;
+  e->acyc_nblk = (e->Sa + e->acyc_cpb - 1) / e->acyc_cpb;
+  e->sigz = c.latent_prior_std > 0 ? (float)c.latent_prior_std : 1.0f / sqrtf((float)e->k);
+  if (stream) {
+    e->stream = (hipStream_t)stream;
+    e->own_stream = false;
+  } else {
+    HIP_OK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->own_stream = true;
+  }
+  HIP_OK(hipEventCreate(&e->ev0));
+  HIP_OK(hipEventCreate(&e->ev1));
+  const size_t Ml = e->Mloc, dd = (size_t)e->d * e->d;
+  HIP_OK(dalloc(&e->z, Ml * e->D));
+  HIP_OK(dalloc(&e->vz, Ml * e->D));
+  HIP_OK(dalloc(&e->theta, Ml * e->P));
+  HIP_OK(dalloc(&e->vtheta, Ml * e->P));
+  HIP_OK(dalloc(&e->baseline, Ml));
+  HIP_OK(dalloc(&e->scores, Ml * dd));
+  HIP_OK(dalloc(&e->thr, Ml * dd));
+  HIP_OK(dalloc(&e->w_lik, Ml * dd));
+  HIP_OK(dalloc(&e->acyc_part, Ml * e->acyc_nblk * dd));
+  HIP_OK(dalloc(&e->w_acyc, Ml * dd));
+  HIP_OK(dalloc(&e->logprobs_z, Ml * e->S));
+  HIP_OK(dalloc(&e->logprobs_th, Ml * e->S));
+  HIP_OK(dalloc(&e->pack, (size_t)e->M * e->E));
+  HIP_OK(dalloc(&e->kz, Ml * e->M));
+  if (c.joint) HIP_OK(dalloc(&e->kt, Ml * e->M));
+  HIP_OK(dalloc(&e->phi_z, Ml * e->D));
+  HIP_OK(dalloc(&e->phi_th, Ml * e->P));
+  HIP_OK(dalloc(&e->counters, (size_t)8));
+  if (c.likelihood == DIBS_LIK_BGE) {
+    HIP_OK(dalloc(&e->masks, Ml * e->S * e->d * e->W));
+    HIP_OK(dalloc(&e->node_scores, Ml * e->S * e->d));
+  }
+  if (c.joint) {
+    if (joint_alloc(&e->jw, e->Mloc, e->d, e->N, e->S) != 0) return fail("joint work buffers: hipMalloc failed");
+  }
+  *out = e;
+  return 0;
+}
+
+extern "C" int dibs_engine_destroy(dibs_engine* e) {
+  if (!e) return 0;
+  hipSetDevice(e->cfg.device_id);
+  hipStreamSynchronize(e->stream);
+  void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->scores, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
+                  e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
+                  e->node_scores, e->x, e->mask, e->R, e->gam, e->Nj};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  joint_free(&e->jw);
+  hipEventDestroy(e->ev0);
+  hipEventDestroy(e->ev1);
+  for (auto& pe : e->pending) {
+    hipEventDestroy(pe.second.first);
+    hipEventDestroy(pe.second.second);
+  }
+  if (e->own_stream) hipStreamDestroy(e->stream);
+  delete e;
+  return 0;
+}
+
+// BGe statistics that do not depend on the graph (linearGaussian.py:78-94): R_j, N_j and the (j, l) table of
+// log_gamma_term.  Computed once per data set on the host in double, uploaded as f32 / f64.
+static int bge_prepare(dibs_engine* e, const float* x, const int32_t* mask, const float* mean_obs) {
+  const int d = e->d, N = e->N;
+  const double amu = e->cfg.bge_alpha_mu;
+  e->alpha_lambd = e->cfg.bge_alpha_lambd > 0 ? e->cfg.bge_alpha_lambd : d + 2.0;
+  if (!(e->alpha_lambd > d + 1)) return fail("BGe: alpha_lambd must be > n_vars + 1");  // linearGaussian.py:47
+  const double small_t = amu * (e->alpha_lambd - d - 1) / (amu + 1);
+  bool any = false;
+  if (mask)
+    for (int64_t i = 0; i < (int64_t)N * d; ++i) any |= mask[i] != 0;
+  e->n_mats = any ? d : 1;
+  std::vector<float> R((size_t)e->n_mats * d * d);
+  std::vector<double> Nj(d), gam((size_t)d * (d + 1)), xb(d);
+  for (int jm = 0; jm < e->n_mats; ++jm) {
+    double Nn = 0;
+    for (int n = 0; n < N; ++n) Nn += (any && mask[(int64_t)n * d + jm]) ? 0.0 : 1.0;
+    for (int a = 0; a < d; ++a) {
+      double s = 0;
+      for (int n = 0; n < N; ++n)
+        if (!(any && mask[(int64_t)n * d + jm])) s += (double)x[(int64_t)n * d + a];
+      xb[a] = Nn > 0 ? s / Nn : 0.0;
+    }
+    for (int a = 0; a < d; ++a)
+      for (int b = 0; b < d; ++b) {
+        double s = 0;
+        for (int n = 0; n < N; ++n)
+          if (!(any && mask[(int64_t)n * d + jm]))
+            s += ((double)x[(int64_t)n * d + a] - xb[a]) * ((double)x[(int64_t)n * d + b] - xb[b]);
+        const double ma = mean_obs ? (double)mean_obs[a] : 0.0, mb = mean_obs ? (double)mean_obs[b] : 0.0;
+        R[(size_t)jm * d * d + a * d + b] =
+            (float)((a == b ? small_t : 0.0) + s + (Nn * amu / (Nn + amu)) * (xb[a] - ma) * (xb[b] - mb));
+      }
+    if (any) Nj[jm] = Nn;
+    else
+      for (int j = 0; j < d; ++j) Nj[j] = Nn;
+  }
+  for (int j = 0; j < d; ++j)
+    for (int l = 0; l <= d; ++l) {
+      const double Nn = Nj[j], al = e->alpha_lambd;
+      gam[(size_t)j * (d + 1) + l] = 0.5 * (log(amu) - log(Nn + amu)) + lgamma(0.5 * (Nn + al - d + l + 1)) -
+                                     lgamma(0.5 * (al - d + l + 1)) - 0.5 * Nn * log(M_PI) +
+                                     0.5 * (al - d + 2 * l + 1) * log(small_t);
+    }
+  if (e->R) hipFree(e->R);
+  if (e->gam) hipFree(e->gam);
+  if (e->Nj) hipFree(e->Nj);
+  HIP_OK(dalloc(&e->R, R.size()));
+  HIP_OK(dalloc(&e->gam, gam.size()));
+  HIP_OK(dalloc(&e->Nj, Nj.size()));
+  HIP_OK(hipMemcpy(e->R, R.data(), R.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(e->gam, gam.data(), gam.size() * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(e->Nj, Nj.data(), Nj.size() * 8, hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int dibs_engine_set_data(dibs_engine* e, const float* x, const int32_t* interv_mask, const float* bge_mean_obs) {
+  if (!e || !x) return fail("null argument");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  HIP_OK(hipStreamSynchronize(e->stream));
+  const size_t n = (size_t)e->N * e->d;
+  if (e->x) hipFree(e->x);
+  if (e->mask) hipFree(e->mask);
+  HIP_OK(dalloc(&e->x, n));
+  HIP_OK(dalloc(&e->mask, n));
+  HIP_OK(hipMemcpy(e->x, x, n * 4, hipMemcpyHostToDevice));
+  if (interv_mask) HIP_OK(hipMemcpy(e->mask, interv_mask, n * 4, hipMemcpyHostToDevice));
+  if (e->cfg.likelihood == DIBS_LIK_BGE) {
+    if (bge_prepare(e, x, interv_mask, bge_mean_obs)) return 1;
+  } else if (e->cfg.likelihood == DIBS_LIK_LINGAUSS) {
+    if (joint_set_data(&e->jw, x, interv_mask, e->N, e->d)) return fail("joint_set_data failed");
+  }
+  e->has_data = true;
+  return 0;
+}
+
+extern "C" int dibs_engine_init_particles(dibs_engine* e, const uint32_t key[2]) {
+  if (!e || !key) return fail("null argument");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  const int L = e->cfg.rng_layout;
+  const Key2 k0{key[0], key[1]};
+  e->key = rng_split_row(k0, 2, 0, L);                     // key, subk = split(key)            svgd.py:294
+  const Key2 subk = rng_split_row(k0, 2, 1, L);
+  const Key2 ikey = rng_split_row(subk, 2, 0, L);          // key, subk = split(key)            svgd.py:145 / :509
+  const Key2 isub = rng_split_row(subk, 2, 1, L);
+  const uint64_t ntot = (uint64_t)e->M * e->D, nloc = (uint64_t)e->Mloc * e->D;
+  hipLaunchKernelGGL(k_init_z, dim3((unsigned)((nloc + 255) / 256)), dim3(256), 0, e->stream, e->z, isub, ntot,
+                     (uint64_t)e->m0 * e->D, nloc, e->sigz, L);
+  if (e->cfg.joint) {
+    const Key2 tsub = rng_split_row(ikey, 2, 1, L);        // key, subk = split(key); sample_parameters(key=subk)  svgd.py:512-513
+    if (e->cfg.likelihood == DIBS_LIK_LINGAUSS) {
+      const uint64_t tt = (uint64_t)e->M * e->P, tl = (uint64_t)e->Mloc * e->P;
+      hipLaunchKernelGGL(k_init_theta_lin, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, e->stream, e->theta, tsub, tt,
+                         (uint64_t)e->m0 * e->P, tl, (float)e->cfg.lin_mean_edge, (float)e->cfg.lin_sig_edge,
+                         (float)e->cfg.lin_min_edge, L);
+    } else {
+      return fail("sample_parameters not implemented for this likelihood");
+    }
+  }
+  HIP_OK(hipMemsetAsync(e->vz, 0, (size_t)e->Mloc * e->D * 4, e->stream));
+  if (e->P) HIP_OK(hipMemsetAsync(e->vtheta, 0, (size_t)e->Mloc * e->P * 4, e->stream));
+  HIP_OK(hipMemsetAsync(e->baseline, 0, (size_t)e->Mloc * 4, e->stream));
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+extern "C" int dibs_engine_set_state(dibs_engine* e, const float* z, const float* v_z, const float* theta,
+                                     const float* v_theta, const uint32_t* key, const float* baseline) {
+  if (!e) return fail("null engine");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  HIP_OK(hipStreamSynchronize(e->stream));
+  const size_t nz = (size_t)e->Mloc * e->D * 4, nt = (size_t)e->Mloc * e->P * 4;
+  if (z) HIP_OK(hipMemcpy(e->z, z, nz, hipMemcpyHostToDevice));
+  if (v_z) HIP_OK(hipMemcpy(e->vz, v_z, nz, hipMemcpyHostToDevice));
+  if (theta && nt) HIP_OK(hipMemcpy(e->theta, theta, nt, hipMemcpyHostToDevice));
+  if (v_theta && nt) HIP_OK(hipMemcpy(e->vtheta, v_theta, nt, hipMemcpyHostToDevice));
+  if (key) e->key = Key2{key[0], key[1]};
+  if (baseline) HIP_OK(hipMemcpy(e->baseline, baseline, (size_t)e->Mloc * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int dibs_engine_get_state(dibs_engine* e, float* z, float* v_z, float* theta, float* v_theta, uint32_t* key,
+                                     float* baseline) {
+  if (!e) return fail("null engine");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  HIP_OK(hipStreamSynchronize(e->stream));
+  const size_t nz = (size_t)e->Mloc * e->D * 4, nt = (size_t)e->Mloc * e->P * 4;
+  if (z) HIP_OK(hipMemcpy(z, e->z, nz, hipMemcpyDeviceToHost));
+  if (v_z) HIP_OK(hipMemcpy(v_z, e->vz, nz, hipMemcpyDeviceToHost));
+  if (theta && nt) HIP_OK(hipMemcpy(theta, e->theta, nt, hipMemcpyDeviceToHost));
+  if (v_theta && nt) HIP_OK(hipMemcpy(v_theta, e->vtheta, nt, hipMemcpyDeviceToHost));
+  if (key) {
+    key[0] = e->key.a;
+    key[1] = e->key.b;
+  }
+  if (baseline) HIP_OK(hipMemcpy(baseline, e->baseline, (size_t)e->Mloc * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// kernels that may need more than the default 64 KiB of dynamic LDS
+template <typename K>
+static void allow_lds(K kernel, size_t bytes) {
+  if (bytes > 48 * 1024) hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// ---- profiling helpers -----------------------------------------------------------------------
+struct KTimer {
+  dibs_engine* e;
+  int id;
+  hipEvent_t a, b;
+  KTimer(dibs_engine* e_, int id_) : e(e_), id(id_), a(nullptr), b(nullptr) {
+    if (e->profiling) {
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+      hipEventRecord(a, e->stream);
+    }
+  }
+  ~KTimer() {
+    if (e->profiling) {
+      hipEventRecord(b, e->stream);
+      e->pending.push_back({id, {a, b}});
+    }
+  }
+};
+
+static void drain_timers(dibs_engine* e) {
+  for (auto& pe : e->pending) {
+    hipEventSynchronize(pe.second.second);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, pe.second.first, pe.second.second);
+    e->t_ms[pe.first] += ms;
+    e->t_n[pe.first] += 1;
+    hipEventDestroy(pe.second.first);
+    hipEventDestroy(pe.second.second);
+  }
+  e->pending.clear();
+}
+
+// ---- one SVGD step, split at the exchange point ----------------------------------------------
+// carry keys: the loop-carry key advances by one split(key, M+1) per estimator batch (svgd.py:245, 251 / 695, 699, 703);
+// the host walks the chain (row 0), kernels derive row 1 + m.
+static Key2 next_carry(const dibs_engine* e, Key2 k) { return rng_split_row(k, (uint32_t)e->M + 1u, 0u, e->cfg.rng_layout); }
+
+template <int NT>
+static void launch_acyc(dibs_engine* e, Key2 carry, float alpha) {
+  constexpr int DP = 16 * NT, LD = DP + 2;
+  const size_t lds = (size_t)3 * DP * LD * 4;
+  allow_lds(k_acyc<NT>, lds);
+  hipLaunchKernelGGL(k_acyc<NT>, dim3(e->acyc_nblk, e->Mloc), dim3(256), lds, e->stream, e->scores, e->acyc_part, carry,
+                     e->m0, e->M, e->d, e->Sa, e->acyc_cpb, alpha, (float)e->cfg.tau, e->cfg.rng_layout,
+                     e->cfg.logistic_minval_tiny);
+}
+
+static int step_local(dibs_engine* e, int t, float* pack) {
+  const dibs_config& c = e->cfg;
+  const float alpha = (float)(c.alpha_linear * t), beta = (float)(c.beta_linear * t);
+  const int L = c.rng_layout;
+  Key2 carry = e->key;
+  Key2 carry_theta{0, 0}, carry_lik, carry_prior;
+  if (c.joint) {
+    carry_theta = carry;
+    carry = next_carry(e, carry);
+  }
+  carry_lik = carry;
+  carry = next_carry(e, carry);
+  carry_prior = carry;
+  carry = next_carry(e, carry);
+  e->key = carry;
+
+  {
+    KTimer tm(e, DIBS_K_EDGE);
+    const size_t lds = (size_t)2 * e->dpad * e->ldk * 4;
+    allow_lds(k_edge_scores, lds);
+    hipLaunchKernelGGL(k_edge_scores, dim3(e->Mloc), dim3(256), lds, e->stream, e->z, e->scores, e->thr, alpha, e->d, e->k,
+                       e->dpad, e->ldk);
+  }
+  if (c.likelihood == DIBS_LIK_BGE) {
+    {
+      KTimer tm(e, DIBS_K_BGE_NODES);
+      BgeParams bp{e->R, e->gam, e->Nj, e->alpha_lambd, e->n_mats};
+      allow_lds(k_bge_nodes, bge_lds_bytes(e->d, e->S, e->W));
+      hipLaunchKernelGGL(k_bge_nodes, dim3(e->d, e->Mloc), dim3(64), bge_lds_bytes(e->d, e->S, e->W), e->stream, e->thr,
+                         e->masks, e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L,
+                         e->profiling ? e->counters : (unsigned long long*)nullptr);
+    }
+    {
+      KTimer tm(e, DIBS_K_LIK_WEIGHTS);
+      const size_t base = (((size_t)e->S * 12 + 15) & ~(size_t)15);
+      const size_t mbytes = (size_t)e->S * e->d * e->W * 8;
+      const int in_lds = base + mbytes <= 64 * 1024;
+      const size_t lds = base + (in_lds ? mbytes : 0);
+      hipLaunchKernelGGL(k_lik_weights_score, dim3(e->Mloc), dim3(256), lds, e->stream, e->node_scores, e->masks, e->scores,
+                         e->logprobs_z, e->w_lik, e->baseline, alpha, c.score_function_baseline, e->d, e->S, e->W, in_lds);
+    }
+  } else if (c.likelihood == DIBS_LIK_LINGAUSS) {
+    JointLaunch jl{e->stream, e->z, e->theta, e->scores, e->thr, e->w_lik, e->logprobs_z, e->logprobs_th, e->baseline,
+                   pack, (size_t)e->E, (size_t)(2 * e->D), (size_t)(2 * e->D + e->P), e->m0, e->M, e->Mloc, e->d, e->N, e->S,
+                   alpha, (float)c.tau, L, c.logistic_minval_tiny, c.grad_estimator_z, c.score_function_baseline,
+                   (float)c.lin_obs_noise, (float)c.lin_mean_edge, (float)c.lin_sig_edge};
+    {
+      KTimer tm(e, DIBS_K_LIN_THETA);
+      joint_lin_theta(&e->jw, jl, carry_theta);
+    }
+    {
+      KTimer tm(e, DIBS_K_LIN_Z);
+      joint_lin_z(&e->jw, jl, carry_lik);
+    }
+  }
+  {
+    KTimer tm(e, DIBS_K_ACYC);
+    switch (e->acyc_nt) {
+      case 1: launch_acyc<1>(e, carry_prior, alpha); break;
+      case 2: launch_acyc<2>(e, carry_prior, alpha); break;
+      case 3: launch_acyc<3>(e, carry_prior, alpha); break;
+      case 4: launch_acyc<4>(e, carry_prior, alpha); break;
+      case 5: launch_acyc<5>(e, carry_prior, alpha); break;
+      case 6: launch_acyc<6>(e, carry_prior, alpha); break;
+      case 7: launch_acyc<7>(e, carry_prior, alpha); break;
+      default: launch_acyc<8>(e, carry_prior, alpha); break;
+    }
+  }
+  {
+    KTimer tm(e, DIBS_K_ZGRAD);
+    float er_c = 0.f;
+    if (c.graph_prior == DIBS_PRIOR_ER) {
+      const double p = c.graph_prior_edges_per_node * e->d / ((e->d * (e->d - 1)) / 2.0);
+      er_c = (float)(log(p) - log(1 - p));
+    }
+    const size_t lds = (size_t)e->d * e->d * 4 + (size_t)e->d * 4;
+    hipLaunchKernelGGL(k_zgrad, dim3(e->Mloc), dim3(256), lds, e->stream, e->z, e->scores, e->w_lik, e->acyc_part,
+                       e->acyc_nblk, e->w_acyc, pack, (size_t)e->E, e->m0, e->d, e->k, e->Sa, alpha, beta,
+                       1.0f / (e->sigz * e->sigz), c.graph_prior, er_c);
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(err));
+  return 0;
+}
+
+static int step_update(dibs_engine* e, int t, const float* pack) {
+  (void)t;
+  const dibs_config& c = e->cfg;
+  {
+    KTimer tm(e, DIBS_K_KMAT);
+    allow_lds(k_kmat, (size_t)(e->D > e->P ? e->D : e->P) * 4);
+    hipLaunchKernelGGL(k_kmat, dim3(e->Mloc), dim3(256), (size_t)e->D * 4, e->stream, pack, (size_t)e->E, (size_t)0,
+                       (int)e->D, e->kz, e->m0, e->M, (float)c.scale_latent, (float)c.h_latent);
+    if (c.joint)
+      hipLaunchKernelGGL(k_kmat, dim3(e->Mloc), dim3(256), (size_t)e->P * 4, e->stream, pack, (size_t)e->E,
+                         (size_t)(2 * e->D), (int)e->P, e->kt, e->m0, e->M, (float)c.scale_theta, (float)c.h_theta);
+  }
+  {
+    KTimer tm(e, DIBS_K_PHI_UPDATE);
+    const size_t lds = (size_t)2 * PHI_TA * e->M * 4;
+    allow_lds(k_phi_update, lds);
+    const int gy = (e->Mloc + PHI_TA - 1) / PHI_TA;
+    hipLaunchKernelGGL(k_phi_update, dim3((unsigned)((e->D + 255) / 256), gy), dim3(256), lds, e->stream, pack, (size_t)e->E,
+                       (size_t)0, (size_t)e->D, (int)e->D, e->kz, e->kt, 0, e->z, e->vz, e->phi_z, e->m0, e->Mloc, e->M,
+                       (float)c.h_latent, (float)c.stepsize, c.optimizer == DIBS_OPT_RMSPROP);
+    if (c.joint)
+      hipLaunchKernelGGL(k_phi_update, dim3((unsigned)((e->P + 255) / 256), gy), dim3(256), lds, e->stream, pack,
+                         (size_t)e->E, (size_t)(2 * e->D), (size_t)(2 * e->D + e->P), (int)e->P, e->kz, e->kt, 1, e->theta,
+                         e->vtheta, e->phi_th, e->m0, e->Mloc, e->M, (float)c.h_theta, (float)c.stepsize,
+                         c.optimizer == DIBS_OPT_RMSPROP);
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(err));
+  return 0;
+}
+
+extern "C" int dibs_engine_run(dibs_engine* e, int32_t t_start, int32_t n_steps) {
+  if (!e) return fail("null engine");
+  if (!e->has_data) return fail("dibs_engine_set_data has not been called");
+  if (e->cfg.n_ranks != 1) return fail("dibs_engine_run is single-rank; use step_local / step_update");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  for (int t = t_start; t < t_start + n_steps; ++t) {
+    if (step_local(e, t, e->pack)) return 1;
+    if (step_update(e, t, e->pack)) return 1;
+    if (e->profiling && e->pending.size() > 4096) drain_timers(e);
+  }
+  HIP_OK(hipStreamSynchronize(e->stream));
+  if (e->profiling) drain_timers(e);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dibs_engine_step_local(dibs_engine* e, int32_t t, void* send_dev) {
+  if (!e || !send_dev) return fail("null argument");
+  if (!e->has_data) return fail("dibs_engine_set_data has not been called");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  // send_dev holds only this rank's rows: [Mloc, E]; kernels index rows by global particle id
+  float* base = (float*)send_dev - (size_t)e->m0 * e->E;
+  return step_local(e, t, base);
+}
+
+extern "C" int dibs_engine_step_update(dibs_engine* e, int32_t t, const void* recv_dev) {
+  if (!e || !recv_dev) return fail("null argument");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  return step_update(e, t, (const float*)recv_dev);
+}
+
+extern "C" int64_t dibs_engine_gather_elems_per_rank(const dibs_engine* e) { return e ? (int64_t)e->Mloc * e->E : 0; }
+
+extern "C" int dibs_engine_sync(dibs_engine* e) {
+  if (!e) return fail("null engine");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  HIP_OK(hipStreamSynchronize(e->stream));
+  if (e->profiling) drain_timers(e);
+  return 0;
+}
+
+extern "C" int64_t dibs_engine_theta_size(const dibs_engine* e) { return e ? e->P : 0; }
+
+struct BufInfo {
+  const void* p;
+  int64_t bytes;
+};
+static BufInfo buf_info(const dibs_engine* e, int which) {
+  const int64_t Ml = e->Mloc, dd = (int64_t)e->d * e->d;
+  switch (which) {
+    case DIBS_BUF_Z: return {e->z, Ml * e->D * 4};
+    case DIBS_BUF_V_Z: return {e->vz, Ml * e->D * 4};
+    case DIBS_BUF_THETA: return {e->theta, Ml * e->P * 4};
+    case DIBS_BUF_V_THETA: return {e->vtheta, Ml * e->P * 4};
+    case DIBS_BUF_SCORES: return {e->scores, Ml * dd * 4};
+    case DIBS_BUF_LOGPROBS_Z: return {e->logprobs_z, Ml * e->S * 4};
+    case DIBS_BUF_LOGPROBS_THETA: return {e->logprobs_th, Ml * e->S * 4};
+    case DIBS_BUF_W_LIK: return {e->w_lik, Ml * dd * 4};
+    case DIBS_BUF_W_ACYC: return {e->w_acyc, Ml * dd * 4};
+    case DIBS_BUF_KXX: return {e->kz, Ml * e->M * 4};
+    case DIBS_BUF_PHI_Z: return {e->phi_z, Ml * e->D * 4};
+    case DIBS_BUF_PHI_THETA: return {e->phi_th, Ml * e->P * 4};
+    case DIBS_BUF_BASELINE: return {e->baseline, Ml * 4};
+    case DIBS_BUF_NODE_SCORES: return {e->node_scores, e->node_scores ? Ml * e->S * e->d * 8 : 0};
+    case DIBS_BUF_PARENT_MASKS: return {e->masks, e->masks ? Ml * e->S * e->d * e->W * 8 : 0};
+    case DIBS_BUF_GATHER: return {e->pack, (int64_t)e->M * e->E * 4};
+    case DIBS_BUF_GRAD_Z: return {nullptr, Ml * e->D * 4};
+    case DIBS_BUF_GRAD_THETA: return {nullptr, Ml * e->P * 4};
+    default: return {nullptr, -1};
+  }
+}
+
+extern "C" int64_t dibs_engine_buffer_bytes(const dibs_engine* e, int32_t which) { return e ? buf_info(e, which).bytes : -1; }
+
+extern "C" int dibs_engine_read_buffer(dibs_engine* e, int32_t which, void* host, int64_t nbytes) {
+  if (!e || !host) return fail("null argument");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  HIP_OK(hipStreamSynchronize(e->stream));
+  const BufInfo bi = buf_info(e, which);
+  if (bi.bytes < 0) return fail("unknown buffer id");
+  if (bi.bytes != nbytes) return fail("buffer size mismatch: expected " + std::to_string(bi.bytes) + " bytes");
+  if (nbytes == 0) return 0;
+  if (which == DIBS_BUF_GRAD_Z || which == DIBS_BUF_GRAD_THETA) {  // strided rows of the packed buffer (single-rank engine buffer)
+    const size_t off = which == DIBS_BUF_GRAD_Z ? (size_t)e->D : (size_t)(2 * e->D + e->P);
+    const size_t w = which == DIBS_BUF_GRAD_Z ? (size_t)e->D * 4 : (size_t)e->P * 4;
+    HIP_OK(hipMemcpy2D(host, w, e->pack + (size_t)e->m0 * e->E + off, (size_t)e->E * 4, w, e->Mloc, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  if (which == DIBS_BUF_KXX && e->kt) {  // kxx = k_z + k_theta
+    std::vector<float> a((size_t)e->Mloc * e->M), b(a.size());
+    HIP_OK(hipMemcpy(a.data(), e->kz, a.size() * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(b.data(), e->kt, a.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < a.size(); ++i) ((float*)host)[i] = a[i] + b[i];
+    return 0;
+  }
+  HIP_OK(hipMemcpy(host, bi.p, nbytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int dibs_engine_set_profiling(dibs_engine* e, int32_t enable) {
+  if (!e) return fail("null engine");
+  hipStreamSynchronize(e->stream);
+  drain_timers(e);
+  e->profiling = enable != 0;
+  return 0;
+}
+
+extern "C" int dibs_engine_reset_timers(dibs_engine* e) {
+  if (!e) return fail("null engine");
+  hipStreamSynchronize(e->stream);
+  drain_timers(e);
+  for (int i = 0; i < DIBS_K_COUNT; ++i) {
+    e->t_ms[i] = 0;
+    e->t_n[i] = 0;
+  }
+  hipMemset(e->counters, 0, 8 * sizeof(unsigned long long));
+  return 0;
+}
+
+extern "C" int dibs_engine_get_timers(dibs_engine* e, double* total_ms, int64_t* launches, int32_t n) {
+  if (!e) return fail("null engine");
+  hipStreamSynchronize(e->stream);
+  drain_timers(e);
+  for (int i = 0; i < n && i < DIBS_K_COUNT; ++i) {
+    if (total_ms) total_ms[i] = e->t_ms[i];
+    if (launches) launches[i] = e->t_n[i];
+  }
+  return 0;
+}
+
+extern "C" int dibs_engine_get_counters(dibs_engine* e, double* out, int32_t n) {
+  if (!e || !out) return fail("null argument");
+  HIP_OK(hipStreamSynchronize(e->stream));
+  unsigned long long h[8];
+  HIP_OK(hipMemcpy(h, e->counters, sizeof h, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n && i < 8; ++i) out[i] = (double)h[i];
+  return 0;
+}
+
+extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* theta, int32_t n, const float* x_ho,
+                                 const int32_t* mask_ho, int32_t n_ho, float* out) {
+  (void)e; (void)g; (void)theta; (void)n; (void)x_ho; (void)mask_ho; (void)n_ho; (void)out;
+  return fail("dibs_score_graphs: not implemented yet");
+}

@@ -1,0 +1,136 @@
+// Counter-based PRNG for the engine: Threefry-2x32-20 and the JAX layering the reference relies on
+// (jax.random.split / bits / uniform / normal / bernoulli / logistic; call sites:
+//  dibs/inference/svgd.py:145-146,245,251,294,509-513,695-703 and dibs/inference/dibs.py:115,350,431,595).
+// Host+device so the host can advance the loop-carry key while kernels derive per-particle keys.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DIBS_HD __host__ __device__ __forceinline__
+
+struct Key2 {
+  uint32_t a, b;
+};
+
+DIBS_HD uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+DIBS_HD void threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t& o0, uint32_t& o1) {
+  const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
+  uint32_t x0 = c0 + k0, x1 = c1 + k1;
+#define TF_R(r) x0 += x1; x1 = rotl32(x1, r); x1 ^= x0;
+  TF_R(13) TF_R(15) TF_R(26) TF_R(6)
+  x0 += k1; x1 += k2 + 1u;
+  TF_R(17) TF_R(29) TF_R(16) TF_R(24)
+  x0 += k2; x1 += k0 + 2u;
+  TF_R(13) TF_R(15) TF_R(26) TF_R(6)
+  x0 += k0; x1 += k1 + 3u;
+  TF_R(17) TF_R(29) TF_R(16) TF_R(24)
+  x0 += k1; x1 += k2 + 4u;
+  TF_R(13) TF_R(15) TF_R(26) TF_R(6)
+  x0 += k2; x1 += k0 + 5u;
+#undef TF_R
+  o0 = x0;
+  o1 = x1;
+}
+
+// element i of random_bits(key, n).  layout 0 = legacy (counts split in halves, concat(y0, y1)),
+// 1 = partitionable (counter (hi, lo) = i, y0 ^ y1).
+DIBS_HD uint32_t rng_bits_at(Key2 key, uint64_t n, uint64_t i, int layout) {
+  uint32_t y0, y1;
+  if (layout == 1) {
+    threefry2x32(key.a, key.b, (uint32_t)(i >> 32), (uint32_t)i, y0, y1);
+    return y0 ^ y1;
+  }
+  const uint64_t half = (n + 1) / 2;
+  const uint64_t c = i < half ? i : i - half;
+  uint32_t c1 = (uint32_t)(half + c);
+  if ((n & 1) && c == half - 1) c1 = 0;
+  threefry2x32(key.a, key.b, (uint32_t)c, c1, y0, y1);
+  return i < half ? y0 : y1;
+}
+
+// the two elements c and c + n/2 of random_bits(key, n) for EVEN n (one Threefry call in the legacy layout)
+DIBS_HD void rng_bits_pair(Key2 key, uint64_t n, uint64_t c, int layout, uint32_t& lo, uint32_t& hi) {
+  const uint64_t half = n >> 1;
+  if (layout == 1) {
+    uint32_t y0, y1;
+    threefry2x32(key.a, key.b, (uint32_t)(c >> 32), (uint32_t)c, y0, y1);
+    lo = y0 ^ y1;
+    const uint64_t c2 = c + half;
+    threefry2x32(key.a, key.b, (uint32_t)(c2 >> 32), (uint32_t)c2, y0, y1);
+    hi = y0 ^ y1;
+  } else {
+    threefry2x32(key.a, key.b, (uint32_t)c, (uint32_t)(half + c), lo, hi);
+  }
+}
+
+// row r of jax.random.split(key, num)
+DIBS_HD Key2 rng_split_row(Key2 key, uint32_t num, uint32_t r, int layout) {
+  Key2 o;
+  if (layout == 1) {
+    threefry2x32(key.a, key.b, 0u, r, o.a, o.b);
+    return o;
+  }
+  o.a = rng_bits_at(key, 2ull * num, 2ull * r, 0);
+  o.b = rng_bits_at(key, 2ull * num, 2ull * r + 1, 0);
+  return o;
+}
+
+DIBS_HD float rng_unit_float(uint32_t bits) {
+  union {
+    uint32_t u;
+    float f;
+  } v;
+  v.u = (bits >> 9) | 0x3F800000u;
+  return v.f - 1.0f;
+}
+
+// correctly-rounded single ops that the compiler may not contract into an fma
+DIBS_HD float dibs_fmul(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __fmul_rn(a, b);
+#else
+  volatile float r = a * b;
+  return r;
+#endif
+}
+DIBS_HD float dibs_fadd(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __fadd_rn(a, b);
+#else
+  volatile float r = a + b;
+  return r;
+#endif
+}
+#define DIBS_FMUL(a, b) dibs_fmul(a, b)
+#define DIBS_FADD(a, b) dibs_fadd(a, b)
+
+// jax.random.uniform(minval=lo, maxval=hi): max(lo, floats * (hi - lo) + lo), two roundings (no fma)
+DIBS_HD float rng_uniform(uint32_t bits, float lo, float hi) {
+  const float v = DIBS_FADD(DIBS_FMUL(rng_unit_float(bits), hi - lo), lo);
+  return v > lo ? v : lo;
+}
+
+// jax.random.logistic: x = uniform(eps|tiny, 1); log(x / (1 - x))
+__device__ __forceinline__ float rng_logistic(uint32_t bits, int tiny) {
+  const float lo = tiny ? 1.17549435e-38f : 1.1920929e-07f;
+  const float x = rng_uniform(bits, lo, 1.0f);
+  return logf(x / (1.0f - x));
+}
+
+// jax.random.normal: sqrt(2) * erfinv(uniform(nextafter(-1, 0), 1)); erfinv = Giles' single-precision
+// polynomial (the form XLA lowers lax.erf_inv(f32) to)
+__device__ __forceinline__ float rng_normal(uint32_t bits) {
+  const float x = rng_uniform(bits, -0.99999994f, 1.0f);
+  float w = (float)(-log1p((double)DIBS_FMUL(-x, x)));
+  const bool lt = w < 5.0f;
+  w = lt ? w - 2.5f : sqrtf(w) - 3.0f;
+  const float A[9] = {2.81022636e-08f, 3.43273939e-07f, -3.5233877e-06f, -4.39150654e-06f, 0.00021858087f,
+                      -0.00125372503f, -0.00417768164f, 0.246640727f, 1.50140941f};
+  const float B[9] = {-0.000200214257f, 0.000100950558f, 0.00134934322f, -0.00367342844f, 0.00573950773f,
+                      -0.0076224613f, 0.00943887047f, 1.00167406f, 2.83297682f};
+  float p = lt ? A[0] : B[0];
+#pragma unroll
+  for (int i = 1; i < 9; ++i) p = DIBS_FADD(lt ? A[i] : B[i], DIBS_FMUL(p, w));
+  return DIBS_FMUL(1.41421354f, DIBS_FMUL(p, x));
+}

@@ -1,0 +1,104 @@
+"""Thin object wrapper over the C ABI (include/dibs_hip.h): one Engine = one device + one stream."""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._abi import BUF, K_COUNT, KERNELS, DibsConfig
+
+_BUF_DTYPE = {"NODE_SCORES": np.float64, "PARENT_MASKS": np.uint64}
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    def __init__(self, cfg: DibsConfig, stream=None):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        _lib.check(self.lib.dibs_engine_create(C.byref(cfg), C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.M, self.d, self.k = cfg.n_particles, cfg.n_vars, cfg.n_dim
+        self.Mloc = cfg.n_particles // cfg.n_ranks
+        self.P = int(self.lib.dibs_engine_theta_size(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.dibs_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_data(self, x, interv_mask=None, bge_mean_obs=None):
+        x = np.ascontiguousarray(x, np.float32)
+        assert x.shape == (self.cfg.n_observations, self.d), x.shape
+        m = None if interv_mask is None else np.ascontiguousarray(interv_mask, np.int32)
+        mo = None if bge_mean_obs is None else np.ascontiguousarray(bge_mean_obs, np.float32)
+        _lib.check(self.lib.dibs_engine_set_data(self._h, _ptr(x), _ptr(m), _ptr(mo)))
+
+    def init_particles(self, key):
+        key = np.ascontiguousarray(key, np.uint32).reshape(2)
+        _lib.check(self.lib.dibs_engine_init_particles(self._h, _ptr(key)))
+
+    def set_state(self, z=None, v_z=None, theta=None, v_theta=None, key=None, baseline=None):
+        f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+        z, v_z, theta, v_theta, baseline = f(z), f(v_z), f(theta), f(v_theta), f(baseline)
+        key = None if key is None else np.ascontiguousarray(key, np.uint32)
+        _lib.check(self.lib.dibs_engine_set_state(self._h, _ptr(z), _ptr(v_z), _ptr(theta), _ptr(v_theta), _ptr(key),
+                                                  _ptr(baseline)))
+
+    def get_state(self):
+        z = np.empty((self.Mloc, self.d, self.k, 2), np.float32)
+        v_z = np.empty_like(z)
+        theta = np.empty((self.Mloc, self.P), np.float32) if self.P else None
+        v_theta = np.empty_like(theta) if self.P else None
+        key = np.empty(2, np.uint32)
+        baseline = np.empty(self.Mloc, np.float32)
+        _lib.check(self.lib.dibs_engine_get_state(self._h, _ptr(z), _ptr(v_z), _ptr(theta), _ptr(v_theta), _ptr(key),
+                                                  _ptr(baseline)))
+        return dict(z=z, v_z=v_z, theta=theta, v_theta=v_theta, key=key, baseline=baseline)
+
+    def run(self, t_start, n_steps):
+        _lib.check(self.lib.dibs_engine_run(self._h, int(t_start), int(n_steps)))
+
+    def step_local(self, t, send_ptr):
+        _lib.check(self.lib.dibs_engine_step_local(self._h, int(t), C.c_void_p(send_ptr)))
+
+    def step_update(self, t, recv_ptr):
+        _lib.check(self.lib.dibs_engine_step_update(self._h, int(t), C.c_void_p(recv_ptr)))
+
+    def gather_elems_per_rank(self):
+        return int(self.lib.dibs_engine_gather_elems_per_rank(self._h))
+
+    def sync(self):
+        _lib.check(self.lib.dibs_engine_sync(self._h))
+
+    def read(self, name):
+        nbytes = int(self.lib.dibs_engine_buffer_bytes(self._h, BUF[name]))
+        if nbytes < 0:
+            raise KeyError(name)
+        dt = _BUF_DTYPE.get(name, np.float32)
+        out = np.empty(nbytes // np.dtype(dt).itemsize, dt)
+        _lib.check(self.lib.dibs_engine_read_buffer(self._h, BUF[name], _ptr(out), nbytes))
+        return out
+
+    def set_profiling(self, on):
+        _lib.check(self.lib.dibs_engine_set_profiling(self._h, int(bool(on))))
+
+    def reset_timers(self):
+        _lib.check(self.lib.dibs_engine_reset_timers(self._h))
+
+    def timers(self):
+        ms = np.zeros(K_COUNT, np.float64)
+        n = np.zeros(K_COUNT, np.int64)
+        _lib.check(self.lib.dibs_engine_get_timers(self._h, _ptr(ms), _ptr(n), K_COUNT))
+        return {KERNELS[i]: (float(ms[i]), int(n[i])) for i in range(K_COUNT) if n[i]}
+
+    def counters(self):
+        out = np.zeros(8, np.float64)
+        _lib.check(self.lib.dibs_engine_get_counters(self._h, _ptr(out), 8))
+        return out
