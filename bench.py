@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""SVGD steps/sec of the DiBS hot path on MI355X (BASELINE.json metric: d=50, n_particles=128, BGe).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one SVGD step (svgd.py:226-267 of the reference) over all 128 particles on synthetic ER-2
+linear-Gaussian data that is resident in HBM before the timed region.  N > 1 shards the particles over the
+ranks (strong scaling: total work fixed) with one RCCL all-gather of [z | grad_z] per step.
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D_VARS, N_PARTICLES, N_OBS, S_MC, SA_MC = 50, 128, 100, 128, 32
+PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def binary_powering_matmuls(n):
+    return (n.bit_length() - 1) + (bin(n).count("1") - 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    K, W, N = args.steps, args.warmup, args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != N:
+        raise SystemExit(f"--gpus {N} but WORLD_SIZE={world}")
+
+    import torch
+    from dibs_amd import random
+    from dibs_amd._abi import make_config
+    from dibs_amd.engine import Engine
+    from dibs_amd.target import make_linear_gaussian_equivalent_model
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if N > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    data, _, _ = make_linear_gaussian_equivalent_model(key=random.PRNGKey(0), n_vars=D_VARS, graph_prior_str="er",
+                                                       n_observations=N_OBS)
+    cfg = make_config(n_vars=D_VARS, n_particles=N_PARTICLES, n_observations=N_OBS, n_grad_mc_samples=S_MC,
+                      n_acyclicity_mc_samples=SA_MC, rank=rank, n_ranks=N, device_id=local_rank)
+    stream = torch.cuda.current_stream().cuda_stream if N > 1 else None
+    eng = Engine(cfg, stream=stream)
+    eng.set_data(data.x)
+    eng.init_particles(random.PRNGKey(1))
+
+    if N > 1:
+        n_loc = eng.gather_elems_per_rank()
+        send = torch.zeros(n_loc, dtype=torch.float32, device="cuda")
+        recv = torch.zeros(n_loc * N, dtype=torch.float32, device="cuda")
+
+        def run(t0, n):
+            for t in range(t0, t0 + n):
+                eng.step_local(t, send.data_ptr())
+                dist.all_gather_into_tensor(recv, send)
+                eng.step_update(t, recv.data_ptr())
+    else:
+        def run(t0, n):
+            eng.run(t0, n)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(0, W)                       # untimed warm-up: steps 0 .. W-1 of the trajectory
+    fence()
+    t_begin = time.perf_counter()
+    run(W, K)                       # timed: steps W .. W+K-1
+    fence()
+    elapsed = time.perf_counter() - t_begin
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    steps_per_s = K / elapsed
+
+    out = {
+        "metric": "SVGD steps/sec (d=50, n_particles=128, BGe)", "value": steps_per_s, "unit": "steps/s", "n_gpus": N,
+        "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
+        "scaling": "strong" if N > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "MarginalDiBS+BGe (score-function estimator), Erdos-Renyi-2 linear-Gaussian data",
+                   "n_vars": D_VARS, "n_particles": N_PARTICLES, "n_observations": N_OBS, "n_grad_mc_samples": S_MC,
+                   "n_acyclicity_mc_samples": SA_MC, "timed_steps": f"t={W}..{W + K - 1} of one trajectory from PRNGKey(1)",
+                   "parallelism": f"particles sharded over {N} rank(s), 1 all-gather/step" if N > 1 else "single GPU"},
+    }
+
+    if rank == 0 and N == 1:
+        # ---- roofline of the dominant kernel: same K steps replayed with per-kernel HIP events ----
+        eng.init_particles(random.PRNGKey(1))
+        eng.run(0, W)
+        eng.set_profiling(True)
+        eng.reset_timers()
+        eng.run(W, K)
+        timers = eng.timers()
+        bge_flops = float(eng.counters()[0])  # executed Cholesky flops (sum n^3/3 over all sampled parent sets)
+        eng.set_profiling(False)
+        total_ms = sum(ms for ms, _ in timers.values())
+        dom = max(timers, key=lambda k_: timers[k_][0])
+        dom_ms, dom_n = timers[dom]
+        avg_s = dom_ms / dom_n * 1e-3
+        dense_bge = N_PARTICLES * S_MC * D_VARS * 2 * D_VARS ** 3 / 3.0
+        acyc_flops = N_PARTICLES * SA_MC * binary_powering_matmuls(D_VARS - 1) * 2 * D_VARS ** 3
+        per_launch = {"bge_nodes": bge_flops / max(dom_n, 1) if dom == "bge_nodes" else None, "acyc": acyc_flops}
+        flops = per_launch.get(dom)
+        roof = {"kernel": dom, "bound": "mfma", "pipe": "valu_f32" if dom == "bge_nodes" else "mfma_f32",
+                "avg_launch_us": avg_s * 1e6, "launches": dom_n, "share_of_step": dom_ms / total_ms,
+                "unit": "TFLOP/s", "peak": PEAK_F32_TFLOPS, "traffic": None}
+        if flops:
+            roof["achieved"] = flops / avg_s / 1e12
+            roof["frac"] = roof["achieved"] / PEAK_F32_TFLOPS
+            roof["flops_per_launch"] = flops
+            if dom == "bge_nodes":
+                roof["flops_model"] = "executed: sum over sampled parent sets of (l+1)^3/3 (compact Cholesky)"
+                roof["dense_equivalent_tflops"] = dense_bge / avg_s / 1e12  # SURVEY 8(d) count: masked d x d LU, twice
+        else:
+            roof["achieved"], roof["frac"] = None, None
+        out["roofline"] = roof
+        bytes_step = 16.0 * N_PARTICLES * (2 * D_VARS * D_VARS)
+        out["hbm_algorithmic"] = {"bytes_per_step": bytes_step, "achieved_GBps": bytes_step * steps_per_s / 1e9,
+                                  "frac_of_8TBps": bytes_step * steps_per_s / 1e9 / PEAK_HBM_GBPS}
+        out["kernel_us_per_step"] = {k_: ms / K * 1e3 for k_, (ms, n_) in timers.items()}
+
+        if not args.no_cpu_baseline:
+            # ---- CPU baseline: the oracle's C port on this box's host cores, bounded sample ----
+            from oracle.c_oracle import COracle
+            cores = os.cpu_count() or 1
+            co = COracle("f64")
+            cfg1 = make_config(n_vars=D_VARS, n_particles=N_PARTICLES, n_observations=N_OBS, n_grad_mc_samples=S_MC,
+                               n_acyclicity_mc_samples=SA_MC)
+            st = co.new_state(cfg1, random.PRNGKey(1))
+            t0 = time.perf_counter()
+            co.run(cfg1, data.x, None, st, 0, 2, bge_mode=0, n_threads=cores)   # the reference's masked d x d slogdet
+            faithful = 2 / (time.perf_counter() - t0)
+            st = co.new_state(cfg1, random.PRNGKey(1))
+            t0 = time.perf_counter()
+            co.run(cfg1, data.x, None, st, 0, 8, bge_mode=1, n_threads=cores)   # same compact Cholesky as the GPU
+            compact = 8 / (time.perf_counter() - t0)
+            out["cpu_baseline"] = {"value": faithful, "unit": "steps/s", "cores": cores, "kind": "port",
+                                   "sample": "2 steps (t=0,1) of the same workload, f64 C port of the reference algorithm "
+                                             "(masked d x d LU slogdet per node, as func.py:128-145), OpenMP over particles"}
+            out["cpu_baseline_compact"] = {"value": compact, "unit": "steps/s", "cores": cores, "kind": "port",
+                                           "sample": "8 steps (t=0..7), same C port with the GPU's compact parent-set Cholesky"}
+    eng.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,128 @@
+"""Host-side logic of the drop-in facade (no GPU): constructor contract, error behaviour, metrics, factories."""
+import numpy as np
+import pytest
+
+from conftest import make_data
+from dibs_amd import random
+from dibs_amd.graph_utils import acyclic_constr_nograd, mat_is_dag
+from dibs_amd.inference import JointDiBS, MarginalDiBS
+from dibs_amd.metrics import ParticleDistribution, expected_edges, expected_shd, pairwise_structural_hamming_distance, \
+    threshold_metrics
+from dibs_amd.models import BGe, DenseNonlinearGaussian, ErdosReniDAGDistribution, LinearGaussian, \
+    ScaleFreeDAGDistribution
+
+
+def test_constructor_defaults_match_reference():
+    data, gm, lm = make_data(6, edges_per_node=1)
+    m = MarginalDiBS(x=data.x, graph_model=gm, likelihood_model=lm)  # svgd.py:60-83
+    assert (m.kernel.h, m.optimizer, m.optimizer_param, m.grad_estimator_z) == (5.0, "rmsprop", {"stepsize": 0.005}, "score")
+    assert m.alpha(3) == 3.0 and m.n_grad_mc_samples == 128 and m.n_acyclicity_mc_samples == 32
+    assert m.interv_mask.shape == data.x.shape and not m.interv_mask.any()
+    dataj, gmj, lmj = make_data(6, edges_per_node=1, joint=True)
+    j = JointDiBS(x=dataj.x, graph_model=gmj, likelihood_model=lmj)  # svgd.py:425-448
+    assert (j.kernel.h_latent, j.kernel.h_theta, j.grad_estimator_z) == (5.0, 500.0, "reparam")
+    assert abs(j.alpha(10) - 0.5) < 1e-12
+    cfg = j._make_config(8, None)
+    assert (cfg.joint, cfg.likelihood, cfg.grad_estimator_z, cfg.n_dim) == (1, 1, 1, 6)
+
+
+def test_error_behaviour():
+    data, gm, lm = make_data(6, edges_per_node=1)
+    with pytest.raises(ValueError):  # svgd.py:122
+        MarginalDiBS(x=data.x, graph_model=gm, likelihood_model=lm, optimizer="adam")
+    with pytest.raises(NotImplementedError):
+        MarginalDiBS(x=data.x, graph_model=gm, likelihood_model=LinearGaussian(n_vars=6))
+    with pytest.raises(NotImplementedError):  # JointDiBS + BGe is not constructible in the reference either
+        JointDiBS(x=data.x, graph_model=gm, likelihood_model=lm)
+    with pytest.raises(NotImplementedError):
+        MarginalDiBS(x=data.x, graph_model=object(), likelihood_model=lm)
+    with pytest.raises(NotImplementedError):  # linearGaussian.py:53-54
+        lm.sample_parameters(key=random.PRNGKey(0), n_vars=6)
+    with pytest.raises(KeyError):  # nonlinearGaussian.py:61
+        DenseNonlinearGaussian(n_vars=4, hidden_layers=(5,), activation="gelu")
+    with pytest.raises(AssertionError):  # linearGaussian.py:47
+        BGe(n_vars=5, alpha_lambd=5.5)
+    m = MarginalDiBS(x=data.x, graph_model=gm, likelihood_model=lm, grad_estimator_z="nope")
+    with pytest.raises(ValueError):  # dibs.py:318
+        m._make_config(4, None)
+
+
+def test_particle_to_g_lim_and_edge_probs():
+    data, gm, lm = make_data(5)
+    m = MarginalDiBS(x=data.x, graph_model=gm, likelihood_model=lm)
+    z = random.normal(random.PRNGKey(0), (3, 5, 5, 2))
+    g = m.particle_to_g_lim(z)
+    s = np.einsum("mik,mjk->mij", z[..., 0], z[..., 1])
+    assert g.dtype == np.int32 and (np.diagonal(g, axis1=1, axis2=2) == 0).all()
+    off = ~np.eye(5, dtype=bool)
+    assert np.array_equal(g[:, off], (s > 0)[:, off].astype(np.int32))
+    p = m.edge_probs(z, 4)
+    assert np.allclose(p[:, off], 1 / (1 + np.exp(-4 * s[:, off])), atol=1e-6) and (np.diagonal(p, axis1=1, axis2=2) == 0).all()
+
+
+def test_shd_and_expected_shd():
+    g = np.zeros((4, 4), np.int32)
+    g[0, 1] = g[1, 2] = 1
+    a = g.copy()
+    a[0, 1], a[1, 0] = 0, 1  # a reversal counts once
+    b = g.copy()
+    b[2, 3] = 1  # an insertion
+    assert pairwise_structural_hamming_distance(x=np.stack([a, b, g]), y=g[None]).squeeze(1).tolist() == [1, 1, 0]
+    cyc = np.zeros((4, 4), np.int32)
+    cyc[0, 1] = cyc[1, 0] = 1
+    dist = ParticleDistribution(logp=np.log([0.25, 0.25, 0.25, 0.25]), g=np.stack([a, b, g, cyc]))
+    assert abs(expected_shd(dist=dist, g=g) - (1 + 1 + 0) / 3) < 1e-12  # cyclic particle dropped, weights renormalised
+    assert abs(expected_edges(dist=dist) - (2 + 3 + 2) / 3) < 1e-12
+    allcyc = ParticleDistribution(logp=np.log([1.0]), g=cyc[None])
+    assert expected_shd(dist=allcyc, g=g) == 4 * 3 / 2
+    tm = threshold_metrics(dist=dist, g=g)
+    assert 0.5 <= tm["roc_auc"] <= 1.0
+
+
+def test_acyclicity_f32_filter_matches_reference_semantics():
+    d = 20
+    chain = np.zeros((d, d), np.float32)
+    for i in range(d - 1):
+        chain[i, i + 1] = 1
+    assert acyclic_constr_nograd(chain, d) == 0 and mat_is_dag(chain)
+    two = chain.copy()
+    two[1, 0] = 1
+    assert acyclic_constr_nograd(two, d) > 0 and not mat_is_dag(two)
+    # a single long cycle falls below float32 resolution -> counted as a DAG, like the reference
+    ring = chain.copy()
+    ring[d - 1, 0] = 1
+    assert not mat_is_dag(ring) and acyclic_constr_nograd(ring, d) == 0
+
+
+def test_graph_models_and_factories():
+    er = ErdosReniDAGDistribution(20, n_edges_per_node=2)
+    assert abs(er.p - 40 / 190) < 1e-12
+    g = er.sample_G(random.PRNGKey(0))
+    assert mat_is_dag(g) and g.shape == (20, 20)
+    soft = np.full((20, 20), 0.3)
+    e = soft.sum()
+    assert abs(er.unnormalized_log_prob_soft(soft_g=soft) - (e * np.log(er.p) + (190 - e) * np.log(1 - er.p))) < 1e-9
+    sf = ScaleFreeDAGDistribution(20)
+    gs = sf.sample_G(random.PRNGKey(1))
+    assert mat_is_dag(gs) and gs.sum() >= 19
+    assert abs(sf.unnormalized_log_prob_soft(soft_g=soft) - np.sum(-3 * np.log(1 + soft.sum(0)))) < 1e-9
+    data, gm, lm = make_data(12, joint=True)
+    assert data.x.shape == (100, 12) and data.x_ho.shape == (100, 12) and len(data.x_interv) == 10
+    interv, xi = data.x_interv[0]
+    assert len(interv) == 2 and all(np.all(xi[:, k] == 0) for k in interv)
+    # a data set is a deterministic function of its key
+    data2, _, _ = make_data(12, joint=True)
+    assert np.array_equal(data.x, data2.x) and np.array_equal(data.g, data2.g)
+
+
+def test_lingauss_sample_parameters_stream():
+    lm = LinearGaussian(n_vars=4)
+    th = lm.sample_parameters(key=random.PRNGKey(3), n_vars=4, n_particles=5)
+    raw = random.normal(random.PRNGKey(3), (5, 4, 4))
+    assert th.shape == (5, 4, 4) and np.allclose(th, raw + np.sign(raw) * 0.5) and np.abs(th).min() >= 0.5
+    nn = DenseNonlinearGaussian(n_vars=4, hidden_layers=(3,))
+    tree = nn.sample_parameters(key=random.PRNGKey(4), n_vars=4, n_particles=2)
+    assert tree[0][0].shape == (2, 4, 4, 3) and tree[0][1].shape == (2, 4, 3) and tree[1] == () and tree[2][0].shape == (2, 4, 3, 1)
+    flat = nn.tree_to_flat(tree)
+    back = nn.flat_to_tree(flat, 4)
+    assert flat.shape == (2, 4 * 4 * 3 + 4 * 3 + 4 * 3 + 4) and np.array_equal(back[2][1], tree[2][1])
