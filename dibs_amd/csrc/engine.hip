@@ -91,7 +91,7 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
   *out = nullptr;
   const dibs_config& c = *cfg;
   if (c.abi_version != DIBS_ABI_VERSION) return fail("dibs_config.abi_version mismatch");
-  if (c.n_vars < 2 || c.n_vars > 128) return fail("n_vars must be in [2, 128]");
+  if (c.n_vars < 2 || c.n_vars > 112) return fail("n_vars must be in [2, 112]");
   if (c.n_dim < 1) return fail("n_dim must be >= 1");
   if (c.n_particles < 1 || c.n_grad_mc_samples < 1 || c.n_acyclicity_mc_samples < 1) return fail("sizes must be >= 1");
   if (c.n_ranks < 1 || c.rank < 0 || c.rank >= c.n_ranks) return fail("bad rank / n_ranks");
@@ -468,8 +468,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
       case 4: launch_acyc<4>(e, carry_prior, alpha); break;
       case 5: launch_acyc<5>(e, carry_prior, alpha); break;
       case 6: launch_acyc<6>(e, carry_prior, alpha); break;
-      case 7: launch_acyc<7>(e, carry_prior, alpha); break;
-      default: launch_acyc<8>(e, carry_prior, alpha); break;
+      default: launch_acyc<7>(e, carry_prior, alpha); break;
     }
   }
   {

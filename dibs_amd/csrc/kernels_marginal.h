@@ -323,25 +323,35 @@ __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restr
 //     reference: graph_utils.py:8-28, dibs.py:121-140, 557-601
 // grid = (ceil(Sa / CPB), Mloc), block = 256; dynamic LDS = 3 * DP * LD * 4, DP = 16 NT, LD = DP + 2
 // ------------------------------------------------------------------------------------------------
+// C = A * B on DP x DP tiles held in dynamic LDS.  Operands are addressed as OFFSETS (in floats) into the
+// kernel's LDS array so that every access is a ds_read / ds_write (a runtime-selected generic pointer would turn
+// them into flat accesses).
 template <int NT>
-__device__ __forceinline__ void lds_matmul(float* __restrict__ C, const float* __restrict__ A, const float* __restrict__ B,
-                                           int kp, int lane, int wave) {
+__device__ __forceinline__ void lds_matmul(float* __restrict__ lds, int c_off, int a_off, int b_off, int kp, int lane,
+                                           int wave) {
   constexpr int DP = 16 * NT, LD = DP + 2;
   for (int ti = wave; ti < NT; ti += 4) {
     f32x4 acc[NT];
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj) acc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* ap = A + (size_t)(ti * 16 + (lane & 15)) * LD + (lane >> 4);
-    const float* bpn = B + (size_t)(lane >> 4) * LD + (lane & 15);
+    const int ap = a_off + (ti * 16 + (lane & 15)) * LD + (lane >> 4);
+    const int bq = b_off + (lane >> 4) * LD + (lane & 15);
     for (int k0 = 0; k0 < kp; k0 += 4) {
-      const float a = ap[k0];
+      const float a = lds[ap + k0];
 #pragma unroll
-      for (int tj = 0; tj < NT; ++tj) acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bpn[(size_t)k0 * LD + tj * 16], acc[tj], 0, 0, 0);
+      for (int tj = 0; tj < NT; ++tj)
+        acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, lds[bq + k0 * LD + tj * 16], acc[tj], 0, 0, 0);
     }
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) C[(size_t)(ti * 16 + (lane >> 4) * 4 + r) * LD + tj * 16 + (lane & 15)] = acc[tj][r];
+      for (int r = 0; r < 4; ++r) {
+        // Force the MFMA result through a VGPR: hipcc (ROCm 7.2) otherwise emits `ds_write_b32 vaddr, aN` (AGPR data
+        // operand) for part of the tile, which stored wrong values on gfx950 (scripts/probe/acyc_probe.hip, variant 3).
+        float tmp = acc[tj][r];
+        asm volatile("" : "+v"(tmp));
+        lds[c_off + (ti * 16 + (lane >> 4) * 4 + r) * LD + tj * 16 + (lane & 15)] = tmp;
+      }
   }
 }
 
@@ -349,11 +359,8 @@ template <int NT>
 __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, float* __restrict__ part, Key2 carry, int m0,
                                               int M_global, int d, int Sa, int cpb, float alpha, float tau, int layout,
                                               int tiny) {
-  constexpr int DP = 16 * NT, LD = DP + 2;
+  constexpr int DP = 16 * NT, LD = DP + 2, BUF = DP * LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Mb = smem;
-  float* X = smem + (size_t)DP * LD;
-  float* Y = X + (size_t)DP * LD;
   const int blk = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Key2 km = rng_split_row(carry, (uint32_t)M_global + 1u, (uint32_t)(m0 + m) + 1u, layout);  // dibs.py:595: key used directly
   const uint64_t dd = (uint64_t)d * d, nbits = (uint64_t)Sa * dd;
@@ -369,7 +376,8 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
     const int sa = blk * cpb + c;
     if (sa >= Sa) break;
     __syncthreads();
-    for (int e = tid; e < DP * LD; e += 256) {
+    // buffer 0: M = I + G~/d  (zero padded)
+    for (int e = tid; e < BUF; e += 256) {
       const int i = e / LD, jj = e - i * LD;
       float v = 0.f;
       if (i < d && jj < d) {
@@ -380,35 +388,35 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
           v = g * inv_d;
         }
       }
-      Mb[e] = v;
+      smem[e] = v;
     }
     __syncthreads();
-    // left-to-right binary powering of e = d - 1
+    // left-to-right binary powering of e = d - 1; the running power ping-pongs between buffers 1 and 2
     const int ex = d - 1;
-    const float* cur = Mb;
+    int cur = 0;
     if (ex >= 1) {
-      int hb = 31 - __builtin_clz((unsigned)ex);
+      const int hb = 31 - __builtin_clz((unsigned)ex);
       for (int b = hb - 1; b >= 0; --b) {
-        float* dst = (cur == X) ? Y : X;
-        lds_matmul<NT>(dst, cur, cur, kp, lane, wave);
+        int dst = (cur == BUF) ? 2 * BUF : BUF;
+        lds_matmul<NT>(smem, dst, cur, cur, kp, lane, wave);
         __syncthreads();
         cur = dst;
         if ((ex >> b) & 1) {
-          dst = (cur == X) ? Y : X;
-          lds_matmul<NT>(dst, cur, Mb, kp, lane, wave);
+          dst = (cur == BUF) ? 2 * BUF : BUF;
+          lds_matmul<NT>(smem, dst, cur, 0, kp, lane, wave);
           __syncthreads();
           cur = dst;
         }
       }
     }
-    // out[i][j] += cur[j][i] * tau * alpha * g (1 - g),  g = d * M[i][j]  (i != j)
+    // out[i][j] += (M^{d-1})[j][i] * tau * alpha * g (1 - g),  g = d * M[i][j]  (i != j)
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
       const int e = tid + q * 256;
       const int i = e / DP, jj = e - i * DP;
       if (i < d && jj < d && i != jj) {
-        const float g = Mb[(size_t)i * LD + jj] * (float)d;
-        const float pw = (ex == 0) ? (i == jj ? 1.f : 0.f) : cur[(size_t)jj * LD + i];
+        const float g = smem[i * LD + jj] * (float)d;
+        const float pw = smem[cur + jj * LD + i];
         out[q] += pw * tau * alpha * g * (1.0f - g);
       }
     }

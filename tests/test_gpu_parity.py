@@ -83,7 +83,8 @@ def test_marginal_bge_step_stages(c_oracle64, d, M, S, Sa, prior, steps):
         assert np.array_equal(gg, dbg["g_samples"]), "sampled graphs must be bit-identical"
         assert (g["key"] == st["key"]).all()
         assert rel_err(eng.read("SCORES"), dbg["scores"]) < 2e-6
-        assert rel_err(eng.read("NODE_SCORES"), dbg["node_scores"]) < 1e-4
+        # fp32 Cholesky pivots: the log-det error is multiplied by (N + alpha_lambd - d + l) / 2 ~ 50-90
+        assert rel_err(eng.read("NODE_SCORES"), dbg["node_scores"]) < (1e-4 if d <= 50 else 5e-4)
         assert rel_err(eng.read("LOGPROBS_Z"), dbg["logprobs_z"]) < 2e-5
         assert rel_err(eng.read("W_LIK"), dbg["w_lik"]) < 2e-3
         assert rel_err(eng.read("W_ACYC"), dbg["w_acyc"]) < 1e-5
