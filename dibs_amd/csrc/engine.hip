@@ -6,6 +6,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <utility>
 
 #include "../../include/dibs_hip.h"
 #include "kernels_marginal.h"
@@ -32,7 +33,7 @@ struct dibs_engine {
   hipStream_t stream;
   bool own_stream;
   // state
-  float *z, *vz, *theta, *vtheta, *baseline;
+  float *z, *vz, *theta, *vtheta, *baseline, *baseline2;
   Key2 key;
   // data
   float* x;
@@ -165,6 +166,7 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
   HIP_OK(dalloc(&e->theta, Ml * e->P));
   HIP_OK(dalloc(&e->vtheta, Ml * e->P));
   HIP_OK(dalloc(&e->baseline, Ml));
+  HIP_OK(dalloc(&e->baseline2, Ml));
   HIP_OK(dalloc(&e->scores, Ml * dd));
   HIP_OK(dalloc(&e->thr, Ml * dd));
   HIP_OK(dalloc(&e->w_lik, Ml * dd));
@@ -193,7 +195,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (!e) return 0;
   hipSetDevice(e->cfg.device_id);
   hipStreamSynchronize(e->stream);
-  void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->scores, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
+  void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
                   e->node_scores, e->x, e->mask, e->R, e->gam, e->Nj};
   for (void* p : ptrs)
@@ -431,19 +433,30 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     {
       KTimer tm(e, DIBS_K_BGE_NODES);
       BgeParams bp{e->R, e->gam, e->Nj, e->alpha_lambd, e->n_mats};
-      allow_lds(k_bge_nodes, bge_lds_bytes(e->d, e->S, e->W));
-      hipLaunchKernelGGL(k_bge_nodes, dim3(e->d, e->Mloc), dim3(64), bge_lds_bytes(e->d, e->S, e->W), e->stream, e->thr,
-                         e->masks, e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L,
-                         e->profiling ? e->counters : (unsigned long long*)nullptr);
+      unsigned long long* cnt = e->profiling ? e->counters : (unsigned long long*)nullptr;
+      const size_t lds4 = bge_lds_bytes(e->d, e->S, e->W, 4), lds1 = bge_lds_bytes(e->d, e->S, e->W, 1);
+      if (e->n_mats == 1 && lds4 <= 80 * 1024) {
+        allow_lds(k_bge_nodes<4>, lds4);
+        hipLaunchKernelGGL(k_bge_nodes<4>, dim3((e->d + 3) / 4, e->Mloc), dim3(256), lds4, e->stream, e->thr, e->masks,
+                           e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L, cnt);
+      } else {
+        allow_lds(k_bge_nodes<1>, lds1);
+        hipLaunchKernelGGL(k_bge_nodes<1>, dim3(e->d, e->Mloc), dim3(64), lds1, e->stream, e->thr, e->masks,
+                           e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L, cnt);
+      }
     }
     {
       KTimer tm(e, DIBS_K_LIK_WEIGHTS);
+      const int ny = e->d < 4 ? e->d : 4;
       const size_t base = (((size_t)e->S * 12 + 15) & ~(size_t)15);
-      const size_t mbytes = (size_t)e->S * e->d * e->W * 8;
+      const size_t mbytes = (size_t)e->S * ((e->d + ny - 1) / ny) * e->W * 8;
       const int in_lds = base + mbytes <= 64 * 1024;
       const size_t lds = base + (in_lds ? mbytes : 0);
-      hipLaunchKernelGGL(k_lik_weights_score, dim3(e->Mloc), dim3(256), lds, e->stream, e->node_scores, e->masks, e->scores,
-                         e->logprobs_z, e->w_lik, e->baseline, alpha, c.score_function_baseline, e->d, e->S, e->W, in_lds);
+      allow_lds(k_lik_weights_score, lds);
+      hipLaunchKernelGGL(k_lik_weights_score, dim3(e->Mloc, ny), dim3(256), lds, e->stream, e->node_scores, e->masks,
+                         e->scores, e->logprobs_z, e->w_lik, e->baseline, e->baseline2, alpha, c.score_function_baseline,
+                         e->d, e->S, e->W, in_lds);
+      std::swap(e->baseline, e->baseline2);
     }
   } else if (c.likelihood == DIBS_LIK_LINGAUSS) {
     JointLaunch jl{e->stream, e->z, e->theta, e->scores, e->thr, e->w_lik, e->logprobs_z, e->logprobs_th, e->baseline,
@@ -494,10 +507,11 @@ static int step_update(dibs_engine* e, int t, const float* pack) {
   {
     KTimer tm(e, DIBS_K_KMAT);
     allow_lds(k_kmat, (size_t)(e->D > e->P ? e->D : e->P) * 4);
-    hipLaunchKernelGGL(k_kmat, dim3(e->Mloc), dim3(256), (size_t)e->D * 4, e->stream, pack, (size_t)e->E, (size_t)0,
+    const dim3 kg(e->Mloc, (e->M + KMAT_BT - 1) / KMAT_BT);
+    hipLaunchKernelGGL(k_kmat, kg, dim3(256), (size_t)((e->D + 3) & ~3) * 4, e->stream, pack, (size_t)e->E, (size_t)0,
                        (int)e->D, e->kz, e->m0, e->M, (float)c.scale_latent, (float)c.h_latent);
     if (c.joint)
-      hipLaunchKernelGGL(k_kmat, dim3(e->Mloc), dim3(256), (size_t)e->P * 4, e->stream, pack, (size_t)e->E,
+      hipLaunchKernelGGL(k_kmat, kg, dim3(256), (size_t)((e->P + 3) & ~3) * 4, e->stream, pack, (size_t)e->E,
                          (size_t)(2 * e->D), (int)e->P, e->kt, e->m0, e->M, (float)c.scale_theta, (float)c.h_theta);
   }
   {

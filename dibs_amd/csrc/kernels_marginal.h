@@ -93,12 +93,19 @@ __global__ __launch_bounds__(256) void k_edge_scores(const float* __restrict__ z
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2+K3  BGe node scores.  block (j, m): sample column j of all S graphs (Threefry, both outputs of a
-//        call used: sample s and s + S/2 share a counter pair in the legacy layout), store the parent sets,
-//        then per sample factor R[pa u {j}] (Cholesky, j ordered last) -> logdet R[pa,pa] and the Schur
-//        complement -> node score.
-//        reference: dibs.py:102-119 (sample_g), linearGaussian.py:63-118, func.py:128-145
-// grid = (d, Mloc), block = 64 (one wave); dynamic LDS: see bge_lds_bytes()
+// K2+K3  BGe node scores.  Wave w of block (jb, m) owns node j = jb * WAVES + w of particle m:
+//   1. samples column j of all S graphs (Threefry; sample s and s + S/2 share one counter pair in the legacy
+//      layout, so both outputs of every call are used) and stores the parent sets (bit masks);
+//   2. per sample factors A = R[pa u {j}] with j ordered last (Cholesky): logdet R[pa,pa] = sum_{r<l} log d_r,
+//      Schur complement of j = d_l, which give the two masked slogdets of the reference.  Three tiers by n = l+1:
+//        n <= 8   one problem per lane, 8x8 Cholesky entirely in registers;
+//        n <= 32  two problems per wave (32-lane groups), lane = row, own row of L in registers, pivot rows
+//                 broadcast from LDS with ds_read_b128;
+//        else     one problem per wave, L in LDS (generic).
+//   reference: dibs.py:102-119 (sample_g), linearGaussian.py:63-118, func.py:128-145
+// grid = (ceil(d / WAVES), Mloc), block = 64 * WAVES; WAVES = 4 shares one R in LDS (no interventions),
+// WAVES = 1 loads R_j per block.  dynamic LDS: bge_lds_bytes()
+// layouts: masks [Mloc][d][S][W] u64, node_scores [Mloc][d][S] f64
 // ------------------------------------------------------------------------------------------------
 struct BgeParams {
   const float* R;       // [n_mats, d, d]
@@ -108,104 +115,277 @@ struct BgeParams {
   int n_mats;
 };
 
-__host__ __device__ inline size_t bge_lds_bytes(int d, int S, int W) {
-  // Rs[d*d] + Lw[d * ldl] + thr[d] + idx[d+1] + masks[S*W] (u64)
-  const int ldl = d | 1;
-  size_t b = (size_t)d * d * 4 + (size_t)d * ldl * 4 + (size_t)d * 4 + (size_t)(d + 4) * 4;
-  b = (b + 15) & ~(size_t)15;
-  return b + (size_t)S * W * 8;
+__host__ __device__ inline int bge_lbuf_floats(int d) {
+  const int generic = d > 32 ? d * (d | 1) : 0;
+  const int g32 = 2 * 32 * 36;  // >= 4 * 16 * 20
+  return ((generic > g32 ? generic : g32) + 3) & ~3;
+}
+__host__ __device__ inline int bge_idx_len(int d) { return d + 4 > 36 ? d + 4 : 36; }  // >= 32: the 32-lane tier zero-fills 32 slots
+__host__ __device__ inline size_t bge_wave_bytes(int d, int S, int W) {
+  // masks[S*W] u64 | Lbuf | thr[d] | idx[4][idx_len] | three u16 queues [S]
+  size_t b = (size_t)S * W * 8 + (size_t)bge_lbuf_floats(d) * 4 + (size_t)d * 4 + (size_t)4 * bge_idx_len(d) * 4 + (size_t)S * 6;
+  return (b + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t bge_lds_bytes(int d, int S, int W, int waves) {
+  const size_t r = (((size_t)d * d * 4) + 15) & ~(size_t)15;
+  return r + (size_t)waves * bge_wave_bytes(d, S, W);
 }
 
-__global__ __launch_bounds__(64) void k_bge_nodes(const uint32_t* __restrict__ thr, uint64_t* __restrict__ masks,
-                                                  double* __restrict__ node_scores, BgeParams bp, Key2 carry, int m0,
-                                                  int M_global, int d, int S, int W, int layout,
-                                                  unsigned long long* __restrict__ counters) {
+// LDS traffic between lanes of ONE wave: the hardware executes a wave's DS operations in order, so only the
+// compiler has to be kept from reordering them.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double bge_assemble(const BgeParams& bp, int j, int l, int d, double Nn, double ld_pa, double schur) {
+  if (!(Nn > 0.0)) return 0.0;
+  const double al = bp.alpha_lambd;
+  const double ld_all = ld_pa + log(schur);
+  return bp.gam[(size_t)j * (d + 1) + l] + 0.5 * (Nn + al - d + l) * ld_pa - 0.5 * (Nn + al - d + l + 1) * ld_all;
+}
+
+// Cooperative tier: G lanes per problem (lane = row), 64 / G problems per wave.  Row r of L lives in the owning
+// lane's registers; the pivot row is re-read from LDS (one ds_read_b128 per four columns, broadcast inside the group);
+// every lane recomputes the pivot d_k from that row, so a column step depends on LDS only through the previous
+// column's store.  The gathered row A[r][:] and the diagonal are preloaded.
+template <int G>
+__device__ __forceinline__ double bge_chol_groups(const float* __restrict__ Rs, float* __restrict__ Lb, int* __restrict__ idxs,
+                                                  const uint64_t* __restrict__ mk, const unsigned short* __restrict__ list,
+                                                  int cnt, int W, int d, int j, int lane, const BgeParams& bp, double Nn,
+                                                  double* __restrict__ ns_out) {
+  constexpr int NP = 64 / G, LD = G + 4;
+  const int grp = lane / G, r = lane % G;
+  const int ilen = bge_idx_len(d);
+  int* myidx = idxs + grp * ilen;
+  float* Lh = Lb + grp * G * LD;
+  double flops = 0.0;
+  for (int q = 0; q < cnt; q += NP) {
+    const bool has = q + grp < cnt;
+    const int sP = has ? (int)list[q + grp] : 0;
+    int l = 0;
+    myidx[r] = 0;  // slots >= n must hold a valid index
+    wave_lds_fence();
+    if (has) {
+      for (int w = 0; w < W; ++w) {
+        const uint64_t word = mk[sP * W + w];
+        for (int bb = r; bb < 64; bb += G)
+          if ((word >> bb) & 1ull) myidx[l + __popcll(word & ((1ull << bb) - 1ull))] = w * 64 + bb;
+        l += __popcll(word);
+      }
+      if (r == 0) myidx[l] = j;
+    }
+    const int n = has ? l + 1 : 0;
+    int nmax = 0;
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+      const int t = __shfl(n, g * G, 64);
+      nmax = t > nmax ? t : nmax;
+    }
+    wave_lds_fence();
+    const int ir = (r < n) ? myidx[r] : 0;
+    float Ar[G], Dk[G], Lr[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const int ik = myidx[k];
+      Ar[k] = Rs[ir * d + ik];
+      Dk[k] = Rs[ik * d + ik];
+      Lr[k] = 0.f;
+    }
+    float mypiv = 1.f;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      if (k >= nmax) break;
+      float acc = Ar[k], pv = Dk[k];
+#pragma unroll
+      for (int p4 = 0; p4 < (k + 3) / 4; ++p4) {
+        const float4 v = *reinterpret_cast<const float4*>(Lh + k * LD + p4 * 4);
+        if (p4 * 4 + 0 < k) { acc = fmaf(-Lr[p4 * 4 + 0], v.x, acc); pv = fmaf(-v.x, v.x, pv); }
+        if (p4 * 4 + 1 < k) { acc = fmaf(-Lr[p4 * 4 + 1], v.y, acc); pv = fmaf(-v.y, v.y, pv); }
+        if (p4 * 4 + 2 < k) { acc = fmaf(-Lr[p4 * 4 + 2], v.z, acc); pv = fmaf(-v.z, v.z, pv); }
+        if (p4 * 4 + 3 < k) { acc = fmaf(-Lr[p4 * 4 + 3], v.w, acc); pv = fmaf(-v.w, v.w, pv); }
+      }
+      if (r == k) mypiv = pv;
+      const float lv = acc * rsqrtf(pv);
+      Lr[k] = lv;
+      if (r > k) Lh[r * LD + k] = lv;
+      wave_lds_fence();
+    }
+    double lg = (r < l) ? log((double)mypiv) : 0.0;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);
+    const double schur = (double)__shfl(mypiv, grp * G + (l < G ? l : 0), 64);
+    if (r == 0 && has) {
+      ns_out[sP] = bge_assemble(bp, j, l, d, Nn, lg, schur);
+      flops += (double)n * n * n / 3.0;
+    }
+  }
+  return flops;
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __restrict__ thr, uint64_t* __restrict__ masks,
+                                                          double* __restrict__ node_scores, BgeParams bp, Key2 carry,
+                                                          int m0, int M_global, int d, int S, int W, int layout,
+                                                          unsigned long long* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int j = blockIdx.x, m = blockIdx.y, lane = threadIdx.x;
-  const int ldl = d | 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = blockIdx.y;
+  const int j = blockIdx.x * WAVES + wave;
+  const bool active = j < d;
   float* Rs = reinterpret_cast<float*>(smem_raw);
-  float* Lw = Rs + (size_t)d * d;
-  uint32_t* thrs = reinterpret_cast<uint32_t*>(Lw + (size_t)d * ldl);
-  int* idx = reinterpret_cast<int*>(thrs + d);
-  size_t off = (size_t)d * d * 4 + (size_t)d * ldl * 4 + (size_t)d * 4 + (size_t)(d + 4) * 4;
-  off = (off + 15) & ~(size_t)15;
-  uint64_t* mk = reinterpret_cast<uint64_t*>(smem_raw + off);
+  const size_t r_bytes = (((size_t)d * d * 4) + 15) & ~(size_t)15;
+  unsigned char* wbase = smem_raw + r_bytes + (size_t)wave * bge_wave_bytes(d, S, W);
+  uint64_t* mk = reinterpret_cast<uint64_t*>(wbase);
+  float* Lb = reinterpret_cast<float*>(mk + (size_t)S * W);
+  uint32_t* thrs = reinterpret_cast<uint32_t*>(Lb + bge_lbuf_floats(d));
+  int* idxs = reinterpret_cast<int*>(thrs + d);  // [4][bge_idx_len(d)]
+  unsigned short* list16 = reinterpret_cast<unsigned short*>(idxs + 4 * bge_idx_len(d));
+  unsigned short* list32 = list16 + S;
+  unsigned short* listg = list32 + S;
 
-  const float* Rg = bp.R + (bp.n_mats > 1 ? (size_t)j * d * d : 0);
-  for (int e = lane; e < d * d; e += 64) Rs[e] = Rg[e];
-  for (int i = lane; i < d; i += 64) thrs[i] = thr[((size_t)m * d + i) * d + j];
-  for (int e = lane; e < S * W; e += 64) mk[e] = 0ull;
+  {  // R: shared by the block (WAVES > 1 requires n_mats == 1)
+    const float* Rg = bp.R + (bp.n_mats > 1 ? (size_t)(blockIdx.x * WAVES) * d * d : 0);
+    for (int e = tid; e < d * d; e += 64 * WAVES) Rs[e] = Rg[e];
+  }
+  if (active)
+    for (int i = lane; i < d; i += 64) thrs[i] = thr[((size_t)m * d + i) * d + j];
   __syncthreads();
+  if (!active) return;
 
-  // keys: particle key = row (1 + m_global) of split(carry, M+1); subk_ = row 1 of split(particle key)   dibs.py:350-351
+  // ---- 1. sample column j of the S graphs -------------------------------------------------------
+  // particle key = row (1 + m_global) of split(carry, M+1); subk_ = row 1 of split(particle key)   dibs.py:350-351
   const Key2 kp = rng_split_row(carry, (uint32_t)M_global + 1u, (uint32_t)(m0 + m) + 1u, layout);
   const Key2 kg = rng_split_row(kp, 2u, 1u, layout);
   const uint64_t dd = (uint64_t)d * d, nbits = (uint64_t)S * dd;
-
   if ((S & 1) == 0) {
     const int hS = S >> 1;
     for (int p = lane; p < hS; p += 64) {
-      uint64_t a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+      uint64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+      const uint64_t cbase = (uint64_t)p * dd + j;
       for (int i = 0; i < d; ++i) {
         uint32_t y0, y1;
-        rng_bits_pair(kg, nbits, (uint64_t)p * dd + (uint64_t)i * d + j, layout, y0, y1);
+        rng_bits_pair(kg, nbits, cbase + (uint64_t)i * d, layout, y0, y1);
         const uint32_t t = thrs[i];
-        a[i >> 6] |= (uint64_t)((y0 >> 9) < t) << (i & 63);
-        b[i >> 6] |= (uint64_t)((y1 >> 9) < t) << (i & 63);
+        const uint64_t ba = (uint64_t)((y0 >> 9) < t) << (i & 63), bb = (uint64_t)((y1 >> 9) < t) << (i & 63);
+        if (i < 64) { a0 |= ba; b0 |= bb; } else { a1 |= ba; b1 |= bb; }
       }
-      for (int w = 0; w < W; ++w) {
-        mk[p * W + w] = a[w];
-        mk[(p + hS) * W + w] = b[w];
-      }
+      mk[p * W] = a0;
+      mk[(p + hS) * W] = b0;
+      if (W > 1) { mk[p * W + 1] = a1; mk[(p + hS) * W + 1] = b1; }
     }
   } else {
     for (int s = lane; s < S; s += 64) {
-      uint64_t a[4] = {0, 0, 0, 0};
+      uint64_t a0 = 0, a1 = 0;
       for (int i = 0; i < d; ++i) {
         const uint32_t y = rng_bits_at(kg, nbits, (uint64_t)s * dd + (uint64_t)i * d + j, layout);
-        a[i >> 6] |= (uint64_t)((y >> 9) < thrs[i]) << (i & 63);
+        const uint64_t ba = (uint64_t)((y >> 9) < thrs[i]) << (i & 63);
+        if (i < 64) a0 |= ba; else a1 |= ba;
       }
-      for (int w = 0; w < W; ++w) mk[s * W + w] = a[w];
+      mk[s * W] = a0;
+      if (W > 1) mk[s * W + 1] = a1;
     }
   }
-  __syncthreads();
-  {  // parent sets to global: masks[m][s][j][w]
-    uint64_t* mg = masks + (size_t)m * S * d * W;
-    for (int e = lane; e < S * W; e += 64) {
-      const int s = e / W, w = e - s * W;
-      mg[((size_t)s * d + j) * W + w] = mk[e];
-    }
+  wave_lds_fence();
+  {
+    uint64_t* mg = masks + ((size_t)m * d + j) * S * W;
+    for (int e = lane; e < S * W; e += 64) mg[e] = mk[e];
   }
 
   const double Nn = bp.Nj[j];
+  double* ns_out = node_scores + ((size_t)m * d + j) * S;
   double flops = 0.0;
-  for (int s = 0; s < S; ++s) {
-    // ---- index list: parents ascending, then j ----
+  int n16 = 0, n32 = 0, ng = 0;
+
+  // ---- 2a. n <= 8: one problem per lane, registers only -----------------------------------------
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const bool valid = s < S;
+    uint64_t w0 = valid ? mk[s * W] : 0ull, w1 = (valid && W > 1) ? mk[s * W + 1] : 0ull;
+    const int l = __popcll(w0) + __popcll(w1);
+    const bool small = valid && l <= 7;
+    if (small) {
+      int idx[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        int b = 0;
+        if (w0) { b = __ffsll((long long)w0) - 1; w0 &= w0 - 1; }
+        else if (w1) { b = 64 + __ffsll((long long)w1) - 1; w1 &= w1 - 1; }
+        idx[t] = (t == l) ? j : b;
+      }
+      const int n = l + 1;
+      float A[8][8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) A[r][c] = (r < n) ? Rs[idx[r] * d + idx[c]] : (r == c ? 1.0f : 0.0f);
+      float piv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float dk = A[k][k];
+#pragma unroll
+        for (int p = 0; p < k; ++p) dk = fmaf(-A[k][p], A[k][p], dk);
+        piv[k] = dk;
+        const float inv = rsqrtf(dk);
+#pragma unroll
+        for (int r = k + 1; r < 8; ++r) {
+          float v = A[r][k];
+#pragma unroll
+          for (int p = 0; p < k; ++p) v = fmaf(-A[r][p], A[k][p], v);
+          A[r][k] = v * inv;
+        }
+      }
+      double prod = 1.0, schur = 1.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (k < l) prod *= (double)piv[k];
+        if (k == l) schur = (double)piv[k];
+      }
+      ns_out[s] = bge_assemble(bp, j, l, d, Nn, log(prod), schur);
+      flops += (double)n * n * n / 3.0;
+    }
+    // queue the rest by tier: n <= 16 (4 per wave), n <= 32 (2 per wave), generic
+    const bool t16 = valid && !small && l <= 15, t32 = valid && !small && !t16 && l <= 31, tg = valid && !small && l > 31;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long b16 = __ballot(t16), b32 = __ballot(t32), bg = __ballot(tg);
+    if (t16) list16[n16 + __popcll(b16 & lt)] = (unsigned short)s;
+    if (t32) list32[n32 + __popcll(b32 & lt)] = (unsigned short)s;
+    if (tg) listg[ng + __popcll(bg & lt)] = (unsigned short)s;
+    n16 += __popcll(b16);
+    n32 += __popcll(b32);
+    ng += __popcll(bg);
+  }
+  wave_lds_fence();
+
+  // ---- 2b. larger problems, cooperatively ---------------------------------------------------------
+  if (n16) flops += bge_chol_groups<16>(Rs, Lb, idxs, mk, list16, n16, W, d, j, lane, bp, Nn, ns_out);
+  if (n32) flops += bge_chol_groups<32>(Rs, Lb, idxs, mk, list32, n32, W, d, j, lane, bp, Nn, ns_out);
+  for (int q = 0; q < ng; ++q) {
+    // ---- generic: one problem per wave, lane owns rows r and r + 64, L in LDS ----
+    const int sA = listg[q];
     int l = 0;
+    int* myidx = idxs;
     for (int w = 0; w < W; ++w) {
-      const uint64_t word = mk[s * W + w];
-      const int i = w * 64 + lane;
-      const bool bit = (word >> lane) & 1ull;
-      const int pos = l + __popcll(word & ((1ull << lane) - 1ull));
-      if (bit && i < d) idx[pos] = i;
+      const uint64_t word = mk[sA * W + w];
+      if ((word >> lane) & 1ull) myidx[l + __popcll(word & ((1ull << lane) - 1ull))] = w * 64 + lane;
       l += __popcll(word);
     }
-    if (lane == 0) idx[l] = j;
-    const int n = l + 1;
-    __syncthreads();
-    // ---- left-looking Cholesky of A = R[idx, idx]; lane owns row r (and r + 64) ----
-    float mypiv[2] = {1.f, 1.f};  // pivot d_r = L_rr^2 of the rows this lane owns
+    if (lane == 0) myidx[l] = j;
+    const int n = l + 1, ldl = d | 1;
+    wave_lds_fence();
+    float mypiv[2] = {1.f, 1.f};
     for (int kk = 0; kk < n; ++kk) {
-      const int ik = idx[kk];
+      const int ik = myidx[kk];
       float accs[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int r = lane + h * 64;
         float acc = 0.f;
         if (r >= kk && r < n) {
-          acc = Rs[idx[r] * d + ik];
-          const float* lr = Lw + (size_t)r * ldl;
-          const float* lk = Lw + (size_t)kk * ldl;
+          acc = Rs[myidx[r] * d + ik];
+          const float* lr = Lb + (size_t)r * ldl;
+          const float* lk = Lb + (size_t)kk * ldl;
           for (int p = 0; p < kk; ++p) acc = fmaf(-lr[p], lk[p], acc);
         }
         accs[h] = acc;
@@ -216,11 +396,10 @@ __global__ __launch_bounds__(64) void k_bge_nodes(const uint32_t* __restrict__ t
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int r = lane + h * 64;
-        if (r > kk && r < n) Lw[(size_t)r * ldl + kk] = accs[h] * inv;
+        if (r > kk && r < n) Lb[(size_t)r * ldl + kk] = accs[h] * inv;
       }
-      __syncthreads();
+      wave_lds_fence();
     }
-    // logdet R[pa,pa] = sum_{r < l} log d_r ; Schur complement of j = d_l
     double lg = 0.0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -229,18 +408,16 @@ __global__ __launch_bounds__(64) void k_bge_nodes(const uint32_t* __restrict__ t
     }
     const double ld_pa = wave_sum_d(lg);
     const double schur = (double)__shfl(l < 64 ? mypiv[0] : mypiv[1], l & 63, 64);
-    flops += (double)n * n * n / 3.0;
     if (lane == 0) {
-      double sc = 0.0;
-      if (Nn > 0.0) {
-        const double al = bp.alpha_lambd;
-        const double ld_all = ld_pa + log(schur);
-        sc = bp.gam[(size_t)j * (d + 1) + l] + 0.5 * (Nn + al - d + l) * ld_pa - 0.5 * (Nn + al - d + l + 1) * ld_all;
-      }
-      node_scores[((size_t)m * S + s) * d + j] = sc;
+      ns_out[sA] = bge_assemble(bp, j, l, d, Nn, ld_pa, schur);
+      flops += (double)n * n * n / 3.0;
     }
+    wave_lds_fence();
   }
-  if (counters && lane == 0) atomicAdd(counters, (unsigned long long)flops);
+  if (counters) {
+    const double tot = wave_sum_d(flops);
+    if (lane == 0) atomicAdd(counters, (unsigned long long)tot);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -252,25 +429,29 @@ __global__ __launch_bounds__(64) void k_bge_nodes(const uint32_t* __restrict__ t
 __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restrict__ node_scores,
                                                            const uint64_t* __restrict__ masks,
                                                            const float* __restrict__ scores, float* __restrict__ logprobs,
-                                                           float* __restrict__ w_lik, float* __restrict__ baseline,
-                                                           float alpha, double sf_baseline, int d, int S, int W,
-                                                           int masks_in_lds) {
+                                                           float* __restrict__ w_lik, const float* __restrict__ baseline,
+                                                           float* __restrict__ baseline_out, float alpha,
+                                                           double sf_baseline, int d, int S, int W, int masks_in_lds) {
+  // block (m, y) handles the columns j = y, y + gridDim.y, ... of particle m; every block recomputes l_s / softmax
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* lp = reinterpret_cast<double*>(smem_raw);
   float* wt = reinterpret_cast<float*>(lp + S);
   uint64_t* mkl = reinterpret_cast<uint64_t*>(smem_raw + (((size_t)S * 12 + 15) & ~(size_t)15));
   __shared__ double red[8];
-  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint64_t* mg = masks + (size_t)m * S * d * W;
+  const int m = blockIdx.x, y = blockIdx.y, ny = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncol = (d - y + ny - 1) / ny;  // columns of this block
+  const uint64_t* mg = masks + (size_t)m * d * S * W;  // [j][s][w]
   if (masks_in_lds)
-    for (int e = tid; e < S * d * W; e += 256) mkl[e] = mg[e];
-  const uint64_t* mk = masks_in_lds ? mkl : mg;
+    for (int e = tid; e < ncol * S * W; e += 256) {
+      const int c = e / (S * W), rest = e - c * (S * W);
+      mkl[e] = mg[(size_t)(y + c * ny) * S * W + rest];
+    }
   for (int s = tid; s < S; s += 256) {
-    const double* ns = node_scores + ((size_t)m * S + s) * d;
+    const double* ns = node_scores + (size_t)m * d * S + s;
     double t = 0.0;
-    for (int j = 0; j < d; ++j) t += ns[j];
+    for (int j = 0; j < d; ++j) t += ns[(size_t)j * S];
     lp[s] = t;
-    logprobs[(size_t)m * S + s] = (float)t;
+    if (y == 0) logprobs[(size_t)m * S + s] = (float)t;
   }
   __syncthreads();
   double mx = -INFINITY, sm = 0.0;
@@ -287,9 +468,7 @@ __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restr
   }
   den = wave_sum_d(den);
   sm = wave_sum_d(sm);
-  if (lane == 0) {
-    red[4 + wave] = den;
-  }
+  if (lane == 0) red[4 + wave] = den;
   __syncthreads();
   den = red[4] + red[5] + red[6] + red[7];
   __syncthreads();
@@ -299,21 +478,22 @@ __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restr
   sm = red[0] + red[1] + red[2] + red[3];
   const float bold = baseline[m];
   const float scale = sf_baseline > 0.0 ? (float)exp(-(double)bold) : 1.0f;
-  for (int e = tid; e < d * d; e += 256) {
-    const int i = e / d, j = e - i * d;
+  for (int e = tid; e < ncol * d; e += 256) {
+    const int c = e / d, i = e - c * d, j = y + c * ny;
     float out = 0.f;
     if (i != j) {
       float acc = 0.f;
       const int w = i >> 6;
       const uint64_t bit = 1ull << (i & 63);
+      const uint64_t* col = masks_in_lds ? mkl + (size_t)c * S * W : mg + (size_t)j * S * W;
       for (int s = 0; s < S; ++s)
-        if (mk[((size_t)s * d + j) * W + w] & bit) acc += wt[s];
-      const float p = (float)sigmoid_d((double)__fmul_rn(alpha, scores[(size_t)m * d * d + e]));
+        if (col[(size_t)s * W + w] & bit) acc += wt[s];
+      const float p = (float)sigmoid_d((double)__fmul_rn(alpha, scores[(size_t)m * d * d + i * d + j]));
       out = scale * alpha * (acc - p);
     }
-    w_lik[(size_t)m * d * d + e] = out;
+    w_lik[(size_t)m * d * d + i * d + j] = out;
   }
-  if (tid == 0) baseline[m] = (float)(sf_baseline * (sm / S) + (1.0 - sf_baseline) * (double)bold);
+  if (tid == 0 && y == 0) baseline_out[m] = (float)(sf_baseline * (sm / S) + (1.0 - sf_baseline) * (double)bold);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -498,21 +678,42 @@ __global__ __launch_bounds__(256) void k_zgrad(const float* __restrict__ z, cons
 //     reference: kernel.py:20-30 / 52-71, svgd.py:165-176 / 537-551
 // grid = Mloc, block = 256; dynamic LDS = len * 4
 // ------------------------------------------------------------------------------------------------
+#define KMAT_BT 16
 __global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, size_t pack_stride, size_t seg_off, int len,
                                               float* __restrict__ kout, int m0, int M, float scale, float h) {
+  // block (a, bt): particle a (local) against b = bt * KMAT_BT .. +KMAT_BT-1; wave w takes b = b0 + w, b0 + w + 4, ...
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int a = blockIdx.x, b0 = blockIdx.y * KMAT_BT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* za = pack + (size_t)(m0 + a) * pack_stride + seg_off;
-  for (int e = tid; e < len; e += 256) smem[e] = za[e];
+  const int len4 = len >> 2;
+  for (int e = tid; e < len4; e += 256) reinterpret_cast<float4*>(smem)[e] = reinterpret_cast<const float4*>(za)[e];
+  for (int e = (len4 << 2) + tid; e < len; e += 256) smem[e] = za[e];
   __syncthreads();
-  for (int b = wave; b < M; b += 4) {
+  for (int b = b0 + wave; b < b0 + KMAT_BT && b < M; b += 4) {
     const float* zb = pack + (size_t)b * pack_stride + seg_off;
-    float s = 0.f;
-    for (int e = lane; e < len; e += 64) {
-      const float df = smem[e] - zb[e];
-      s = fmaf(df, df, s);
+    const float4* zb4 = reinterpret_cast<const float4*>(zb);
+    const float4* za4 = reinterpret_cast<const float4*>(smem);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int e = lane;
+    for (; e + 192 < len4; e += 256) {
+      const float4 q0 = zb4[e], q1 = zb4[e + 64], q2 = zb4[e + 128], q3 = zb4[e + 192];
+      const float4 p0 = za4[e], p1 = za4[e + 64], p2 = za4[e + 128], p3 = za4[e + 192];
+      float t;
+      t = p0.x - q0.x; s0 = fmaf(t, t, s0); t = p0.y - q0.y; s0 = fmaf(t, t, s0); t = p0.z - q0.z; s0 = fmaf(t, t, s0); t = p0.w - q0.w; s0 = fmaf(t, t, s0);
+      t = p1.x - q1.x; s1 = fmaf(t, t, s1); t = p1.y - q1.y; s1 = fmaf(t, t, s1); t = p1.z - q1.z; s1 = fmaf(t, t, s1); t = p1.w - q1.w; s1 = fmaf(t, t, s1);
+      t = p2.x - q2.x; s2 = fmaf(t, t, s2); t = p2.y - q2.y; s2 = fmaf(t, t, s2); t = p2.z - q2.z; s2 = fmaf(t, t, s2); t = p2.w - q2.w; s2 = fmaf(t, t, s2);
+      t = p3.x - q3.x; s3 = fmaf(t, t, s3); t = p3.y - q3.y; s3 = fmaf(t, t, s3); t = p3.z - q3.z; s3 = fmaf(t, t, s3); t = p3.w - q3.w; s3 = fmaf(t, t, s3);
     }
-    const double tot = wave_sum_d((double)s);
+    for (; e < len4; e += 64) {
+      const float4 q0 = zb4[e], p0 = za4[e];
+      float t;
+      t = p0.x - q0.x; s0 = fmaf(t, t, s0); t = p0.y - q0.y; s0 = fmaf(t, t, s0); t = p0.z - q0.z; s0 = fmaf(t, t, s0); t = p0.w - q0.w; s0 = fmaf(t, t, s0);
+    }
+    for (int e1 = (len4 << 2) + lane; e1 < len; e1 += 64) {
+      const float t = smem[e1] - zb[e1];
+      s1 = fmaf(t, t, s1);
+    }
+    const double tot = wave_sum_d((double)s0 + (double)s1 + (double)s2 + (double)s3);
     if (lane == 0) kout[(size_t)a * M + b] = (float)((double)scale * exp(-tot / (double)h));
   }
 }

@@ -97,8 +97,8 @@ enum {
   DIBS_BUF_KXX = 10,       /* f32 [Mloc, M]         kxx[a_local, b_global]         */
   DIBS_BUF_PHI_Z = 11,     /* f32 [Mloc, d, k, 2]                                  */
   DIBS_BUF_BASELINE = 12,  /* f32 [Mloc]                                           */
-  DIBS_BUF_NODE_SCORES = 13,/* f32 [Mloc, S, d]     BGe per-node scores            */
-  DIBS_BUF_PARENT_MASKS = 14,/* u64 [Mloc, S, d, W] sampled parent sets (bit i of word i/64 = g[i, j]) */
+  DIBS_BUF_NODE_SCORES = 13,/* f64 [Mloc, d, S]     BGe per-node scores            */
+  DIBS_BUF_PARENT_MASKS = 14,/* u64 [Mloc, d, S, W] sampled parent sets of node j (bit i of word i/64 = g[i, j]) */
   DIBS_BUF_LOGPROBS_THETA = 15, /* f32 [Mloc, S]                                   */
   DIBS_BUF_PHI_THETA = 16,
   DIBS_BUF_GATHER = 17,    /* f32 packed all-gather payload        */

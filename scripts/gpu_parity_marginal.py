@@ -49,14 +49,14 @@ def main(d=5, M=4, S=128, Sa=32, steps=(0, 1, 5), epn=1):
         dbg = co.step(cfg, x.astype(np.float64), None, st, t, debug=True)
         eng.run(t, 1)
         g = eng.get_state()
-        gm = eng.read("PARENT_MASKS").reshape(M, S, d, -1)
+        gm = eng.read("PARENT_MASKS").reshape(M, d, S, -1)
         # compare sampled graphs
         og = dbg["g_samples"]  # [M,S,d,d] (i,j)
         gg = np.zeros_like(og)
         for i in range(d):
-            gg[:, :, i, :] = ((gm[:, :, :, i // 64] >> np.uint64(i % 64)) & np.uint64(1)).astype(np.uint8)
+            gg[:, :, i, :] = ((gm[:, :, :, i // 64] >> np.uint64(i % 64)) & np.uint64(1)).astype(np.uint8).transpose(0, 2, 1)
         nflip = int((gg != og).sum())
-        ns = eng.read("NODE_SCORES").reshape(M, S, d)
+        ns = eng.read("NODE_SCORES").reshape(M, d, S).transpose(0, 2, 1)
         print(f" t={t}: graphs flipped {nflip}/{og.size}  scores {rel(eng.read('SCORES'), dbg['scores']):.2e}  "
               f"node {rel(ns, dbg['node_scores']):.2e}  lp {rel(eng.read('LOGPROBS_Z'), dbg['logprobs_z']):.2e}  "
               f"w_lik {rel(eng.read('W_LIK'), dbg['w_lik']):.2e}  w_acyc {rel(eng.read('W_ACYC'), dbg['w_acyc']):.2e}  "
