@@ -460,8 +460,8 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     }
   } else if (c.likelihood == DIBS_LIK_LINGAUSS) {
     JointLaunch jl{e->stream, e->z, e->theta, e->scores, e->thr, e->w_lik, e->logprobs_z, e->logprobs_th, e->baseline,
-                   pack, (size_t)e->E, (size_t)(2 * e->D), (size_t)(2 * e->D + e->P), e->m0, e->M, e->Mloc, e->d, e->N, e->S,
-                   alpha, (float)c.tau, L, c.logistic_minval_tiny, c.grad_estimator_z, c.score_function_baseline,
+                   e->baseline2, pack, (size_t)e->E, (size_t)(2 * e->D), (size_t)(2 * e->D + e->P), e->m0, e->M, e->Mloc, e->d,
+                   e->N, e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny, c.grad_estimator_z, c.score_function_baseline,
                    (float)c.lin_obs_noise, (float)c.lin_mean_edge, (float)c.lin_sig_edge};
     {
       KTimer tm(e, DIBS_K_LIN_THETA);
@@ -470,6 +470,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     {
       KTimer tm(e, DIBS_K_LIN_Z);
       joint_lin_z(&e->jw, jl, carry_lik);
+      std::swap(e->baseline, e->baseline2);
     }
   }
   {

@@ -1,12 +1,23 @@
-// JointDiBS likelihood kernels (LinearGaussian) -- see DESIGN.md.  (stub: filled in next milestone)
+// JointDiBS + LinearGaussian likelihood kernels (gfx950).
+//   log p(theta, D | G) = sum_ij g_ij logN(theta_ij; mu_e, sig_e) + sum_{n,j: not intervened} logN(x_nj; (x (g o theta))_nj, sqrt(obs_noise))
+//   r = (1 - mask) o (x - x (g o theta)) / obs_noise
+//   d/dg = logN(theta) + theta o (x^T r)            d/dtheta = g o (-(theta - mu_e)/sig_e^2 + x^T r)
+// reference: dibs/models/linearGaussian.py:278-338; estimators dibs/inference/dibs.py:395-459 (Z, reparam),
+//            :325-391 (Z, score), :488-551 (theta).  Both contractions run on v_mfma_f32_16x16x4_f32 with x, theta and
+//            the per-sample operand resident in LDS.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "rng.h"
+#include "kernels_marginal.h"
+
+enum { LIN_MODE_THETA = 0, LIN_MODE_Z_SCORE = 1, LIN_MODE_Z_REPARAM = 2 };
 
 struct JointWork {
-  float* xtx;  // [n_mats, d, d]  x^T diag(1 - mask_j) x
-  int n_mats;
+  float* x;        // [N, d] device copy
+  int32_t* mask;   // [N, d]
+  float* wsm;      // [Mloc, S] softmax weights scratch
+  int any_mask;
 };
 
 struct JointLaunch {
@@ -18,7 +29,8 @@ struct JointLaunch {
   float* w_lik;
   float* logprobs_z;
   float* logprobs_th;
-  float* baseline;
+  const float* baseline;
+  float* baseline_out;
   float* pack;
   size_t pack_stride, theta_off, gtheta_off;
   int m0, M, Mloc, d, N, S;
@@ -28,8 +40,367 @@ struct JointLaunch {
   float obs_noise, mean_edge, sig_edge;
 };
 
-static inline int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) { (void)w; (void)Mloc; (void)d; (void)N; (void)S; return 0; }
-static inline void joint_free(JointWork* w) { (void)w; }
-static inline int joint_set_data(JointWork* w, const float* x, const int32_t* mask, int N, int d) { (void)w; (void)x; (void)mask; (void)N; (void)d; return 1; }
-static inline void joint_lin_theta(JointWork* w, const JointLaunch& jl, Key2 carry) { (void)w; (void)jl; (void)carry; }
-static inline void joint_lin_z(JointWork* w, const JointLaunch& jl, Key2 carry) { (void)w; (void)jl; (void)carry; }
+struct LinGeom {
+  int d, N, kp, np, ldx, ldw;  // kp = ceil4(d), np = ceil16(N) (rows of x / res incl. zero padding)
+};
+__host__ __device__ inline LinGeom lin_geom(int d, int N, int NT) {
+  LinGeom g;
+  g.d = d;
+  g.N = N;
+  g.kp = (d + 3) & ~3;
+  g.np = (N + 15) & ~15;
+  const int dp = 16 * NT;
+  g.ldx = dp + 2;  // x rows / res rows: (row * ld + k) bank pattern of the MFMA A/B fragment reads
+  g.ldw = dp + 2;
+  return g;
+}
+// LDS: X[np][ldx] | TH[d*d] | WG[max(kp, np)][ldw]  (WG doubles as the residual matrix in the gradient kernel)
+__host__ __device__ inline size_t lin_lds_bytes(int d, int N, int NT, bool with_res) {
+  const LinGeom g = lin_geom(d, N, NT);
+  size_t f = (size_t)g.np * g.ldx + (size_t)d * d + (size_t)g.kp * g.ldw;
+  if (with_res) f += (size_t)g.np * g.ldw;
+  return ((f * 4 + 15) & ~(size_t)15) + 64 * 8;
+}
+
+__device__ __forceinline__ float lin_logn(float v, float mu, float sig) {
+  const float zt = (v - mu) / sig;
+  return -0.5f * zt * zt - logf(sig) - 0.918938533204672742f;
+}
+
+// element (i, j) of sample s: hard Bernoulli graph (theta / score modes) or Gumbel-soft graph (reparam)
+__device__ __forceinline__ float lin_sample_g(int mode, Key2 key, uint64_t nbits, uint64_t dd, int s, int i, int j, int d,
+                                              const uint32_t* __restrict__ thr_m, const float* __restrict__ sc_m, float alpha,
+                                              float tau, int layout, int tiny) {
+  if (i == j) return 0.f;
+  const uint32_t bits = rng_bits_at(key, nbits, (uint64_t)s * dd + (uint64_t)i * d + j, layout);
+  if (mode == LIN_MODE_Z_REPARAM) {
+    const float eps = rng_logistic(bits, tiny);
+    return 1.0f / (1.0f + expf(-tau * (eps + alpha * sc_m[i * d + j])));
+  }
+  return (bits >> 9) < thr_m[i * d + j] ? 1.0f : 0.0f;
+}
+
+__device__ __forceinline__ Key2 lin_mode_key(int mode, Key2 carry, int M_global, int m_global, int layout) {
+  const Key2 kp = rng_split_row(carry, (uint32_t)M_global + 1u, (uint32_t)m_global + 1u, layout);
+  if (mode == LIN_MODE_THETA) return kp;            // dibs.py:510: particle key itself
+  return rng_split_row(kp, 2u, 1u, layout);         // dibs.py:350-351 / 430-431: subk_ of split(particle key)
+}
+
+template <int NT>
+__device__ __forceinline__ void lin_load_common(float* X, float* TH, const float* __restrict__ x, const float* __restrict__ theta_m,
+                                                const LinGeom g, int tid) {
+  for (int e = tid; e < g.np * g.ldx; e += 256) {
+    const int n = e / g.ldx, c = e - n * g.ldx;
+    X[e] = (n < g.N && c < g.d) ? x[(size_t)n * g.d + c] : 0.f;
+  }
+  for (int e = tid; e < g.d * g.d; e += 256) TH[e] = theta_m[e];
+}
+
+// WG = g o theta for sample s (zero padded); returns this thread's share of sum_ij g_ij logN(theta_ij)
+template <int NT>
+__device__ __forceinline__ float lin_build_wg(float* WG, const float* TH, int mode, Key2 key, uint64_t nbits, int s,
+                                              const uint32_t* thr_m, const float* sc_m, float alpha, float tau, int layout,
+                                              int tiny, float mu, float sig, const LinGeom g, int tid) {
+  float prior = 0.f;
+  const uint64_t dd = (uint64_t)g.d * g.d;
+  for (int e = tid; e < g.kp * g.ldw; e += 256) {
+    const int i = e / g.ldw, j = e - i * g.ldw;
+    float v = 0.f;
+    if (i < g.d && j < g.d) {
+      const float gv = lin_sample_g(mode, key, nbits, dd, s, i, j, g.d, thr_m, sc_m, alpha, tau, layout, tiny);
+      const float th = TH[i * g.d + j];
+      v = gv * th;
+      prior += gv * lin_logn(th, mu, sig);
+    }
+    WG[e] = v;
+  }
+  return prior;
+}
+
+// pred = X * WG for the row tiles of this wave; calls f(n, j, pred_nj) on every valid element
+template <int NT, typename F>
+__device__ __forceinline__ void lin_pred_tiles(const float* X, const float* WG, const LinGeom g, int lane, int wave, F&& f) {
+  const int nrt = g.np >> 4;
+  for (int ti = wave; ti < nrt; ti += 4) {
+    f32x4 acc[NT];
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj) acc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ap = (ti * 16 + (lane & 15)) * g.ldx + (lane >> 4);
+    const int bq = (lane >> 4) * g.ldw + (lane & 15);
+    for (int k0 = 0; k0 < g.kp; k0 += 4) {
+      const float a = X[ap + k0];
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, WG[bq + k0 * g.ldw + tj * 16], acc[tj], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = ti * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
+        float v = acc[tj][r];
+        asm volatile("" : "+v"(v));
+        if (n < g.N && j < g.d) f(n, j, v);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// log p(theta, D | G_s) for all samples.  grid = (ceil(S / spb), Mloc), block = 256
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_lin_logprobs(const float* __restrict__ x, const int32_t* __restrict__ mask,
+                                                      const float* __restrict__ theta, const float* __restrict__ scores,
+                                                      const uint32_t* __restrict__ thr, float* __restrict__ logprobs, Key2 carry,
+                                                      int mode, int m0, int M_global, int d, int N, int S, int spb, float alpha,
+                                                      float tau, int layout, int tiny, float obs_noise, float mu, float sig,
+                                                      int any_mask) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const LinGeom g = lin_geom(d, N, NT);
+  float* X = smem;
+  float* TH = X + (size_t)g.np * g.ldx;
+  float* WG = TH + (size_t)d * d;
+  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)d * d + (size_t)g.kp * g.ldw) + 3) & ~(size_t)3));
+  const int m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t dd = (size_t)d * d;
+  lin_load_common<NT>(X, TH, x, theta + (size_t)m * dd, g, tid);
+  const Key2 key = lin_mode_key(mode, carry, M_global, m0 + m, layout);
+  const uint64_t nbits = (uint64_t)S * dd;
+  const float inv2 = 0.5f / obs_noise;
+  const float lognorm_x = -0.5f * logf(obs_noise) - 0.918938533204672742f;
+  for (int c = 0; c < spb; ++c) {
+    const int s = blockIdx.x * spb + c;
+    if (s >= S) break;
+    __syncthreads();
+    float part = lin_build_wg<NT>(WG, TH, mode, key, nbits, s, thr + (size_t)m * dd, scores + (size_t)m * dd, alpha, tau, layout,
+                                  tiny, mu, sig, g, tid);
+    __syncthreads();
+    lin_pred_tiles<NT>(X, WG, g, lane, wave, [&](int n, int j, float pred) {
+      if (any_mask && mask[(size_t)n * d + j]) return;
+      const float e = X[n * g.ldx + j] - pred;
+      part += lognorm_x - inv2 * e * e;
+    });
+    const double tot = wave_sum_d((double)part);
+    if (lane == 0) red[wave] = tot;
+    __syncthreads();
+    if (tid == 0) logprobs[(size_t)m * S + s] = (float)(red[0] + red[1] + red[2] + red[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// softmax-weighted gradient: w = softmax(l); only samples with w_s != 0 are re-evaluated (in float the weights of
+// all but a few samples underflow to exactly 0 -- the oracle skips them the same way).
+//   mode THETA     : grad_theta = sum_s w_s g_s o (-(theta - mu)/sig^2 + x^T r_s)   -> pack row (+ copy of theta)
+//   mode Z_REPARAM : W = sum_s w_s (logN(theta) + theta o x^T r_s) o tau alpha g~(1 - g~), off-diagonal   -> w_lik
+//   mode Z_SCORE   : W = scale * alpha (sum_s w_s G_s - P), off-diagonal                                 -> w_lik
+// grid = Mloc, block = 256
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_lin_grad(const float* __restrict__ x, const int32_t* __restrict__ mask,
+                                                  const float* __restrict__ theta, const float* __restrict__ scores,
+                                                  const uint32_t* __restrict__ thr, const float* __restrict__ logprobs,
+                                                  float* __restrict__ out, size_t out_stride, float* __restrict__ theta_copy,
+                                                  const float* __restrict__ baseline, float* __restrict__ baseline_out,
+                                                  Key2 carry, int mode, int m0, int M_global, int d, int N, int S, float alpha,
+                                                  float tau, int layout, int tiny, float obs_noise, float mu, float sig,
+                                                  double sf_baseline, int any_mask) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const LinGeom g = lin_geom(d, N, NT);
+  float* X = smem;
+  float* TH = X + (size_t)g.np * g.ldx;
+  float* WG = TH + (size_t)d * d;
+  float* RS = WG + (size_t)g.kp * g.ldw;  // residuals [np][ldw]
+  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)d * d + (size_t)g.kp * g.ldw + (size_t)g.np * g.ldw) + 3) & ~(size_t)3));
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t dd = (size_t)d * d;
+  lin_load_common<NT>(X, TH, x, theta + (size_t)m * dd, g, tid);
+  for (int e = tid; e < g.np * g.ldw; e += 256) RS[e] = 0.f;
+  const Key2 key = lin_mode_key(mode, carry, M_global, m0 + m, layout);
+  const uint64_t nbits = (uint64_t)S * dd;
+  const float* lp = logprobs + (size_t)m * S;
+  // softmax statistics (double)
+  double mx = -INFINITY;
+  for (int s = tid; s < S; s += 256) mx = (double)lp[s] > mx ? (double)lp[s] : mx;
+  mx = wave_max_d(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = red[0];
+  for (int w = 1; w < 4; ++w) mx = red[w] > mx ? red[w] : mx;
+  double den = 0.0, sm = 0.0;
+  for (int s = tid; s < S; s += 256) {
+    den += exp((double)lp[s] - mx);
+    sm += (double)lp[s];
+  }
+  den = wave_sum_d(den);
+  sm = wave_sum_d(sm);
+  __syncthreads();
+  if (lane == 0) {
+    red[wave] = den;
+    red[4 + wave] = sm;
+  }
+  __syncthreads();
+  den = red[0] + red[1] + red[2] + red[3];
+  sm = red[4] + red[5] + red[6] + red[7];
+
+  // accumulators in the MFMA C layout: element (i = ti*16 + (lane>>4)*4 + r, j = tj*16 + (lane&15)), ti = wave + 4*u
+  constexpr int NU = (NT + 3) / 4;
+  f32x4 acc[NU][NT];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj) acc[u][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float inv_on = 1.0f / obs_noise;
+  const float* sc_m = scores + (size_t)m * dd;
+  const uint32_t* thr_m = thr + (size_t)m * dd;
+
+  for (int s = 0; s < S; ++s) {
+    const float w = (float)(exp((double)lp[s] - mx) / den);
+    if (w == 0.f) continue;  // block-uniform
+    if (mode == LIN_MODE_Z_SCORE) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = (wave + 4 * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
+            if (i < d && j < d) acc[u][tj][r] += w * lin_sample_g(mode, key, nbits, dd, s, i, j, d, thr_m, sc_m, alpha, tau, layout, tiny);
+          }
+      continue;
+    }
+    __syncthreads();
+    lin_build_wg<NT>(WG, TH, mode, key, nbits, s, thr_m, sc_m, alpha, tau, layout, tiny, mu, sig, g, tid);
+    __syncthreads();
+    lin_pred_tiles<NT>(X, WG, g, lane, wave, [&](int n, int j, float pred) {
+      const bool mk = any_mask && mask[(size_t)n * d + j];
+      RS[n * g.ldw + j] = mk ? 0.f : (X[n * g.ldx + j] - pred) * inv_on;
+    });
+    __syncthreads();
+    // xtr = X^T * RS (K = np), then fold into the accumulators
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int ti = wave + 4 * u;
+      if (ti >= NT) break;
+      f32x4 t[NT];
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) t[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int ap = (lane >> 4) * g.ldx + ti * 16 + (lane & 15);
+      const int bq = (lane >> 4) * g.ldw + (lane & 15);
+      for (int k0 = 0; k0 < g.np; k0 += 4) {
+        const float a = X[ap + k0 * g.ldx];
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) t[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, RS[bq + k0 * g.ldw + tj * 16], t[tj], 0, 0, 0);
+      }
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = ti * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
+          if (i < d && j < d) {
+            float xtr = t[tj][r];
+            asm volatile("" : "+v"(xtr));
+            const float th = TH[i * d + j];
+            if (mode == LIN_MODE_THETA) {
+              const float gv = lin_sample_g(mode, key, nbits, dd, s, i, j, d, thr_m, sc_m, alpha, tau, layout, tiny);
+              acc[u][tj][r] += w * gv * (-(th - mu) / (sig * sig) + xtr);
+            } else if (i != j) {
+              const float gv = lin_sample_g(mode, key, nbits, dd, s, i, j, d, thr_m, sc_m, alpha, tau, layout, tiny);
+              acc[u][tj][r] += w * (lin_logn(th, mu, sig) + th * xtr) * tau * alpha * gv * (1.0f - gv);
+            }
+          }
+        }
+    }
+  }
+  // epilogue
+  const float bold = baseline ? baseline[m] : 0.f;
+  const float scale = (mode == LIN_MODE_Z_SCORE && sf_baseline > 0.0) ? (float)exp(-(double)bold) : 1.0f;
+  float* om = out + (size_t)m * out_stride;
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = (wave + 4 * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
+        if (i < d && j < d) {
+          float v = acc[u][tj][r];
+          if (mode == LIN_MODE_Z_SCORE) {
+            const float p = (float)sigmoid_d((double)__fmul_rn(alpha, sc_m[i * d + j]));
+            v = i == j ? 0.f : scale * alpha * (v - p);
+          }
+          om[i * d + j] = v;
+          if (theta_copy) theta_copy[(size_t)m * out_stride + i * d + j] = TH[i * d + j];
+        }
+      }
+  if (mode != LIN_MODE_THETA && baseline_out && tid == 0)
+    baseline_out[m] = (mode == LIN_MODE_Z_SCORE) ? (float)(sf_baseline * (sm / S) + (1.0 - sf_baseline) * (double)bold) : bold;
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+static inline int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) {
+  (void)d;
+  (void)N;
+  w->x = nullptr;
+  w->mask = nullptr;
+  w->any_mask = 0;
+  if (hipMalloc((void**)&w->wsm, (size_t)Mloc * S * 4) != hipSuccess) return 1;
+  return 0;
+}
+static inline void joint_free(JointWork* w) {
+  if (w->x) hipFree(w->x);
+  if (w->mask) hipFree(w->mask);
+  if (w->wsm) hipFree(w->wsm);
+  w->x = nullptr;
+  w->mask = nullptr;
+  w->wsm = nullptr;
+}
+static inline int joint_set_data(JointWork* w, const float* x, const int32_t* mask, int N, int d) {
+  const size_t n = (size_t)N * d;
+  if (w->x) hipFree(w->x);
+  if (w->mask) hipFree(w->mask);
+  if (hipMalloc((void**)&w->x, n * 4) != hipSuccess) return 1;
+  if (hipMalloc((void**)&w->mask, n * 4) != hipSuccess) return 1;
+  if (hipMemcpy(w->x, x, n * 4, hipMemcpyHostToDevice) != hipSuccess) return 1;
+  w->any_mask = 0;
+  if (mask) {
+    for (size_t i = 0; i < n; ++i) w->any_mask |= mask[i] != 0;
+    if (hipMemcpy(w->mask, mask, n * 4, hipMemcpyHostToDevice) != hipSuccess) return 1;
+  } else if (hipMemset(w->mask, 0, n * 4) != hipSuccess) {
+    return 1;
+  }
+  return 0;
+}
+
+template <int NT>
+static void joint_lin_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode) {
+  const int spb = 4;
+  const size_t lds1 = lin_lds_bytes(jl.d, jl.N, NT, false), lds2 = lin_lds_bytes(jl.d, jl.N, NT, true);
+  if (lds1 > 48 * 1024) hipFuncSetAttribute((const void*)k_lin_logprobs<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+  if (lds2 > 48 * 1024) hipFuncSetAttribute((const void*)k_lin_grad<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+  float* lp = mode == LIN_MODE_THETA ? jl.logprobs_th : jl.logprobs_z;
+  hipLaunchKernelGGL(k_lin_logprobs<NT>, dim3((jl.S + spb - 1) / spb, jl.Mloc), dim3(256), lds1, jl.stream, w->x, w->mask, jl.theta,
+                     jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, spb, jl.alpha, jl.tau, jl.layout, jl.tiny,
+                     jl.obs_noise, jl.mean_edge, jl.sig_edge, w->any_mask);
+  float* out = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off : jl.w_lik;
+  const size_t ostride = mode == LIN_MODE_THETA ? jl.pack_stride : (size_t)jl.d * jl.d;
+  float* tcopy = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr;
+  hipLaunchKernelGGL(k_lin_grad<NT>, dim3(jl.Mloc), dim3(256), lds2, jl.stream, w->x, w->mask, jl.theta, jl.scores, jl.thr, lp, out,
+                     ostride, tcopy, jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode, jl.m0,
+                     jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise, jl.mean_edge, jl.sig_edge,
+                     jl.sf_baseline, w->any_mask);
+}
+
+static inline void joint_lin_dispatch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode) {
+  switch ((jl.d + 15) / 16) {
+    case 1: joint_lin_launch<1>(w, jl, carry, mode); break;
+    case 2: joint_lin_launch<2>(w, jl, carry, mode); break;
+    case 3: joint_lin_launch<3>(w, jl, carry, mode); break;
+    case 4: joint_lin_launch<4>(w, jl, carry, mode); break;
+    case 5: joint_lin_launch<5>(w, jl, carry, mode); break;
+    case 6: joint_lin_launch<6>(w, jl, carry, mode); break;
+    default: joint_lin_launch<7>(w, jl, carry, mode); break;
+  }
+}
+static inline void joint_lin_theta(JointWork* w, const JointLaunch& jl, Key2 carry) { joint_lin_dispatch(w, jl, carry, LIN_MODE_THETA); }
+static inline void joint_lin_z(JointWork* w, const JointLaunch& jl, Key2 carry) {
+  joint_lin_dispatch(w, jl, carry, jl.est_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM);
+}
