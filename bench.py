@@ -67,15 +67,11 @@ def main():
     eng.init_particles(random.PRNGKey(1))
 
     if N > 1:
-        n_loc = eng.gather_elems_per_rank()
-        send = torch.zeros(n_loc, dtype=torch.float32, device="cuda")
-        recv = torch.zeros(n_loc * N, dtype=torch.float32, device="cuda")
+        from dibs_amd.distributed import make_buffers, run_sharded
+        send, recv = make_buffers(eng, N, torch.device("cuda", local_rank), torch.float32)
 
         def run(t0, n):
-            for t in range(t0, t0 + n):
-                eng.step_local(t, send.data_ptr())
-                dist.all_gather_into_tensor(recv, send)
-                eng.step_update(t, recv.data_ptr())
+            run_sharded(eng, t0, n, send, recv)   # phase A -> one all-gather (RCCL) -> phase B, per step
     else:
         def run(t0, n):
             eng.run(t0, n)

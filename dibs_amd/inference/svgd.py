@@ -77,8 +77,8 @@ class _SVGDBase(DiBS):
             rng_layout=random.LAYOUT, has_interventions=bool(self.interv_mask.any()), rank=rank, n_ranks=n_ranks,
             device_id=device_id, **kw)
 
-    def _new_engine(self, n_particles, n_dim, **kw):
-        eng = Engine(self._make_config(n_particles, n_dim, **kw))
+    def _new_engine(self, n_particles, n_dim, stream=None, **kw):
+        eng = Engine(self._make_config(n_particles, n_dim, **kw), stream=stream)
         eng.set_data(self.x, self.interv_mask if self.interv_mask.any() else None,
                      getattr(self.likelihood_model, "mean_obs", None))
         return eng

@@ -93,6 +93,35 @@ class COracle:
             raise RuntimeError(f"orc_step failed rc={rc}")
         return out
 
+    def pack_stride(self, cfg):
+        self.lib.orc_pack_stride.restype = C.c_int64
+        return int(self.lib.orc_pack_stride(C.byref(cfg)))
+
+    def new_local_state(self, cfg, key):
+        """state of the shard cfg.rank of cfg.n_ranks (same init streams as the global state)"""
+        full = DibsConfig.from_buffer_copy(cfg)
+        full.rank, full.n_ranks = 0, 1
+        st = self.new_state(full, key)
+        Ml = cfg.n_particles // cfg.n_ranks
+        sl = slice(cfg.rank * Ml, (cfg.rank + 1) * Ml)
+        return {k: (v[sl].copy() if (v is not None and k != "key") else v) for k, v in st.items()}
+
+    def step_local(self, cfg, x, mask, st, t, pack_local, bge_mode=1, n_threads=0, mean_obs=None):
+        x = np.ascontiguousarray(x, self.real)
+        mask = None if mask is None else np.ascontiguousarray(mask, np.int32)
+        mean_obs = None if mean_obs is None else np.ascontiguousarray(mean_obs, self.real)
+        rc = self.lib.orc_step_local(C.byref(cfg), self._p(x), self._p(mask), self._p(mean_obs), self._p(st["z"]),
+                                     self._p(st["theta"]), self._p(st["key"]), self._p(st["baseline"]), int(t),
+                                     self._p(pack_local), None, int(bge_mode), int(n_threads))
+        if rc != 0:
+            raise RuntimeError(f"orc_step_local failed rc={rc}")
+
+    def step_update(self, cfg, pack_all, st, n_threads=0):
+        rc = self.lib.orc_step_update(C.byref(cfg), self._p(pack_all), self._p(st["z"]), self._p(st["v_z"]),
+                                      self._p(st["theta"]), self._p(st["v_theta"]), None, int(n_threads))
+        if rc != 0:
+            raise RuntimeError(f"orc_step_update failed rc={rc}")
+
     def run(self, cfg, x, mask, st, t_start, n_steps, bge_mode=1, n_threads=0, mean_obs=None):
         x = np.ascontiguousarray(x, self.real)
         mask = None if mask is None else np.ascontiguousarray(mask, np.int32)

@@ -580,12 +580,24 @@ static void matpow(const real* m, int n, real* result, real* zb, real* tmp, int 
 
 static inline double sigmoid_d(double v) { return 1.0 / (1.0 + exp(-v)); }
 
-ORC_EXPORT int orc_step(const dibs_config* c, const real* x, const int32_t* mask, const real* mean_obs, real* z,
-                        real* vz, real* theta, real* vtheta, uint32_t key[2], real* baseline, int t, orc_debug* dbg,
-                        int bge_mode, int n_threads) {
-  const int d = c->n_vars, k = c->n_dim, M = c->n_particles, S = c->n_grad_mc_samples, Sa = c->n_acyclicity_mc_samples;
+/* One SVGD step in two phases so that particles can be sharded over ranks:
+ *   phase A (local)  : estimators for the particles [m0, m0 + Mloc) of this rank -> packed rows
+ *                      [z | grad_z | theta | grad_theta] (row stride E = ceil4(2D + 2P)), key / baseline advance
+ *   phase B (update) : kernel rows, phi and optimizer step for the local particles from ALL packed rows.
+ * z, vz, theta, vtheta, baseline are the LOCAL shards; PRNG rows are indexed by the GLOBAL particle id. */
+static int64_t pack_stride(const dibs_config* c) {
+  const int64_t D = (int64_t)c->n_vars * c->n_dim * 2, P = orc_theta_size(c);
+  return (2 * D + 2 * P + 3) & ~(int64_t)3;
+}
+ORC_EXPORT int64_t orc_pack_stride(const dibs_config* c) { return pack_stride(c); }
+
+ORC_EXPORT int orc_step_local(const dibs_config* c, const real* x, const int32_t* mask, const real* mean_obs, real* z,
+                              real* theta, uint32_t key[2], real* baseline, int t, real* pack_local, orc_debug* dbg,
+                              int bge_mode, int n_threads) {
+  const int d = c->n_vars, k = c->n_dim, Mg = c->n_particles, S = c->n_grad_mc_samples, Sa = c->n_acyclicity_mc_samples;
+  const int M = Mg / c->n_ranks, m0 = c->rank * M; /* M = local particle count from here on */
   const int L = c->rng_layout;
-  const int64_t D = (int64_t)d * k * 2, dd = (int64_t)d * d, P = orc_theta_size(c);
+  const int64_t D = (int64_t)d * k * 2, dd = (int64_t)d * d, P = orc_theta_size(c), E = pack_stride(c);
   const real alpha = (real)(c->alpha_linear * t), beta = (real)(c->beta_linear * t), tau = (real)c->tau;
   const double sigz = latent_std(c);
   if (d > 256) return 2;
@@ -616,17 +628,17 @@ ORC_EXPORT int orc_step(const dibs_config* c, const real* x, const int32_t* mask
       }
 
   uint32_t carry[2] = {key[0], key[1]};
-  uint32_t* pk = (uint32_t*)malloc(sizeof(uint32_t) * 2 * (M + 1));
+  uint32_t* pk = (uint32_t*)malloc(sizeof(uint32_t) * 2 * (Mg + 1));
 
   /* ---- theta estimator (joint only; FIRST key batch, svgd.py:695-696) ---- */
   if (c->joint) {
-    orc_split(carry, M + 1, L, pk);
+    orc_split(carry, Mg + 1, L, pk);
     carry[0] = pk[0];
     carry[1] = pk[1];
     int err = 0;
 #pragma omp parallel for schedule(dynamic)
     for (int m = 0; m < M; ++m) {
-      const uint32_t* km = pk + 2 * (1 + m);
+      const uint32_t* km = pk + 2 * (1 + m0 + m);
       real* g = (real*)malloc(sizeof(real) * dd);
       real* dth = (real*)malloc(sizeof(real) * P);
       real* acc = (real*)calloc(P, sizeof(real));
@@ -669,7 +681,7 @@ ORC_EXPORT int orc_step(const dibs_config* c, const real* x, const int32_t* mask
   }
 
   /* ---- Z likelihood estimator ---- */
-  orc_split(carry, M + 1, L, pk);
+  orc_split(carry, Mg + 1, L, pk);
   carry[0] = pk[0];
   carry[1] = pk[1];
   if (c->grad_estimator_z != DIBS_EST_SCORE && c->grad_estimator_z != DIBS_EST_REPARAM) return 4;
@@ -677,7 +689,7 @@ ORC_EXPORT int orc_step(const dibs_config* c, const real* x, const int32_t* mask
 #pragma omp parallel for schedule(dynamic)
   for (int m = 0; m < M; ++m) {
     uint32_t sp[4];
-    orc_split(pk + 2 * (1 + m), 2, L, sp); /* subk, subk_ = split(subk)  dibs.py:350 / :430 */
+    orc_split(pk + 2 * (1 + m0 + m), 2, L, sp); /* subk, subk_ = split(subk)  dibs.py:350 / :430 */
     const uint32_t* kg = sp + 2;
     real* g = (real*)malloc(sizeof(real) * dd);
     uint8_t* gh = (uint8_t*)malloc(dd);
@@ -762,7 +774,7 @@ ORC_EXPORT int orc_step(const dibs_config* c, const real* x, const int32_t* mask
   }
 
   /* ---- latent prior: acyclicity + graph prior  (dibs.py:557-658) ---- */
-  orc_split(carry, M + 1, L, pk);
+  orc_split(carry, Mg + 1, L, pk);
   carry[0] = pk[0];
   carry[1] = pk[1];
   double er_c = 0;
@@ -772,7 +784,7 @@ ORC_EXPORT int orc_step(const dibs_config* c, const real* x, const int32_t* mask
   }
 #pragma omp parallel for schedule(dynamic)
   for (int m = 0; m < M; ++m) {
-    const uint32_t* km = pk + 2 * (1 + m); /* particle key itself: dibs.py:595 */
+    const uint32_t* km = pk + 2 * (1 + m0 + m); /* particle key itself: dibs.py:595 */
     real* gs = (real*)malloc(sizeof(real) * dd);
     real* mm = (real*)malloc(sizeof(real) * dd);
     real* pw = (real*)malloc(sizeof(real) * dd);
@@ -835,45 +847,17 @@ ORC_EXPORT int orc_step(const dibs_config* c, const real* x, const int32_t* mask
     free(W); free(Pm); free(colsum);
   }
 
-  /* ---- kernel matrix (kernel.py:20-30 / 52-71) ---- */
-  real* kz = (real*)malloc(sizeof(real) * (size_t)M * M);
-  real* kt = (real*)calloc((size_t)M * M, sizeof(real));
-#pragma omp parallel for schedule(dynamic)
-  for (int a = 0; a < M; ++a)
-    for (int b = 0; b < M; ++b) {
-      double s = 0;
-      for (int64_t i = 0; i < D; ++i) { double df = (double)z[a * D + i] - (double)z[b * D + i]; s += df * df; }
-      kz[(size_t)a * M + b] = (real)(c->scale_latent * exp(-s / c->h_latent));
-      if (c->joint) {
-        double st = 0;
-        for (int64_t i = 0; i < P; ++i) { double df = (double)theta[a * P + i] - (double)theta[b * P + i]; st += df * df; }
-        kt[(size_t)a * M + b] = (real)(c->scale_theta * exp(-st / c->h_theta));
-      }
+  /* ---- pack rows [z | grad_z | theta | grad_theta] ---- */
+  for (int m = 0; m < M; ++m) {
+    real* row = pack_local + (int64_t)m * E;
+    memcpy(row, z + m * D, sizeof(real) * D);
+    memcpy(row + D, gradz + m * D, sizeof(real) * D);
+    if (P) {
+      memcpy(row + 2 * D, theta + m * P, sizeof(real) * P);
+      memcpy(row + 2 * D + P, gradth + m * P, sizeof(real) * P);
     }
-
-  /* ---- phi (svgd.py:194-224, 591-670):  phi_a = -(1/M) sum_b [ k[b,a] grad_b - (2/h) k_z[b,a] (z_b - z_a) ] ---- */
-  real* phiz = (real*)malloc(sizeof(real) * M * D);
-  real* phith = P ? (real*)malloc(sizeof(real) * M * P) : NULL;
-#pragma omp parallel for schedule(dynamic)
-  for (int a = 0; a < M; ++a) {
-    for (int64_t i = 0; i < D; ++i) {
-      double s = 0;
-      for (int b = 0; b < M; ++b) {
-        double kk = (double)kz[(size_t)b * M + a] + (double)kt[(size_t)b * M + a];
-        s += kk * (double)gradz[b * D + i] - (2.0 / c->h_latent) * (double)kz[(size_t)b * M + a] * ((double)z[b * D + i] - (double)z[a * D + i]);
-      }
-      phiz[a * D + i] = (real)(-s / M);
-    }
-    for (int64_t i = 0; i < P; ++i) {
-      double s = 0;
-      for (int b = 0; b < M; ++b) {
-        double kk = (double)kz[(size_t)b * M + a] + (double)kt[(size_t)b * M + a];
-        s += kk * (double)gradth[b * P + i] - (2.0 / c->h_theta) * (double)kt[(size_t)b * M + a] * ((double)theta[b * P + i] - (double)theta[a * P + i]);
-      }
-      phith[a * P + i] = (real)(-s / M);
-    }
+    for (int64_t i = 2 * D + 2 * P; i < E; ++i) row[i] = 0;
   }
-
   if (dbg) {
     if (dbg->scores) memcpy(dbg->scores, scores, sizeof(real) * M * dd);
     if (dbg->logprobs_z) memcpy(dbg->logprobs_z, lpz, sizeof(real) * (size_t)M * S);
@@ -882,11 +866,71 @@ ORC_EXPORT int orc_step(const dibs_config* c, const real* x, const int32_t* mask
     if (dbg->w_acyc) memcpy(dbg->w_acyc, wacyc, sizeof(real) * M * dd);
     if (dbg->grad_z) memcpy(dbg->grad_z, gradz, sizeof(real) * M * D);
     if (dbg->grad_theta && P) memcpy(dbg->grad_theta, gradth, sizeof(real) * M * P);
-    if (dbg->kxx) for (size_t i = 0; i < (size_t)M * M; ++i) dbg->kxx[i] = kz[i] + kt[i];
+  }
+  for (int m = 0; m < M; ++m) baseline[m] = newb[m];
+  key[0] = carry[0];
+  key[1] = carry[1];
+  free(scores); free(wlik); free(wacyc); free(gradz); free(gradth); free(lpz); free(lpth); free(newb); free(pk);
+  if (c->likelihood == DIBS_LIK_BGE) bge_free(&bp);
+  return 0;
+}
+
+ORC_EXPORT int orc_step_update(const dibs_config* c, const real* pack_all, real* z, real* vz, real* theta, real* vtheta,
+                               orc_debug* dbg, int n_threads) {
+  const int d = c->n_vars, k = c->n_dim, Mg = c->n_particles;
+  const int M = Mg / c->n_ranks, m0 = c->rank * M;
+  const int64_t D = (int64_t)d * k * 2, P = orc_theta_size(c), E = pack_stride(c);
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+  /* ---- kernel rows (kernel.py:20-30 / 52-71): local a against all b ---- */
+  real* kz = (real*)malloc(sizeof(real) * (size_t)M * Mg);
+  real* kt = (real*)calloc((size_t)M * Mg, sizeof(real));
+#pragma omp parallel for schedule(dynamic)
+  for (int a = 0; a < M; ++a)
+    for (int b = 0; b < Mg; ++b) {
+      const real* ra = pack_all + (int64_t)(m0 + a) * E;
+      const real* rb = pack_all + (int64_t)b * E;
+      double s = 0;
+      for (int64_t i = 0; i < D; ++i) { double df = (double)ra[i] - (double)rb[i]; s += df * df; }
+      kz[(size_t)a * Mg + b] = (real)(c->scale_latent * exp(-s / c->h_latent));
+      if (c->joint) {
+        double st = 0;
+        for (int64_t i = 0; i < P; ++i) { double df = (double)ra[2 * D + i] - (double)rb[2 * D + i]; st += df * df; }
+        kt[(size_t)a * Mg + b] = (real)(c->scale_theta * exp(-st / c->h_theta));
+      }
+    }
+  /* ---- phi (svgd.py:194-224, 591-670): phi_a = -(1/M) sum_b [ k[b,a] grad_b - (2/h) k_seg[b,a] (x_b - x_a) ]
+   *      (column kxx[:, a]; the kernel is symmetric so row a of the local slab is that column) ---- */
+  real* phiz = (real*)malloc(sizeof(real) * M * D);
+  real* phith = P ? (real*)malloc(sizeof(real) * M * P) : NULL;
+#pragma omp parallel for schedule(dynamic)
+  for (int a = 0; a < M; ++a) {
+    const real* ra = pack_all + (int64_t)(m0 + a) * E;
+    for (int64_t i = 0; i < D; ++i) {
+      double s = 0;
+      for (int b = 0; b < Mg; ++b) {
+        const real* rb = pack_all + (int64_t)b * E;
+        double kk = (double)kz[(size_t)a * Mg + b] + (double)kt[(size_t)a * Mg + b];
+        s += kk * (double)rb[D + i] - (2.0 / c->h_latent) * (double)kz[(size_t)a * Mg + b] * ((double)rb[i] - (double)ra[i]);
+      }
+      phiz[a * D + i] = (real)(-s / Mg);
+    }
+    for (int64_t i = 0; i < P; ++i) {
+      double s = 0;
+      for (int b = 0; b < Mg; ++b) {
+        const real* rb = pack_all + (int64_t)b * E;
+        double kk = (double)kz[(size_t)a * Mg + b] + (double)kt[(size_t)a * Mg + b];
+        s += kk * (double)rb[2 * D + P + i] - (2.0 / c->h_theta) * (double)kt[(size_t)a * Mg + b] * ((double)rb[2 * D + i] - (double)ra[2 * D + i]);
+      }
+      phith[a * P + i] = (real)(-s / Mg);
+    }
+  }
+  if (dbg) {
+    if (dbg->kxx) for (size_t i = 0; i < (size_t)M * Mg; ++i) dbg->kxx[i] = kz[i] + kt[i];
     if (dbg->phi_z) memcpy(dbg->phi_z, phiz, sizeof(real) * M * D);
     if (dbg->phi_theta && P) memcpy(dbg->phi_theta, phith, sizeof(real) * M * P);
   }
-
   /* ---- optimizer (jax.example_libraries.optimizers.rmsprop: gamma 0.9, eps 1e-8 inside the sqrt) ---- */
   for (int pass = 0; pass < 2; ++pass) {
     real* xx = pass ? theta : z;
@@ -902,14 +946,20 @@ ORC_EXPORT int orc_step(const dibs_config* c, const real* x, const int32_t* mask
       }
     }
   }
-  for (int m = 0; m < M; ++m) baseline[m] = newb[m];
-  key[0] = carry[0];
-  key[1] = carry[1];
-
-  free(scores); free(wlik); free(wacyc); free(gradz); free(gradth); free(lpz); free(lpth); free(newb);
-  free(pk); free(kz); free(kt); free(phiz); free(phith);
-  if (c->likelihood == DIBS_LIK_BGE) bge_free(&bp);
+  free(kz); free(kt); free(phiz); free(phith);
   return 0;
+}
+
+/* single-rank step = phase A + phase B on the same rows */
+ORC_EXPORT int orc_step(const dibs_config* c, const real* x, const int32_t* mask, const real* mean_obs, real* z,
+                        real* vz, real* theta, real* vtheta, uint32_t key[2], real* baseline, int t, orc_debug* dbg,
+                        int bge_mode, int n_threads) {
+  if (c->n_ranks != 1) return 9;
+  real* pack = (real*)malloc(sizeof(real) * (size_t)c->n_particles * pack_stride(c));
+  int rc = orc_step_local(c, x, mask, mean_obs, z, theta, key, baseline, t, pack, dbg, bge_mode, n_threads);
+  if (!rc) rc = orc_step_update(c, pack, z, vz, theta, vtheta, dbg, n_threads);
+  free(pack);
+  return rc;
 }
 
 ORC_EXPORT int orc_run(const dibs_config* c, const real* x, const int32_t* mask, const real* mean_obs, real* z, real* vz,

@@ -5,10 +5,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dibs_amd._abi import make_config
 from dibs_amd.engine import Engine
 from dibs_amd import random
-from dibs_amd.target import make_linear_gaussian_equivalent_model
+from dibs_amd.target import make_linear_gaussian_equivalent_model, make_linear_gaussian_model
 d, M = 50, 128
-data, _, _ = make_linear_gaussian_equivalent_model(key=random.PRNGKey(0), n_vars=d, graph_prior_str="er")
-cfg = make_config(n_vars=d, n_particles=M, n_observations=100)
+JOINT = len(sys.argv) > 1 and sys.argv[1] == "joint"
+if JOINT:
+    data, _, _ = make_linear_gaussian_model(key=random.PRNGKey(0), n_vars=d, graph_prior_str="er")
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=100, joint=True, likelihood="lingauss")
+else:
+    data, _, _ = make_linear_gaussian_equivalent_model(key=random.PRNGKey(0), n_vars=d, graph_prior_str="er")
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=100)
 eng = Engine(cfg); eng.set_data(data.x); eng.init_particles(random.PRNGKey(1))
 eng.set_profiling(True)
 t = 0
