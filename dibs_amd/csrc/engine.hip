@@ -56,6 +56,8 @@ struct dibs_engine {
   double t_ms[DIBS_K_COUNT];
   int64_t t_n[DIBS_K_COUNT];
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
+  bool has_mean_obs;
+  std::vector<float> mean_obs;
 };
 
 extern "C" const char* dibs_last_error(void) { return g_err.c_str(); }
@@ -127,8 +129,7 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(std::string("libdibs_hip is built for gfx950 only; device is ") + prop.gcnArchName);
 
-  dibs_engine* e = new dibs_engine();
-  memset((void*)e, 0, offsetof(dibs_engine, pending));
+  dibs_engine* e = new dibs_engine();  // value-initialised: every POD member starts at zero
   e->cfg = c;
   e->d = c.n_vars;
   e->k = c.n_dim;
@@ -280,6 +281,8 @@ extern "C" int dibs_engine_set_data(dibs_engine* e, const float* x, const int32_
   HIP_OK(hipMemcpy(e->x, x, n * 4, hipMemcpyHostToDevice));
   if (interv_mask) HIP_OK(hipMemcpy(e->mask, interv_mask, n * 4, hipMemcpyHostToDevice));
   if (e->cfg.likelihood == DIBS_LIK_BGE) {
+    e->has_mean_obs = bge_mean_obs != nullptr;
+    if (bge_mean_obs) e->mean_obs.assign(bge_mean_obs, bge_mean_obs + e->d);
     if (bge_prepare(e, x, interv_mask, bge_mean_obs)) return 1;
   } else if (e->cfg.likelihood == DIBS_LIK_LINGAUSS) {
     if (joint_set_data(&e->jw, x, interv_mask, e->N, e->d)) return fail("joint_set_data failed");
@@ -436,12 +439,12 @@ static int step_local(dibs_engine* e, int t, float* pack) {
       unsigned long long* cnt = e->profiling ? e->counters : (unsigned long long*)nullptr;
       const size_t lds4 = bge_lds_bytes(e->d, e->S, e->W, 4), lds1 = bge_lds_bytes(e->d, e->S, e->W, 1);
       if (e->n_mats == 1 && lds4 <= 80 * 1024) {
-        allow_lds(k_bge_nodes<4>, lds4);
-        hipLaunchKernelGGL(k_bge_nodes<4>, dim3((e->d + 3) / 4, e->Mloc), dim3(256), lds4, e->stream, e->thr, e->masks,
+        allow_lds(k_bge_nodes<4, true>, lds4);
+        hipLaunchKernelGGL((k_bge_nodes<4, true>), dim3((e->d + 3) / 4, e->Mloc), dim3(256), lds4, e->stream, e->thr, e->masks,
                            e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L, cnt);
       } else {
-        allow_lds(k_bge_nodes<1>, lds1);
-        hipLaunchKernelGGL(k_bge_nodes<1>, dim3(e->d, e->Mloc), dim3(64), lds1, e->stream, e->thr, e->masks,
+        allow_lds(k_bge_nodes<1, true>, lds1);
+        hipLaunchKernelGGL((k_bge_nodes<1, true>), dim3(e->d, e->Mloc), dim3(64), lds1, e->stream, e->thr, e->masks,
                            e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L, cnt);
       }
     }
@@ -673,8 +676,113 @@ extern "C" int dibs_engine_get_counters(dibs_engine* e, double* out, int32_t n) 
   return 0;
 }
 
+// BGe statistics of an arbitrary data set (host, double) -> device buffers
+struct BgeStats {
+  float* R = nullptr;
+  double* gam = nullptr;
+  double* Nj = nullptr;
+  int n_mats = 1;
+  double alpha_lambd = 0;
+  ~BgeStats() {
+    if (R) hipFree(R);
+    if (gam) hipFree(gam);
+    if (Nj) hipFree(Nj);
+  }
+};
+
+template <int NT>
+static void launch_lin_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N,
+                             const dibs_config& c, hipStream_t stream) {
+  const size_t lds = lin_lds_bytes(d, N, NT, false);
+  allow_lds(k_lin_logprobs<NT>, lds);
+  hipLaunchKernelGGL(k_lin_logprobs<NT>, dim3(1, n), dim3(256), lds, stream, jw.x, jw.mask, theta, (const float*)nullptr,
+                     reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, N, 1, 1, 0.f, 1.f, 0, 0,
+                     (float)c.lin_obs_noise, (float)c.lin_mean_edge, (float)c.lin_sig_edge, jw.any_mask);
+}
+
 extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* theta, int32_t n, const float* x_ho,
                                  const int32_t* mask_ho, int32_t n_ho, float* out) {
-  (void)e; (void)g; (void)theta; (void)n; (void)x_ho; (void)mask_ho; (void)n_ho; (void)out;
-  return fail("dibs_score_graphs: not implemented yet");
+  if (!e || !g || !x_ho || !out) return fail("null argument");
+  if (n <= 0) return 0;
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  HIP_OK(hipStreamSynchronize(e->stream));
+  const dibs_config& c = e->cfg;
+  const int d = e->d;
+  const size_t dd = (size_t)d * d;
+  float* d_out = nullptr;
+  HIP_OK(dalloc(&d_out, (size_t)n));
+  int rc = 0;
+  if (c.likelihood == DIBS_LIK_BGE) {
+    // statistics of (x_ho, mask_ho): temporarily swap them into the engine, reuse bge_prepare
+    float* R0 = e->R; double *g0 = e->gam, *N0 = e->Nj; const int nm0 = e->n_mats, Nsave = e->N; const double al0 = e->alpha_lambd;
+    e->R = nullptr; e->gam = nullptr; e->Nj = nullptr; e->N = n_ho;
+    std::vector<float> mo;
+    if (e->has_mean_obs) mo = e->mean_obs;
+    rc = bge_prepare(e, x_ho, mask_ho, e->has_mean_obs ? mo.data() : nullptr);
+    BgeStats st;
+    st.R = e->R; st.gam = e->gam; st.Nj = e->Nj; st.n_mats = e->n_mats; st.alpha_lambd = e->alpha_lambd;
+    e->R = R0; e->gam = g0; e->Nj = N0; e->n_mats = nm0; e->N = Nsave; e->alpha_lambd = al0;
+    if (rc) { hipFree(d_out); return 1; }
+    const int W = e->W, CH = 512;
+    uint64_t* d_masks = nullptr;
+    double* d_ns = nullptr;
+    HIP_OK(dalloc(&d_masks, (size_t)d * CH * W));
+    HIP_OK(dalloc(&d_ns, (size_t)d * CH));
+    std::vector<uint64_t> hm((size_t)d * CH * W);
+    for (int q0 = 0; q0 < n; q0 += CH) {
+      const int S = n - q0 < CH ? n - q0 : CH;
+      std::fill(hm.begin(), hm.end(), 0ull);
+      for (int s = 0; s < S; ++s)
+        for (int i = 0; i < d; ++i)
+          for (int j = 0; j < d; ++j)
+            if (i != j && g[(size_t)(q0 + s) * dd + (size_t)i * d + j] != 0) hm[((size_t)j * S + s) * W + (i >> 6)] |= 1ull << (i & 63);
+      HIP_OK(hipMemcpy(d_masks, hm.data(), (size_t)d * S * W * 8, hipMemcpyHostToDevice));
+      BgeParams bp{st.R, st.gam, st.Nj, st.alpha_lambd, st.n_mats};
+      const size_t lds4 = bge_lds_bytes(d, S, W, 4), lds1 = bge_lds_bytes(d, S, W, 1);
+      if (st.n_mats == 1 && lds4 <= 96 * 1024) {
+        allow_lds(k_bge_nodes<4, false>, lds4);
+        hipLaunchKernelGGL((k_bge_nodes<4, false>), dim3((d + 3) / 4, 1), dim3(256), lds4, e->stream, (const uint32_t*)nullptr,
+                           d_masks, d_ns, bp, Key2{0, 0}, 0, 1, d, S, W, 0, (unsigned long long*)nullptr);
+      } else {
+        allow_lds(k_bge_nodes<1, false>, lds1);
+        hipLaunchKernelGGL((k_bge_nodes<1, false>), dim3(d, 1), dim3(64), lds1, e->stream, (const uint32_t*)nullptr, d_masks,
+                           d_ns, bp, Key2{0, 0}, 0, 1, d, S, W, 0, (unsigned long long*)nullptr);
+      }
+      hipLaunchKernelGGL(k_sum_nodes, dim3((S + 127) / 128), dim3(128), 0, e->stream, d_ns, d_out + q0, d, S);
+      HIP_OK(hipStreamSynchronize(e->stream));
+    }
+    hipFree(d_masks);
+    hipFree(d_ns);
+  } else if (c.likelihood == DIBS_LIK_LINGAUSS) {
+    if (!theta) { hipFree(d_out); return fail("theta required"); }
+    JointWork jw;
+    memset(&jw, 0, sizeof jw);
+    if (joint_set_data(&jw, x_ho, mask_ho, n_ho, d)) { hipFree(d_out); return fail("joint_set_data failed"); }
+    float* d_th = nullptr;
+    int32_t* d_g = nullptr;
+    HIP_OK(dalloc(&d_th, (size_t)n * dd));
+    HIP_OK(dalloc(&d_g, (size_t)n * dd));
+    HIP_OK(hipMemcpy(d_th, theta, (size_t)n * dd * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_g, g, (size_t)n * dd * 4, hipMemcpyHostToDevice));
+    switch ((d + 15) / 16) {
+      case 1: launch_lin_given<1>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
+      case 2: launch_lin_given<2>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
+      case 3: launch_lin_given<3>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
+      case 4: launch_lin_given<4>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
+      case 5: launch_lin_given<5>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
+      case 6: launch_lin_given<6>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
+      default: launch_lin_given<7>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
+    }
+    HIP_OK(hipStreamSynchronize(e->stream));
+    hipFree(d_th);
+    hipFree(d_g);
+    joint_free(&jw);
+  } else {
+    hipFree(d_out);
+    return fail("dibs_score_graphs: likelihood not supported yet");
+  }
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
+  hipFree(d_out);
+  return 0;
 }

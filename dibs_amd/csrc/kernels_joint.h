@@ -11,7 +11,7 @@
 #include "rng.h"
 #include "kernels_marginal.h"
 
-enum { LIN_MODE_THETA = 0, LIN_MODE_Z_SCORE = 1, LIN_MODE_Z_REPARAM = 2 };
+enum { LIN_MODE_THETA = 0, LIN_MODE_Z_SCORE = 1, LIN_MODE_Z_REPARAM = 2, LIN_MODE_GIVEN = 3 };
 
 struct JointWork {
   float* x;        // [N, d] device copy
@@ -71,6 +71,7 @@ __device__ __forceinline__ float lin_logn(float v, float mu, float sig) {
 __device__ __forceinline__ float lin_sample_g(int mode, Key2 key, uint64_t nbits, uint64_t dd, int s, int i, int j, int d,
                                               const uint32_t* __restrict__ thr_m, const float* __restrict__ sc_m, float alpha,
                                               float tau, int layout, int tiny) {
+  if (mode == LIN_MODE_GIVEN) return reinterpret_cast<const int32_t*>(thr_m)[i * d + j] != 0 ? 1.0f : 0.0f;  // caller's graph
   if (i == j) return 0.f;
   const uint32_t bits = rng_bits_at(key, nbits, (uint64_t)s * dd + (uint64_t)i * d + j, layout);
   if (mode == LIN_MODE_Z_REPARAM) {

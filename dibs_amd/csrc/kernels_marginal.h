@@ -224,7 +224,7 @@ __device__ __forceinline__ double bge_chol_groups(const float* __restrict__ Rs, 
   return flops;
 }
 
-template <int WAVES>
+template <int WAVES, bool SAMPLE>
 __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __restrict__ thr, uint64_t* __restrict__ masks,
                                                           double* __restrict__ node_scores, BgeParams bp, Key2 carry,
                                                           int m0, int M_global, int d, int S, int W, int layout,
@@ -249,17 +249,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
     const float* Rg = bp.R + (bp.n_mats > 1 ? (size_t)(blockIdx.x * WAVES) * d * d : 0);
     for (int e = tid; e < d * d; e += 64 * WAVES) Rs[e] = Rg[e];
   }
-  if (active)
+  if (active && SAMPLE)
     for (int i = lane; i < d; i += 64) thrs[i] = thr[((size_t)m * d + i) * d + j];
   __syncthreads();
   if (!active) return;
+  if (!SAMPLE) {  // scoring of given graphs (dibs_score_graphs): the parent sets come from the caller
+    const uint64_t* mg = masks + ((size_t)m * d + j) * S * W;
+    for (int e = lane; e < S * W; e += 64) mk[e] = mg[e];
+  }
 
   // ---- 1. sample column j of the S graphs -------------------------------------------------------
   // particle key = row (1 + m_global) of split(carry, M+1); subk_ = row 1 of split(particle key)   dibs.py:350-351
   const Key2 kp = rng_split_row(carry, (uint32_t)M_global + 1u, (uint32_t)(m0 + m) + 1u, layout);
   const Key2 kg = rng_split_row(kp, 2u, 1u, layout);
   const uint64_t dd = (uint64_t)d * d, nbits = (uint64_t)S * dd;
-  if ((S & 1) == 0) {
+  if (!SAMPLE) {
+  } else if ((S & 1) == 0) {
     const int hS = S >> 1;
     for (int p = lane; p < hS; p += 64) {
       uint64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
     }
   }
   wave_lds_fence();
-  {
+  if (SAMPLE) {
     uint64_t* mg = masks + ((size_t)m * d + j) * S * W;
     for (int e = lane; e < S * W; e += 64) mg[e] = mk[e];
   }
@@ -418,6 +423,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
     const double tot = wave_sum_d(flops);
     if (lane == 0) atomicAdd(counters, (unsigned long long)tot);
   }
+}
+
+// out[s] = sum_j node_scores[j][s]   (scoring of given graphs)
+__global__ void k_sum_nodes(const double* __restrict__ node_scores, float* __restrict__ out, int d, int S) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  double t = 0.0;
+  for (int j = 0; j < d; ++j) t += node_scores[(size_t)j * S + s];
+  out[s] = (float)t;
 }
 
 // ------------------------------------------------------------------------------------------------

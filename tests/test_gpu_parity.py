@@ -303,3 +303,44 @@ def test_joint_sample_api():
     assert seen == [(3, (5, 8, 8, 2), (5, 8, 8)), (6, (5, 8, 8, 2), (5, 8, 8))]
     dist = dibs.get_empirical(g, theta)
     assert np.allclose(np.exp(dist.logp).sum(), 1.0)
+
+
+def test_score_graphs_and_mixture(c_oracle64):
+    """dibs_score_graphs (device) == oracle log p(D | G) / log p(theta, D | G); get_mixture / held-out evaluators."""
+    from dibs_amd.inference import JointDiBS, MarginalDiBS
+    from dibs_amd.inference.scoring import score_graphs
+    from dibs_amd.metrics import expected_shd, neg_ave_log_marginal_likelihood, neg_ave_log_likelihood
+    rng = np.random.default_rng(0)
+    for d in (6, 50, 70):
+        data, gm, lm = make_data(d, seed=1)
+        g = (rng.random((9, d, d)) < 0.15).astype(np.int32)
+        g[:, np.arange(d), np.arange(d)] = 0
+        g[0] = data.g
+        g[1] = 0
+        cfg = make_config(n_vars=d, n_particles=1, n_observations=100, edges_per_node=1 if d <= 6 else 2)
+        ref = c_oracle64.score_graphs(cfg, data.x, None, g)
+        got = score_graphs(lm, g, None, data.x, None)
+        assert rel_err(got, ref) < 2e-5
+        mask = (rng.random((100, d)) < 0.1).astype(np.int32)
+        ref = c_oracle64.score_graphs(cfg, data.x_ho, mask, g)
+        got = score_graphs(lm, g, None, data.x_ho, mask)
+        assert rel_err(got, ref) < 2e-5
+    data, gm, lm = make_data(6, seed=1)
+    dibs = MarginalDiBS(x=data.x, graph_model=gm, likelihood_model=lm)
+    g = (rng.random((5, 6, 6)) < 0.2).astype(np.int32)
+    g[:, np.arange(6), np.arange(6)] = 0
+    mix = dibs.get_mixture(g)
+    assert abs(np.exp(mix.logp).sum() - 1) < 1e-6
+    assert np.isfinite(neg_ave_log_marginal_likelihood(dist=mix, eltwise_log_marginal_likelihood=dibs.eltwise_log_marginal_likelihood_observ, x=data.x_ho))
+    assert expected_shd(dist=mix, g=data.g) >= 0
+    # joint
+    dataj, gmj, lmj = make_data(6, seed=2, joint=True)
+    th = rng.normal(size=(5, 6, 6)).astype(np.float32)
+    cfgj = make_config(n_vars=6, n_particles=1, n_observations=100, edges_per_node=1, joint=True, likelihood="lingauss")
+    ref = c_oracle64.score_graphs(cfgj, dataj.x, None, g, th.reshape(5, -1).astype(np.float64))
+    got = score_graphs(lmj, g, th, dataj.x, None)
+    assert rel_err(got, ref) < 2e-5
+    jd = JointDiBS(x=dataj.x, graph_model=gmj, likelihood_model=lmj)
+    mixj = jd.get_mixture(g, th)
+    assert abs(np.exp(mixj.logp).sum() - 1) < 1e-6
+    assert np.isfinite(neg_ave_log_likelihood(dist=mixj, eltwise_log_likelihood=jd.eltwise_log_likelihood_observ, x=dataj.x_ho))
