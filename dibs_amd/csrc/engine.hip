@@ -44,7 +44,7 @@ struct dibs_engine {
   double alpha_lambd;
   bool has_data;
   // work
-  float *scores, *w_lik, *acyc_part, *w_acyc, *logprobs_z, *logprobs_th, *pack, *kz, *kt, *phi_z, *phi_th;
+  float *scores, *probs, *w_tot, *w_lik, *acyc_part, *w_acyc, *logprobs_z, *logprobs_th, *pack, *kz, *kt, *phi_z, *phi_th;
   uint32_t* thr;
   uint64_t* masks;
   double* node_scores;
@@ -119,6 +119,7 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
     const size_t D4 = (size_t)c.n_vars * c.n_dim * 2 * 4;
     if (D4 > LDS_LIMIT - 1024) return fail("n_vars * n_dim too large for the kernel-matrix LDS tile");
     if ((size_t)2 * 8 * c.n_particles * 4 > LDS_LIMIT) return fail("n_particles too large (kernel rows must fit in LDS)");
+    if (((size_t)c.n_vars * c.n_vars + (size_t)2 * c.n_vars * c.n_dim) * 4 > LDS_LIMIT) return fail("n_vars * n_dim too large");
   }
   int ndev = 0;
   HIP_OK(hipGetDeviceCount(&ndev));
@@ -149,7 +150,20 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
     e->ldk = kp + ((2 - kp) % 32 + 32) % 32;  // ldk == 2 (mod 32): conflict-free MFMA operand reads
   }
   e->acyc_nt = e->dpad / 16;
-  e->acyc_cpb = 4;
+  {  // chains per block: fill the 256 CUs in whole rounds (resident blocks per CU limited by the 3 LDS matrices)
+    const size_t lds = (size_t)(3 * e->dpad + 1) * (e->dpad + 4) * 4;
+    const int per_cu = (int)(LDS_LIMIT / lds) < 1 ? 1 : (int)(LDS_LIMIT / lds);
+    const int slots = 256 * (per_cu > 8 ? 8 : per_cu);
+    int best = 1;
+    long best_cost = -1;
+    for (int cpb = 1; cpb <= e->Sa; ++cpb) {
+      const long nblk = (long)((e->Sa + cpb - 1) / cpb) * e->Mloc;
+      const long cost = ((nblk + slots - 1) / slots) * cpb;
+      if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cpb; }
+    }
+    e->acyc_cpb = best;
+    if (const char* ov = getenv("DIBS_ACYC_CPB")) e->acyc_cpb = atoi(ov) > 0 ? atoi(ov) : best;  // tuning override
+  }
   e->acyc_nblk = (e->Sa + e->acyc_cpb - 1) / e->acyc_cpb;
   e->sigz = c.latent_prior_std > 0 ? (float)c.latent_prior_std : 1.0f / sqrtf((float)e->k);
   if (stream) {
@@ -169,6 +183,8 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
   HIP_OK(dalloc(&e->baseline, Ml));
   HIP_OK(dalloc(&e->baseline2, Ml));
   HIP_OK(dalloc(&e->scores, Ml * dd));
+  HIP_OK(dalloc(&e->probs, Ml * dd));
+  HIP_OK(dalloc(&e->w_tot, Ml * dd));
   HIP_OK(dalloc(&e->thr, Ml * dd));
   HIP_OK(dalloc(&e->w_lik, Ml * dd));
   HIP_OK(dalloc(&e->acyc_part, Ml * e->acyc_nblk * dd));
@@ -196,7 +212,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (!e) return 0;
   hipSetDevice(e->cfg.device_id);
   hipStreamSynchronize(e->stream);
-  void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
+  void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->w_tot, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
                   e->node_scores, e->x, e->mask, e->R, e->gam, e->Nj};
   for (void* p : ptrs)
@@ -401,12 +417,12 @@ static Key2 next_carry(const dibs_engine* e, Key2 k) { return rng_split_row(k, (
 
 template <int NT>
 static void launch_acyc(dibs_engine* e, Key2 carry, float alpha) {
-  constexpr int DP = 16 * NT, LD = DP + 2;
-  const size_t lds = (size_t)3 * DP * LD * 4;
+  constexpr int DP = 16 * NT, LD = DP + 4;
+  const size_t lds = (size_t)(3 * DP + 1) * LD * 4;  // + one slack row (the k pipeline may load one step past the end)
   allow_lds(k_acyc<NT>, lds);
   hipLaunchKernelGGL(k_acyc<NT>, dim3(e->acyc_nblk, e->Mloc), dim3(256), lds, e->stream, e->scores, e->acyc_part, carry,
                      e->m0, e->M, e->d, e->Sa, e->acyc_cpb, alpha, (float)e->cfg.tau, e->cfg.rng_layout,
-                     e->cfg.logistic_minval_tiny);
+                     e->cfg.logistic_minval_tiny, getenv("DIBS_ACYC_DBG") ? atoi(getenv("DIBS_ACYC_DBG")) : 0);
 }
 
 static int step_local(dibs_engine* e, int t, float* pack) {
@@ -429,7 +445,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     KTimer tm(e, DIBS_K_EDGE);
     const size_t lds = (size_t)2 * e->dpad * e->ldk * 4;
     allow_lds(k_edge_scores, lds);
-    hipLaunchKernelGGL(k_edge_scores, dim3(e->Mloc), dim3(256), lds, e->stream, e->z, e->scores, e->thr, alpha, e->d, e->k,
+    hipLaunchKernelGGL(k_edge_scores, dim3(e->Mloc), dim3(256), lds, e->stream, e->z, e->scores, e->thr, e->probs, alpha, e->d, e->k,
                        e->dpad, e->ldk);
   }
   if (c.likelihood == DIBS_LIK_BGE) {
@@ -457,7 +473,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
       const size_t lds = base + (in_lds ? mbytes : 0);
       allow_lds(k_lik_weights_score, lds);
       hipLaunchKernelGGL(k_lik_weights_score, dim3(e->Mloc, ny), dim3(256), lds, e->stream, e->node_scores, e->masks,
-                         e->scores, e->logprobs_z, e->w_lik, e->baseline, e->baseline2, alpha, c.score_function_baseline,
+                         e->probs, e->logprobs_z, e->w_lik, e->baseline, e->baseline2, alpha, c.score_function_baseline,
                          e->d, e->S, e->W, in_lds);
       std::swap(e->baseline, e->baseline2);
     }
@@ -495,10 +511,13 @@ static int step_local(dibs_engine* e, int t, float* pack) {
       const double p = c.graph_prior_edges_per_node * e->d / ((e->d * (e->d - 1)) / 2.0);
       er_c = (float)(log(p) - log(1 - p));
     }
-    const size_t lds = (size_t)e->d * e->d * 4 + (size_t)e->d * 4;
-    hipLaunchKernelGGL(k_zgrad, dim3(e->Mloc), dim3(256), lds, e->stream, e->z, e->scores, e->w_lik, e->acyc_part,
-                       e->acyc_nblk, e->w_acyc, pack, (size_t)e->E, e->m0, e->d, e->k, e->Sa, alpha, beta,
-                       1.0f / (e->sigz * e->sigz), c.graph_prior, er_c);
+    hipLaunchKernelGGL(k_wtotal, dim3(e->Mloc, 4), dim3(256), 0, e->stream, e->probs, e->w_lik, e->acyc_part, e->acyc_nblk,
+                       e->w_acyc, e->w_tot, e->d, e->Sa, alpha, beta, c.graph_prior, er_c);
+    const size_t lds = ((size_t)e->d * e->d + (size_t)2 * e->d * e->k) * 4;
+    allow_lds(k_zgrad, lds);
+    const int zs = e->d < 4 ? e->d : 4;
+    hipLaunchKernelGGL(k_zgrad, dim3(e->Mloc, zs), dim3(256), lds, e->stream, e->z, e->w_tot, pack, (size_t)e->E, e->m0, e->d,
+                       e->k, 1.0f / (e->sigz * e->sigz));
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(err));

@@ -55,8 +55,8 @@ __global__ void k_init_theta_lin(float* __restrict__ th, Key2 key, uint64_t n_to
 // grid = Mloc, block = 256; dynamic LDS = 2 * dpad * ldk * 4
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_edge_scores(const float* __restrict__ z, float* __restrict__ scores,
-                                                     uint32_t* __restrict__ thr, float alpha, int d, int k, int dpad,
-                                                     int ldk) {
+                                                     uint32_t* __restrict__ thr, float* __restrict__ probs, float alpha,
+                                                     int d, int k, int dpad, int ldk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Us = smem;
   float* Vs = smem + (size_t)dpad * ldk;
@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void k_edge_scores(const float* __restrict__ z
         scores[o] = s;
         const float pf = (float)sigmoid_d((double)__fmul_rn(alpha, s));
         thr[o] = row == col ? 0u : (uint32_t)ceilf(pf * 8388608.0f);
+        probs[o] = row == col ? 0.f : pf;  // edge_probs (dibs.py:168-184), reused by the prior / estimator kernels
       }
     }
   }
@@ -442,7 +443,7 @@ __global__ void k_sum_nodes(const double* __restrict__ node_scores, float* __res
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restrict__ node_scores,
                                                            const uint64_t* __restrict__ masks,
-                                                           const float* __restrict__ scores, float* __restrict__ logprobs,
+                                                           const float* __restrict__ probs, float* __restrict__ logprobs,
                                                            float* __restrict__ w_lik, const float* __restrict__ baseline,
                                                            float* __restrict__ baseline_out, float alpha,
                                                            double sf_baseline, int d, int S, int W, int masks_in_lds) {
@@ -502,8 +503,7 @@ __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restr
       const uint64_t* col = masks_in_lds ? mkl + (size_t)c * S * W : mg + (size_t)j * S * W;
       for (int s = 0; s < S; ++s)
         if (col[(size_t)s * W + w] & bit) acc += wt[s];
-      const float p = (float)sigmoid_d((double)__fmul_rn(alpha, scores[(size_t)m * d * d + i * d + j]));
-      out = scale * alpha * (acc - p);
+      out = scale * alpha * (acc - probs[(size_t)m * d * d + i * d + j]);
     }
     w_lik[(size_t)m * d * d + i * d + j] = out;
   }
@@ -517,43 +517,88 @@ __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restr
 //     reference: graph_utils.py:8-28, dibs.py:121-140, 557-601
 // grid = (ceil(Sa / CPB), Mloc), block = 256; dynamic LDS = 3 * DP * LD * 4, DP = 16 NT, LD = DP + 2
 // ------------------------------------------------------------------------------------------------
-// C = A * B on DP x DP tiles held in dynamic LDS.  Operands are addressed as OFFSETS (in floats) into the
-// kernel's LDS array so that every access is a ds_read / ds_write (a runtime-selected generic pointer would turn
-// them into flat accesses).
+// Matrices live in LDS as [DP rows][LD] with the COLUMNS PERMUTED: logical column c sits at pc(c) = (c & 15) * NT + (c >> 4),
+// so the NT values {c, c+16, c+32, ...} that one lane needs for the B fragments of a k-step (and produces in the C tile)
+// are contiguous: one ds_read_b128 / ds_write_b128 for NT = 4.  LD = 16 NT + 4.
+template <int NT>
+__device__ __forceinline__ int acyc_pc(int c) { return (c & 15) * NT + (c >> 4); }
+
+// C = A * B.  Operands are OFFSETS (in floats) into the kernel's LDS array so that every access is a ds_* instruction
+// (a runtime-selected generic pointer would turn them into flat accesses).  The next k-step's fragments are loaded
+// while the current MFMAs issue.
 template <int NT>
 __device__ __forceinline__ void lds_matmul(float* __restrict__ lds, int c_off, int a_off, int b_off, int kp, int lane,
                                            int wave) {
-  constexpr int DP = 16 * NT, LD = DP + 2;
+  constexpr int DP = 16 * NT, LD = DP + 4;
   for (int ti = wave; ti < NT; ti += 4) {
     f32x4 acc[NT];
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj) acc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ap = a_off + (ti * 16 + (lane & 15)) * LD + (lane >> 4);
-    const int bq = b_off + (lane >> 4) * LD + (lane & 15);
-    for (int k0 = 0; k0 < kp; k0 += 4) {
-      const float a = lds[ap + k0];
-#pragma unroll
-      for (int tj = 0; tj < NT; ++tj)
-        acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, lds[bq + k0 * LD + tj * 16], acc[tj], 0, 0, 0);
+    // A[row][k]: k = k0 + kk -> physical ((k0 & 15) + kk) * NT + (k0 >> 4)
+    const int ap = a_off + (ti * 16 + (lane & 15)) * LD + (lane >> 4) * NT;
+    // B[k][tj * 16 + col], tj = 0..NT-1 -> physical col * NT + tj (contiguous)
+    const int bq = b_off + (lane >> 4) * LD + (lane & 15) * NT;
+    // two-stage register pipeline over the kp / 4 k-steps (step s: k0 = 4 s); the loads of the following step are
+    // issued before the MFMAs of the current one.  A step index == nsteps is loaded but never used (addresses stay
+    // inside the LDS allocation: one slack row is allocated behind the last buffer).
+    const int nsteps = ((kp + 7) >> 3) << 1;  // even number of k-steps; the operands are zero beyond d
+    float a0, a1, b0[NT], b1[NT];
+#define ACYC_LOAD(A_, B_, S_)                                                     \
+    {                                                                             \
+      const int kk0 = (S_) << 2;                                                  \
+      A_ = lds[ap + (kk0 & 15) * NT + (kk0 >> 4)];                                \
+      if constexpr (NT == 4) {                                                    \
+        const float4 t4 = *reinterpret_cast<const float4*>(lds + bq + kk0 * LD);  \
+        B_[0] = t4.x; B_[1] = t4.y; B_[2] = t4.z; B_[3] = t4.w;                   \
+      } else {                                                                    \
+        _Pragma("unroll") for (int tj = 0; tj < NT; ++tj) B_[tj] = lds[bq + kk0 * LD + tj]; \
+      }                                                                           \
+    }
+    // MFMA as inline asm with the accumulator tied in place ("+a"): with the builtin, hipcc renamed the accumulators
+    // across the pipelined loop (v_accvgpr_read / _mov / _write + s_nop at the loop head), serialising every iteration.
+    // Hazards hipcc cannot see around asm: accumulator init -> first MFMA (s_nop below) and last MFMA -> accumulator
+    // read (s_nop after the loop); back-to-back MFMAs on the same accumulator need none.
+#define ACYC_MFMA(A_, B_) \
+    _Pragma("unroll") for (int tj = 0; tj < NT; ++tj) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tj]) : "v"(A_), "v"(B_[tj]));
+    ACYC_LOAD(a0, b0, 0)
+    asm volatile("s_nop 4" ::: "memory");
+#pragma unroll 1
+    for (int st = 0; st < nsteps; st += 2) {
+      ACYC_LOAD(a1, b1, st + 1)
+      ACYC_MFMA(a0, b0)
+      ACYC_LOAD(a0, b0, st + 2)
+      ACYC_MFMA(a1, b1)
     }
 #pragma unroll
-    for (int tj = 0; tj < NT; ++tj)
+    for (int tj = 0; tj < NT; ++tj) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[tj]));  // last MFMA -> accumulator read
+#undef ACYC_LOAD
+#undef ACYC_MFMA
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 4; ++r) {
+      const int o = c_off + (ti * 16 + (lane >> 4) * 4 + r) * LD + (lane & 15) * NT;
+      float tmp[NT];
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) {
         // Force the MFMA result through a VGPR: hipcc (ROCm 7.2) otherwise emits `ds_write_b32 vaddr, aN` (AGPR data
-        // operand) for part of the tile, which stored wrong values on gfx950 (scripts/probe/acyc_probe.hip, variant 3).
-        float tmp = acc[tj][r];
-        asm volatile("" : "+v"(tmp));
-        lds[c_off + (ti * 16 + (lane >> 4) * 4 + r) * LD + tj * 16 + (lane & 15)] = tmp;
+        // operand) for part of the tile, which stored wrong values on gfx950 (scripts/probe/acyc_probe.hip).
+        tmp[tj] = acc[tj][r];
+        asm volatile("" : "+v"(tmp[tj]));
       }
+      if constexpr (NT == 4) {
+        *reinterpret_cast<float4*>(lds + o) = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+      } else {
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) lds[o + tj] = tmp[tj];
+      }
+    }
   }
 }
 
 template <int NT>
 __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, float* __restrict__ part, Key2 carry, int m0,
                                               int M_global, int d, int Sa, int cpb, float alpha, float tau, int layout,
-                                              int tiny) {
-  constexpr int DP = 16 * NT, LD = DP + 2, BUF = DP * LD;
+                                              int tiny, int dbg_mode) {
+  constexpr int DP = 16 * NT, LD = DP + 4, BUF = DP * LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int blk = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Key2 km = rng_split_row(carry, (uint32_t)M_global + 1u, (uint32_t)(m0 + m) + 1u, layout);  // dibs.py:595: key used directly
@@ -570,25 +615,24 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
     const int sa = blk * cpb + c;
     if (sa >= Sa) break;
     __syncthreads();
-    // buffer 0: M = I + G~/d  (zero padded)
-    for (int e = tid; e < BUF; e += 256) {
-      const int i = e / LD, jj = e - i * LD;
-      float v = 0.f;
-      if (i < d && jj < d) {
-        if (i == jj) v = 1.0f;
-        else {
-          const float eps = rng_logistic(rng_bits_at(km, nbits, (uint64_t)sa * dd + (uint64_t)i * d + jj, layout), tiny);
-          const float g = 1.0f / (1.0f + expf(-tau * (eps + alpha * sm[i * d + jj])));
-          v = g * inv_d;
-        }
+    // buffer 0: M = I + G~/d  (zero padded, permuted columns)
+    for (int e = tid; e < BUF; e += 256) smem[e] = 0.f;
+    __syncthreads();
+    for (int e = tid; e < d * d; e += 256) {
+      const int i = e / d, jj = e - i * d;
+      float v = 1.0f;
+      if (i != jj) {
+        const float eps = (dbg_mode & 1) ? 0.01f * (e & 63) : rng_logistic(rng_bits_at(km, nbits, (uint64_t)sa * dd + (uint64_t)e, layout), tiny);
+        const float g = (dbg_mode & 1) ? 0.5f + eps : 1.0f / (1.0f + expf(-tau * (eps + alpha * sm[e])));
+        v = g * inv_d;
       }
-      smem[e] = v;
+      smem[i * LD + acyc_pc<NT>(jj)] = v;
     }
     __syncthreads();
     // left-to-right binary powering of e = d - 1; the running power ping-pongs between buffers 1 and 2
     const int ex = d - 1;
     int cur = 0;
-    if (ex >= 1) {
+    if (ex >= 1 && !(dbg_mode & 2)) {
       const int hb = 31 - __builtin_clz((unsigned)ex);
       for (int b = hb - 1; b >= 0; --b) {
         int dst = (cur == BUF) ? 2 * BUF : BUF;
@@ -609,8 +653,8 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
       const int e = tid + q * 256;
       const int i = e / DP, jj = e - i * DP;
       if (i < d && jj < d && i != jj) {
-        const float g = smem[i * LD + jj] * (float)d;
-        const float pw = smem[cur + jj * LD + i];
+        const float g = smem[i * LD + acyc_pc<NT>(jj)] * (float)d;
+        const float pw = smem[cur + jj * LD + acyc_pc<NT>(i)];
         out[q] += pw * tau * alpha * g * (1.0f - g);
       }
     }
@@ -625,35 +669,19 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K7  Z gradient: W = W_lik - beta * mean_s(W_acyc) + W_prior;  grad = [W V, W^T U] - z / sigma^2, written
-//     next to a copy of z into the packed all-gather row  [z | grad_z | theta | grad_theta].
-//     reference: dibs.py:604-658 (latent prior), graph.py:93-108 / 182-196 (prior), autodiff of dibs.py:179-180
-// grid = Mloc, block = 256; dynamic LDS = d*d*4 + d*4
+// K7a total score-space gradient  W = W_lik - beta * mean_s(W_acyc) + W_prior   (elementwise; wide grid)
+//     reference: dibs.py:604-658 (latent prior), graph.py:93-108 / 182-196 (prior on edge probabilities)
+// grid = (Mloc, 4), block = 256
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_zgrad(const float* __restrict__ z, const float* __restrict__ scores,
-                                               const float* __restrict__ w_lik, const float* __restrict__ acyc_part,
-                                               int n_part, float* __restrict__ w_acyc, float* __restrict__ pack,
-                                               size_t pack_stride, int m0, int d, int k, int Sa, float alpha, float beta,
-                                               float inv_sig2, int prior_kind, float er_c) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Wm = smem;
-  float* colsum = smem + (size_t)d * d;
+__global__ __launch_bounds__(256) void k_wtotal(const float* __restrict__ probs, const float* __restrict__ w_lik,
+                                                const float* __restrict__ acyc_part, int n_part, float* __restrict__ w_acyc,
+                                                float* __restrict__ w_tot, int d, int Sa, float alpha, float beta,
+                                                int prior_kind, float er_c) {
   const int m = blockIdx.x, tid = threadIdx.x;
   const size_t dd = (size_t)d * d;
-  // pass 1: P and (SF prior) column sums
-  for (int j = tid; j < d; j += 256) colsum[j] = 0.f;
-  __syncthreads();
-  if (prior_kind == 1) {
-    for (int j = tid; j < d; j += 256) {
-      float cs = 0.f;
-      for (int i = 0; i < d; ++i)
-        if (i != j) cs += (float)sigmoid_d((double)__fmul_rn(alpha, scores[m * dd + (size_t)i * d + j]));
-      colsum[j] = cs;
-    }
-    __syncthreads();
-  }
   const float inv_sa = 1.0f / (float)Sa;
-  for (int e = tid; e < (int)dd; e += 256) {
+  const float* pm = probs + m * dd;
+  for (int e = blockIdx.y * 256 + tid; e < (int)dd; e += 256 * gridDim.y) {
     const int i = e / d, j = e - i * d;
     float ac = 0.f;
     for (int q = 0; q < n_part; ++q) ac += acyc_part[((size_t)m * n_part + q) * dd + e];
@@ -661,28 +689,51 @@ __global__ __launch_bounds__(256) void k_zgrad(const float* __restrict__ z, cons
     w_acyc[m * dd + e] = ac;
     float pr = 0.f;
     if (i != j && prior_kind != 2) {
-      const float p = (float)sigmoid_d((double)__fmul_rn(alpha, scores[m * dd + e]));
+      const float p = pm[e];
       const float dp = alpha * p * (1.0f - p);
-      pr = prior_kind == 0 ? er_c * dp : (-3.0f / (1.0f + colsum[j])) * dp;
+      if (prior_kind == 0) pr = er_c * dp;
+      else {
+        float cs = 0.f;  // soft in-degree of node j (graph.py:182-196)
+        for (int r = 0; r < d; ++r) cs += pm[r * d + j];
+        pr = (-3.0f / (1.0f + cs)) * dp;
+      }
     }
-    Wm[e] = w_lik[m * dd + e] - beta * ac + pr;
+    w_tot[m * dd + e] = w_lik[m * dd + e] - beta * ac + pr;
   }
-  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7b back-projection: grad = [W V, W^T U] - z / sigma^2, written next to a copy of z into the packed all-gather row
+//     [z | grad_z | theta | grad_theta].   (autodiff of dibs.py:179-180 in closed form)
+// grid = (Mloc, ZS), block = 256; block y handles rows i = y, y + ZS, ...; dynamic LDS = (d*d + 2*d*k) * 4
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_zgrad(const float* __restrict__ z, const float* __restrict__ w_tot,
+                                               float* __restrict__ pack, size_t pack_stride, int m0, int d, int k,
+                                               float inv_sig2) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wm = smem;
+  float2* Zs = reinterpret_cast<float2*>(smem + (size_t)d * d);
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const size_t dd = (size_t)d * d;
+  for (int e = tid; e < (int)dd; e += 256) Wm[e] = w_tot[m * dd + e];
   const float2* zm = reinterpret_cast<const float2*>(z + (size_t)m * d * k * 2);
+  for (int e = tid; e < d * k; e += 256) Zs[e] = zm[e];
+  __syncthreads();
   float* prow = pack + (size_t)(m0 + m) * pack_stride;
   float2* pz = reinterpret_cast<float2*>(prow);
   float2* pg = reinterpret_cast<float2*>(prow + (size_t)d * k * 2);
-  for (int e = tid; e < d * k; e += 256) {
-    const int i = e / k, q = e - i * k;
+  const int nrow = (d - blockIdx.y + gridDim.y - 1) / gridDim.y;
+  for (int e = tid; e < nrow * k; e += 256) {
+    const int i = blockIdx.y + (e / k) * gridDim.y, q = e % k;
     float su = 0.f, sv = 0.f;
     for (int j = 0; j < d; ++j) {
-      const float2 zj = zm[(size_t)j * k + q];
+      const float2 zj = Zs[j * k + q];
       su = fmaf(Wm[i * d + j], zj.y, su);  // dU[i,q] = sum_j W[i,j] V[j,q]
       sv = fmaf(Wm[j * d + i], zj.x, sv);  // dV[i,q] = sum_j W[j,i] U[j,q]
     }
-    const float2 zi = zm[e];
-    pz[e] = zi;
-    pg[e] = make_float2(su - zi.x * inv_sig2, sv - zi.y * inv_sig2);
+    const float2 zi = Zs[i * k + q];
+    pz[i * k + q] = zi;
+    pg[i * k + q] = make_float2(su - zi.x * inv_sig2, sv - zi.y * inv_sig2);
   }
 }
 
@@ -773,7 +824,20 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
     acc[q] = 0.f;
   }
   const float c2h = 2.0f / h;
-  for (int b = 0; b < M; ++b) {
+  int b = 0;
+  for (; b + 4 <= M; b += 4) {  // four rows in flight (the order of the additions stays b = 0, 1, 2, ...)
+    float g[4], xb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      g[u] = pack[(size_t)(b + u) * pack_stride + grad_off + i];
+      xb[u] = pack[(size_t)(b + u) * pack_stride + val_off + i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < PHI_TA; ++q) acc[q] += ksum[q * M + b + u] * g[u] - c2h * krep[q * M + b + u] * (xb[u] - xa[q]);
+  }
+  for (; b < M; ++b) {
     const float g = pack[(size_t)b * pack_stride + grad_off + i];
     const float xb = pack[(size_t)b * pack_stride + val_off + i];
 #pragma unroll
