@@ -422,7 +422,7 @@ static void launch_acyc(dibs_engine* e, Key2 carry, float alpha) {
   allow_lds(k_acyc<NT>, lds);
   hipLaunchKernelGGL(k_acyc<NT>, dim3(e->acyc_nblk, e->Mloc), dim3(256), lds, e->stream, e->scores, e->acyc_part, carry,
                      e->m0, e->M, e->d, e->Sa, e->acyc_cpb, alpha, (float)e->cfg.tau, e->cfg.rng_layout,
-                     e->cfg.logistic_minval_tiny, getenv("DIBS_ACYC_DBG") ? atoi(getenv("DIBS_ACYC_DBG")) : 0);
+                     e->cfg.logistic_minval_tiny);
 }
 
 static int step_local(dibs_engine* e, int t, float* pack) {

@@ -270,12 +270,32 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
     for (int p = lane; p < hS; p += 64) {
       uint64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
       const uint64_t cbase = (uint64_t)p * dd + j;
-      for (int i = 0; i < d; ++i) {
-        uint32_t y0, y1;
-        rng_bits_pair(kg, nbits, cbase + (uint64_t)i * d, layout, y0, y1);
-        const uint32_t t = thrs[i];
-        const uint64_t ba = (uint64_t)((y0 >> 9) < t) << (i & 63), bb = (uint64_t)((y1 >> 9) < t) << (i & 63);
-        if (i < 64) { a0 |= ba; b0 |= bb; } else { a1 |= ba; b1 |= bb; }
+      if (layout == 0 && nbits < 0xFFFFFFFFull) {
+        // legacy layout, 32-bit counters: element c pairs with c + n/2 in one Threefry call
+        uint32_t c0 = (uint32_t)cbase;
+        const uint32_t half32 = (uint32_t)(nbits >> 1);
+        uint32_t lo = 0, hi = 0, lo2 = 0, hi2 = 0, lo3 = 0, hi3 = 0, lo4 = 0, hi4 = 0;  // bits 0-31, 32-63 (a) / (b)
+        for (int i = 0; i < d; ++i, c0 += (uint32_t)d) {
+          uint32_t y0, y1;
+          threefry2x32(kg.a, kg.b, c0, c0 + half32, y0, y1);
+          const uint32_t t = thrs[i];
+          const uint32_t ba = (uint32_t)((y0 >> 9) < t) << (i & 31), bb = (uint32_t)((y1 >> 9) < t) << (i & 31);
+          const int w32 = i >> 5;
+          if (w32 == 0) { lo |= ba; lo2 |= bb; } else if (w32 == 1) { hi |= ba; hi2 |= bb; }
+          else if (w32 == 2) { lo3 |= ba; lo4 |= bb; } else { hi3 |= ba; hi4 |= bb; }
+        }
+        a0 = ((uint64_t)hi << 32) | lo;
+        b0 = ((uint64_t)hi2 << 32) | lo2;
+        a1 = ((uint64_t)hi3 << 32) | lo3;
+        b1 = ((uint64_t)hi4 << 32) | lo4;
+      } else {
+        for (int i = 0; i < d; ++i) {
+          uint32_t y0, y1;
+          rng_bits_pair(kg, nbits, cbase + (uint64_t)i * d, layout, y0, y1);
+          const uint32_t t = thrs[i];
+          const uint64_t ba = (uint64_t)((y0 >> 9) < t) << (i & 63), bb = (uint64_t)((y1 >> 9) < t) << (i & 63);
+          if (i < 64) { a0 |= ba; b0 |= bb; } else { a1 |= ba; b1 |= bb; }
+        }
       }
       mk[p * W] = a0;
       mk[(p + hS) * W] = b0;
@@ -301,6 +321,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
 
   const double Nn = bp.Nj[j];
   double* ns_out = node_scores + ((size_t)m * d + j) * S;
+  const double score_l0 = bge_assemble(bp, j, 0, d, Nn, 0.0, (double)Rs[j * d + j]);
   double flops = 0.0;
   int n16 = 0, n32 = 0, ng = 0;
 
@@ -311,7 +332,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
     uint64_t w0 = valid ? mk[s * W] : 0ull, w1 = (valid && W > 1) ? mk[s * W + 1] : 0ull;
     const int l = __popcll(w0) + __popcll(w1);
     const bool small = valid && l <= 7;
-    if (small) {
+    if (valid && l == 0) {
+      // no parents: logdet R[pa,pa] = 0, Schur complement = R_jj
+      ns_out[s] = score_l0;
+    } else if (small) {
       int idx[8];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
@@ -597,7 +621,7 @@ __device__ __forceinline__ void lds_matmul(float* __restrict__ lds, int c_off, i
 template <int NT>
 __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, float* __restrict__ part, Key2 carry, int m0,
                                               int M_global, int d, int Sa, int cpb, float alpha, float tau, int layout,
-                                              int tiny, int dbg_mode) {
+                                              int tiny) {
   constexpr int DP = 16 * NT, LD = DP + 4, BUF = DP * LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int blk = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -606,33 +630,52 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
   const int kp = (d + 3) & ~3;
   const float inv_d = 1.0f / (float)d;
   const float* sm = scores + (size_t)m * dd;
-  constexpr int EPT = (DP * DP + 255) / 256;  // output elements per thread (tid-strided over the padded tile)
-  float out[EPT];
+  // thread t owns column pj = t % DP and rows pi0 + q * RSTEP of the d x d matrix (same elements in every chain, so the
+  // per-element constants and the soft-graph entries stay in registers; no division by the runtime d)
+  constexpr int RSTEP = 256 / DP, EPT = (DP + RSTEP - 1) / RSTEP;
+  const int pj = tid % DP, pi0 = tid / DP;
+  const bool pact = pi0 < RSTEP && pj < d;
+  const bool fast = tau == 1.0f;   // sigmoid(eps + a) with eps = log(u / (1 - u))  ==  u / (u + (1 - u) exp(-a)): no log / exp per draw
+  const float ulo = tiny ? 1.17549435e-38f : 1.1920929e-07f;
+  float out[EPT], ea[EPT], gq[EPT];
 #pragma unroll
-  for (int q = 0; q < EPT; ++q) out[q] = 0.f;
+  for (int q = 0; q < EPT; ++q) {
+    const int i = pi0 + q * RSTEP;
+    out[q] = 0.f;
+    gq[q] = 0.f;
+    ea[q] = (pact && i < d && i != pj) ? (fast ? expf(-alpha * sm[i * d + pj]) : alpha * sm[i * d + pj]) : 0.f;
+  }
+  for (int e = tid; e < BUF; e += 256) smem[e] = 0.f;  // padding of buffer 0: zeroed once, never written afterwards
 
   for (int c = 0; c < cpb; ++c) {
     const int sa = blk * cpb + c;
     if (sa >= Sa) break;
     __syncthreads();
-    // buffer 0: M = I + G~/d  (zero padded, permuted columns)
-    for (int e = tid; e < BUF; e += 256) smem[e] = 0.f;
-    __syncthreads();
-    for (int e = tid; e < d * d; e += 256) {
-      const int i = e / d, jj = e - i * d;
-      float v = 1.0f;
-      if (i != jj) {
-        const float eps = (dbg_mode & 1) ? 0.01f * (e & 63) : rng_logistic(rng_bits_at(km, nbits, (uint64_t)sa * dd + (uint64_t)e, layout), tiny);
-        const float g = (dbg_mode & 1) ? 0.5f + eps : 1.0f / (1.0f + expf(-tau * (eps + alpha * sm[e])));
-        v = g * inv_d;
+    // buffer 0: M = I + G~/d  (permuted columns)
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int i = pi0 + q * RSTEP;
+      if (pact && i < d) {
+        float v = 1.0f, g = 0.f;
+        if (i != pj) {
+          const uint32_t bits = rng_bits_at(km, nbits, (uint64_t)sa * dd + (uint64_t)(i * d + pj), layout);
+          if (fast) {
+            const float u = rng_uniform(bits, ulo, 1.0f);
+            g = u / (u + (1.0f - u) * ea[q]);
+          } else {
+            g = 1.0f / (1.0f + expf(-tau * (rng_logistic(bits, tiny) + ea[q])));
+          }
+          v = g * inv_d;
+        }
+        gq[q] = g;
+        smem[i * LD + acyc_pc<NT>(pj)] = v;
       }
-      smem[i * LD + acyc_pc<NT>(jj)] = v;
     }
     __syncthreads();
     // left-to-right binary powering of e = d - 1; the running power ping-pongs between buffers 1 and 2
     const int ex = d - 1;
     int cur = 0;
-    if (ex >= 1 && !(dbg_mode & 2)) {
+    if (ex >= 1) {
       const int hb = 31 - __builtin_clz((unsigned)ex);
       for (int b = hb - 1; b >= 0; --b) {
         int dst = (cur == BUF) ? 2 * BUF : BUF;
@@ -647,24 +690,20 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
         }
       }
     }
-    // out[i][j] += (M^{d-1})[j][i] * tau * alpha * g (1 - g),  g = d * M[i][j]  (i != j)
+    // out[i][j] += (M^{d-1})[j][i] * tau * alpha * g (1 - g)   (i != j; g = 0 on the diagonal)
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
-      const int e = tid + q * 256;
-      const int i = e / DP, jj = e - i * DP;
-      if (i < d && jj < d && i != jj) {
-        const float g = smem[i * LD + acyc_pc<NT>(jj)] * (float)d;
-        const float pw = smem[cur + jj * LD + acyc_pc<NT>(i)];
-        out[q] += pw * tau * alpha * g * (1.0f - g);
-      }
+      const int i = pi0 + q * RSTEP;
+      if (pact && i < d) out[q] += smem[cur + pj * LD + acyc_pc<NT>(i)] * tau * alpha * gq[q] * (1.0f - gq[q]);
     }
   }
-  float* po = part + ((size_t)m * gridDim.x + blk) * dd;
+  if (pact) {
+    float* po = part + ((size_t)m * gridDim.x + blk) * dd;
 #pragma unroll
-  for (int q = 0; q < EPT; ++q) {
-    const int e = tid + q * 256;
-    const int i = e / DP, jj = e - i * DP;
-    if (i < d && jj < d) po[i * d + jj] = out[q];
+    for (int q = 0; q < EPT; ++q) {
+      const int i = pi0 + q * RSTEP;
+      if (i < d) po[i * d + pj] = out[q];
+    }
   }
 }
 
