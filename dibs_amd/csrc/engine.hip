@@ -11,6 +11,7 @@
 #include "../../include/dibs_hip.h"
 #include "kernels_marginal.h"
 #include "kernels_joint.h"
+#include "kernels_nn.h"
 
 #define LDS_LIMIT ((size_t)160 * 1024)
 static thread_local std::string g_err;
@@ -110,7 +111,12 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
     return fail("JointDiBS + BGe is not constructible (BGe has no parameters; linearGaussian.py:53-54)");
   if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z != DIBS_EST_SCORE)
     return fail("BGe + reparam estimator not supported yet");
-  if (c.likelihood == DIBS_LIK_DENSENN) return fail("DenseNonlinearGaussian not supported yet");
+  if (c.likelihood == DIBS_LIK_DENSENN) {
+    if (c.nn_n_hidden != 1) return fail("DenseNonlinearGaussian: exactly one hidden layer is supported on the device");
+    if (c.nn_hidden[0] < 1 || c.nn_hidden[0] > 64) return fail("DenseNonlinearGaussian: hidden width must be in [1, 64]");
+    if (c.n_observations > 128) return fail("DenseNonlinearGaussian: n_observations must be <= 128");
+    if (c.nn_activation < 0 || c.nn_activation > 3) return fail("Invalid activation function");  // nonlinearGaussian.py:61 (KeyError)
+  }
   if (c.graph_prior == DIBS_PRIOR_ER) {
     const double p = c.graph_prior_edges_per_node * c.n_vars / ((c.n_vars * (c.n_vars - 1)) / 2.0);
     if (!(p > 0.0 && p < 1.0)) return fail("Erdos-Renyi prior: edge probability must be in (0, 1)");
@@ -120,6 +126,13 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
     if (D4 > LDS_LIMIT - 1024) return fail("n_vars * n_dim too large for the kernel-matrix LDS tile");
     if ((size_t)2 * 8 * c.n_particles * 4 > LDS_LIMIT) return fail("n_particles too large (kernel rows must fit in LDS)");
     if (((size_t)c.n_vars * c.n_vars + (size_t)2 * c.n_vars * c.n_dim) * 4 > LDS_LIMIT) return fail("n_vars * n_dim too large");
+  }
+  {  // LDS budgets of the likelihood kernels (x, theta / graph, per-sample operand and residuals are LDS-resident)
+    const int nt = (c.n_vars + 15) / 16;
+    if (c.likelihood == DIBS_LIK_LINGAUSS && lin_lds_bytes(c.n_vars, c.n_observations, nt, true) > LDS_LIMIT)
+      return fail("LinearGaussian: n_vars / n_observations too large for the LDS-resident kernels (n_vars <= 80 at 100 observations)");
+    if (c.likelihood == DIBS_LIK_DENSENN && nn_lds_bytes(c.n_vars, c.n_observations, nt, true) > LDS_LIMIT)
+      return fail("DenseNonlinearGaussian: n_vars / n_observations too large for the LDS-resident kernels (n_vars <= 64 at 100 observations)");
   }
   int ndev = 0;
   HIP_OK(hipGetDeviceCount(&ndev));
@@ -300,7 +313,7 @@ extern "C" int dibs_engine_set_data(dibs_engine* e, const float* x, const int32_
     e->has_mean_obs = bge_mean_obs != nullptr;
     if (bge_mean_obs) e->mean_obs.assign(bge_mean_obs, bge_mean_obs + e->d);
     if (bge_prepare(e, x, interv_mask, bge_mean_obs)) return 1;
-  } else if (e->cfg.likelihood == DIBS_LIK_LINGAUSS) {
+  } else {
     if (joint_set_data(&e->jw, x, interv_mask, e->N, e->d)) return fail("joint_set_data failed");
   }
   e->has_data = true;
@@ -326,6 +339,10 @@ extern "C" int dibs_engine_init_particles(dibs_engine* e, const uint32_t key[2])
       hipLaunchKernelGGL(k_init_theta_lin, dim3((unsigned)((tl + 255) / 256)), dim3(256), 0, e->stream, e->theta, tsub, tt,
                          (uint64_t)e->m0 * e->P, tl, (float)e->cfg.lin_mean_edge, (float)e->cfg.lin_sig_edge,
                          (float)e->cfg.lin_min_edge, L);
+    } else if (e->cfg.likelihood == DIBS_LIK_DENSENN) {
+      const int nt = e->Mloc * e->d;
+      hipLaunchKernelGGL(k_init_theta_nn, dim3((nt + 63) / 64), dim3(64), 0, e->stream, e->theta, (size_t)e->P, tsub, e->m0, e->Mloc,
+                         e->M, e->d, e->cfg.nn_hidden[0], e->cfg.nn_bias, (float)e->cfg.nn_sig_param, L);
     } else {
       return fail("sample_parameters not implemented for this likelihood");
     }
@@ -489,6 +506,21 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     {
       KTimer tm(e, DIBS_K_LIN_Z);
       joint_lin_z(&e->jw, jl, carry_lik);
+      std::swap(e->baseline, e->baseline2);
+    }
+  } else if (c.likelihood == DIBS_LIK_DENSENN) {
+    JointLaunch jl{e->stream, e->z, e->theta, e->scores, e->thr, e->w_lik, e->logprobs_z, e->logprobs_th, e->baseline,
+                   e->baseline2, pack, (size_t)e->E, (size_t)(2 * e->D), (size_t)(2 * e->D + e->P), e->m0, e->M, e->Mloc, e->d,
+                   e->N, e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny, c.grad_estimator_z, c.score_function_baseline,
+                   0.f, 0.f, 0.f};
+    const NNParams np_{c.nn_hidden[0], c.nn_activation, c.nn_bias, (float)c.nn_obs_noise, (float)c.nn_sig_param};
+    {
+      KTimer tm(e, DIBS_K_NN_THETA);
+      joint_nn_dispatch(&e->jw, jl, carry_theta, LIN_MODE_THETA, np_, (size_t)e->P);
+    }
+    {
+      KTimer tm(e, DIBS_K_NN_Z);
+      joint_nn_dispatch(&e->jw, jl, carry_lik, c.grad_estimator_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM, np_, (size_t)e->P);
       std::swap(e->baseline, e->baseline2);
     }
   }
@@ -719,6 +751,16 @@ static void launch_lin_given(const JointWork& jw, const float* theta, const int3
                      (float)c.lin_obs_noise, (float)c.lin_mean_edge, (float)c.lin_sig_edge, jw.any_mask);
 }
 
+template <int NT>
+static void launch_nn_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N,
+                            const NNParams& np_, size_t P, hipStream_t stream) {
+  const size_t lds = nn_lds_bytes(d, N, NT, false);
+  allow_lds(k_nn_logprobs<NT>, lds);
+  hipLaunchKernelGGL(k_nn_logprobs<NT>, dim3(1, n), dim3(256), lds, stream, jw.x, jw.mask, theta, P, (const float*)nullptr,
+                     reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, N, 1, 1, 0.f, 1.f, 0, 0, np_,
+                     jw.any_mask);
+}
+
 extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* theta, int32_t n, const float* x_ho,
                                  const int32_t* mask_ho, int32_t n_ho, float* out) {
   if (!e || !g || !x_ho || !out) return fail("null argument");
@@ -791,6 +833,32 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
       case 5: launch_lin_given<5>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
       case 6: launch_lin_given<6>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
       default: launch_lin_given<7>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
+    }
+    HIP_OK(hipStreamSynchronize(e->stream));
+    hipFree(d_th);
+    hipFree(d_g);
+    joint_free(&jw);
+  } else if (c.likelihood == DIBS_LIK_DENSENN) {
+    if (!theta) { hipFree(d_out); return fail("theta required"); }
+    if (n_ho > 128) { hipFree(d_out); return fail("DenseNonlinearGaussian: at most 128 observations per scoring call"); }
+    JointWork jw;
+    memset(&jw, 0, sizeof jw);
+    if (joint_set_data(&jw, x_ho, mask_ho, n_ho, d)) { hipFree(d_out); return fail("joint_set_data failed"); }
+    float* d_th = nullptr;
+    int32_t* d_g = nullptr;
+    HIP_OK(dalloc(&d_th, (size_t)n * e->P));
+    HIP_OK(dalloc(&d_g, (size_t)n * dd));
+    HIP_OK(hipMemcpy(d_th, theta, (size_t)n * e->P * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_g, g, (size_t)n * dd * 4, hipMemcpyHostToDevice));
+    const NNParams np_{c.nn_hidden[0], c.nn_activation, c.nn_bias, (float)c.nn_obs_noise, (float)c.nn_sig_param};
+    switch ((d + 15) / 16) {
+      case 1: launch_nn_given<1>(jw, d_th, d_g, d_out, n, d, n_ho, np_, (size_t)e->P, e->stream); break;
+      case 2: launch_nn_given<2>(jw, d_th, d_g, d_out, n, d, n_ho, np_, (size_t)e->P, e->stream); break;
+      case 3: launch_nn_given<3>(jw, d_th, d_g, d_out, n, d, n_ho, np_, (size_t)e->P, e->stream); break;
+      case 4: launch_nn_given<4>(jw, d_th, d_g, d_out, n, d, n_ho, np_, (size_t)e->P, e->stream); break;
+      case 5: launch_nn_given<5>(jw, d_th, d_g, d_out, n, d, n_ho, np_, (size_t)e->P, e->stream); break;
+      case 6: launch_nn_given<6>(jw, d_th, d_g, d_out, n, d, n_ho, np_, (size_t)e->P, e->stream); break;
+      default: launch_nn_given<7>(jw, d_th, d_g, d_out, n, d, n_ho, np_, (size_t)e->P, e->stream); break;
     }
     HIP_OK(hipStreamSynchronize(e->stream));
     hipFree(d_th);

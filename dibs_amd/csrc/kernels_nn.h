@@ -1,0 +1,474 @@
+// JointDiBS + DenseNonlinearGaussian (one hidden layer of H units per node) on gfx950.
+//   mean_nj = b2_j + sum_h W2_jh act( sum_a x_na g_aj W1_jah + b1_jh )
+//   log p(theta, D | G) = sum_leaves logN(.; 0, sig_p) [first-layer weights masked by g^T] + sum_{n,j not intervened} logN(x_nj; mean_nj, sqrt(obs_noise))
+// reference: dibs/models/nonlinearGaussian.py:35-81 (net), :248-326 (prior, likelihood); estimators as for LinearGaussian.
+// For a fixed hidden unit h the first layer of ALL nodes is one GEMM  pre_h = x [N,d] * T_h [d,d],  T_h[a][j] = g[a][j] W1[j][a][h],
+// so every h is a LinearGaussian-shaped pass on v_mfma_f32_16x16x4_f32; the second layer / activation live in the epilogue.
+// theta row layout (= pytree leaf order of the reference): W1 [d][d][H] (node j, input a, unit h) | b1 [d][H] | W2 [d][H] | b2 [d]
+// (without bias: W1 | W2).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels_joint.h"
+
+struct NNParams {
+  int H, act, bias;
+  float obs_noise, sig_param;
+};
+
+__device__ __forceinline__ float nn_act(int a, float v) {
+  switch (a) {
+    case 0: return v > 0.f ? v : 0.f;
+    case 1: return tanhf(v);
+    case 2: return 1.0f / (1.0f + expf(-v));
+    default: return v > 0.f ? v : 0.01f * v;
+  }
+}
+__device__ __forceinline__ float nn_dact(int a, float v, float fv) {
+  switch (a) {
+    case 0: return v > 0.f ? 1.f : 0.f;
+    case 1: return 1.f - fv * fv;
+    case 2: return fv * (1.f - fv);
+    default: return v > 0.f ? 1.f : 0.01f;
+  }
+}
+
+struct NNOff {
+  size_t w1, b1, w2, b2, P;
+};
+__host__ __device__ inline NNOff nn_offsets(int d, int H, int bias) {
+  NNOff o;
+  o.w1 = 0;
+  o.b1 = (size_t)d * d * H;
+  o.w2 = o.b1 + (bias ? (size_t)d * H : 0);
+  o.b2 = o.w2 + (size_t)d * H;
+  o.P = o.b2 + (bias ? (size_t)d : 0);
+  return o;
+}
+
+// LDS (floats): X[np][ldx] | GS[d*d] | TW[kp][ldw] | (grad kernel) RS[np][ldw] | RS2[np][ldw] | red
+__host__ __device__ inline size_t nn_lds_bytes(int d, int N, int NT, bool grad) {
+  const LinGeom g = lin_geom(d, N, NT);
+  size_t f = (size_t)g.np * g.ldx + (size_t)d * d + (size_t)g.kp * g.ldw;
+  if (grad) f += (size_t)2 * g.np * g.ldw;
+  return ((f * 4 + 15) & ~(size_t)15) + 64 * 8;
+}
+
+// pre = X * TW for the row tiles of this wave, results left in registers: acc[u][tj] (row tile ti = wave + 4 u)
+template <int NT, int NU>
+__device__ __forceinline__ void nn_gemm_x_tw(const float* X, const float* TW, const LinGeom g, int lane, int wave, f32x4 (&acc)[NU][NT]) {
+  const int nrt = g.np >> 4;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int ti = wave + 4 * u;
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj) acc[u][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ti >= nrt) continue;
+    const int ap = (ti * 16 + (lane & 15)) * g.ldx + (lane >> 4);
+    const int bq = (lane >> 4) * g.ldw + (lane & 15);
+    for (int k0 = 0; k0 < g.kp; k0 += 4) {
+      const float a = X[ap + k0];
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) acc[u][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, TW[bq + k0 * g.ldw + tj * 16], acc[u][tj], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[u][tj][r];
+        asm volatile("" : "+v"(v));  // keep MFMA results out of AGPR-sourced stores (see lds_matmul)
+        acc[u][tj][r] = v;
+      }
+  }
+}
+
+// sample graph s into GS (row-major [a][j]) ; returns nothing
+__device__ __forceinline__ void nn_build_graph(float* GS, int mode, Key2 key, uint64_t nbits, int s, const uint32_t* thr_m,
+                                               const float* sc_m, float alpha, float tau, int layout, int tiny, int d, int tid) {
+  const uint64_t dd = (uint64_t)d * d;
+  for (int e = tid; e < d * d; e += 256) {
+    const int a = e / d, j = e - a * d;
+    GS[e] = lin_sample_g(mode, key, nbits, dd, s, a, j, d, thr_m, sc_m, alpha, tau, layout, tiny);
+  }
+}
+
+// TW[a][j] = GS[a][j] * W1[j][a][h]  (zero padded); returns this thread's share of sum g logN(W1[., ., h])
+__device__ __forceinline__ float nn_build_tw(float* TW, const float* GS, const float* __restrict__ th_m, int h, int H, float sigp,
+                                             const LinGeom g, int tid) {
+  float prior = 0.f;
+  for (int e = tid; e < g.kp * g.ldw; e += 256) {
+    const int a = e / g.ldw, j = e - a * g.ldw;
+    float v = 0.f;
+    if (a < g.d && j < g.d) {
+      const float gv = GS[a * g.d + j];
+      const float w = th_m[((size_t)j * g.d + a) * H + h];
+      v = gv * w;
+      prior += gv * lin_logn(w, 0.f, sigp);
+    }
+    TW[e] = v;
+  }
+  return prior;
+}
+
+// ------------------------------------------------------------------------------------------------
+// log p(theta, D | G_s) for all samples.  grid = (ceil(S / spb), Mloc), block = 256
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_nn_logprobs(const float* __restrict__ x, const int32_t* __restrict__ mask,
+                                                     const float* __restrict__ theta, size_t P, const float* __restrict__ scores,
+                                                     const uint32_t* __restrict__ thr, float* __restrict__ logprobs, Key2 carry,
+                                                     int mode, int m0, int M_global, int d, int N, int S, int spb, float alpha,
+                                                     float tau, int layout, int tiny, NNParams np_, int any_mask) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const LinGeom g = lin_geom(d, N, NT);
+  constexpr int NU = 2;  // row tiles per wave (np / 16 <= 8, i.e. N <= 128)
+  float* X = smem;
+  float* GS = X + (size_t)g.np * g.ldx;
+  float* TW = GS + (size_t)d * d;
+  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)d * d + (size_t)g.kp * g.ldw) + 3) & ~(size_t)3));
+  const int m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t dd = (size_t)d * d;
+  const int H = np_.H;
+  const NNOff off = nn_offsets(d, H, np_.bias);
+  const float* th_m = theta + (size_t)m * P;
+  for (int e = tid; e < g.np * g.ldx; e += 256) {
+    const int n = e / g.ldx, c = e - n * g.ldx;
+    X[e] = (n < N && c < d) ? x[(size_t)n * d + c] : 0.f;
+  }
+  // graph-independent part of the prior: all leaves except the first-layer weights
+  float prior_rest = 0.f;
+  for (size_t e = off.b1 + tid; e < off.P; e += 256) prior_rest += lin_logn(th_m[e], 0.f, np_.sig_param);
+  const Key2 key = (mode == LIN_MODE_GIVEN) ? Key2{0, 0} : lin_mode_key(mode, carry, M_global, m0 + m, layout);
+  const uint64_t nbits = (uint64_t)S * dd;
+  const float inv2 = 0.5f / np_.obs_noise;
+  const float lognorm_x = -0.5f * logf(np_.obs_noise) - 0.918938533204672742f;
+  const int nrt = g.np >> 4;
+  for (int c = 0; c < spb; ++c) {
+    const int s = blockIdx.x * spb + c;
+    if (s >= S) break;
+    __syncthreads();
+    nn_build_graph(GS, mode, key, nbits, s, thr + (size_t)m * dd, scores ? scores + (size_t)m * dd : nullptr, alpha, tau, layout, tiny,
+                   d, tid);
+    float part = prior_rest;
+    f32x4 macc[NU][NT];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) macc[u][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < H; ++h) {
+      __syncthreads();
+      part += nn_build_tw(TW, GS, th_m, h, H, np_.sig_param, g, tid);
+      __syncthreads();
+      f32x4 acc[NU][NT];
+      nn_gemm_x_tw<NT, NU>(X, TW, g, lane, wave, acc);
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+          const int j = tj * 16 + (lane & 15);
+          if (j < d && wave + 4 * u < nrt) {
+            const float b1 = np_.bias ? th_m[off.b1 + (size_t)j * H + h] : 0.f;
+            const float w2 = th_m[off.w2 + (size_t)j * H + h];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) macc[u][tj][r] += w2 * nn_act(np_.act, acc[u][tj][r] + b1);
+          }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = (wave + 4 * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
+          if (n < N && j < d && wave + 4 * u < nrt && !(any_mask && mask[(size_t)n * d + j])) {
+            const float mean = macc[u][tj][r] + (np_.bias ? th_m[off.b2 + j] : 0.f);
+            const float e = X[n * g.ldx + j] - mean;
+            part += lognorm_x - inv2 * e * e;
+          }
+        }
+    const double tot = wave_sum_d((double)part);
+    __syncthreads();
+    if (lane == 0) red[wave] = tot;
+    __syncthreads();
+    if (tid == 0) logprobs[(size_t)m * S + s] = (float)(red[0] + red[1] + red[2] + red[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// softmax-weighted gradients (samples whose weight underflows to 0 in float are skipped, as in the oracle):
+//   mode THETA     : grad_theta = sum_s w_s d/dtheta log p(theta, D | G_s)          -> pack row (+ copy of theta)
+//   mode Z_REPARAM : W = sum_s w_s (d/dg) o tau alpha g~(1 - g~), off-diagonal     -> w_lik
+//   mode Z_SCORE   : W = scale * alpha (sum_s w_s G_s - P), off-diagonal           -> w_lik
+// grid = Mloc, block = 256.  Accumulation goes to global memory; every output element is owned by one thread.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, const int32_t* __restrict__ mask,
+                                                 const float* __restrict__ theta, size_t P, const float* __restrict__ scores,
+                                                 const uint32_t* __restrict__ thr, const float* __restrict__ logprobs,
+                                                 float* __restrict__ out, size_t out_stride, float* __restrict__ theta_copy,
+                                                 const float* __restrict__ baseline, float* __restrict__ baseline_out, Key2 carry,
+                                                 int mode, int m0, int M_global, int d, int N, int S, float alpha, float tau,
+                                                 int layout, int tiny, NNParams np_, double sf_baseline, int any_mask) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const LinGeom g = lin_geom(d, N, NT);
+  constexpr int NU = 2, NUD = (NT + 3) / 4;
+  float* X = smem;
+  float* GS = X + (size_t)g.np * g.ldx;
+  float* TW = GS + (size_t)d * d;
+  float* RS = TW + (size_t)g.kp * g.ldw;   // dpre_h  [np][ldw]
+  float* RS2 = RS + (size_t)g.np * g.ldw;  // dmean, then dmean * act(pre_h)
+  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)d * d + (size_t)g.kp * g.ldw + (size_t)2 * g.np * g.ldw) + 3) & ~(size_t)3));
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t dd = (size_t)d * d;
+  const int H = np_.H;
+  const NNOff off = nn_offsets(d, H, np_.bias);
+  const float* th_m = theta + (size_t)m * P;
+  float* om = out + (size_t)m * out_stride;
+  for (int e = tid; e < g.np * g.ldx; e += 256) {
+    const int n = e / g.ldx, c = e - n * g.ldx;
+    X[e] = (n < N && c < d) ? x[(size_t)n * d + c] : 0.f;
+  }
+  for (int e = tid; e < 2 * g.np * g.ldw; e += 256) RS[e] = 0.f;
+  // outputs start at zero (theta mode: P entries; z modes: d*d)
+  const size_t n_out = mode == LIN_MODE_THETA ? P : dd;
+  for (size_t e = tid; e < n_out; e += 256) om[e] = 0.f;
+  const Key2 key = lin_mode_key(mode, carry, M_global, m0 + m, layout);
+  const uint64_t nbits = (uint64_t)S * dd;
+  const float* lp = logprobs + (size_t)m * S;
+  double mx = -INFINITY;
+  for (int s = tid; s < S; s += 256) mx = (double)lp[s] > mx ? (double)lp[s] : mx;
+  mx = wave_max_d(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = red[0];
+  for (int w = 1; w < 4; ++w) mx = red[w] > mx ? red[w] : mx;
+  double den = 0.0, sm = 0.0;
+  for (int s = tid; s < S; s += 256) {
+    den += exp((double)lp[s] - mx);
+    sm += (double)lp[s];
+  }
+  den = wave_sum_d(den);
+  sm = wave_sum_d(sm);
+  __syncthreads();
+  if (lane == 0) {
+    red[wave] = den;
+    red[4 + wave] = sm;
+  }
+  __syncthreads();
+  den = red[0] + red[1] + red[2] + red[3];
+  sm = red[4] + red[5] + red[6] + red[7];
+  const float inv_on = 1.0f / np_.obs_noise;
+  const float inv_sp2 = 1.0f / (np_.sig_param * np_.sig_param);
+  const float* sc_m = scores + (size_t)m * dd;
+  const uint32_t* thr_m = thr + (size_t)m * dd;
+  const int nrt = g.np >> 4;
+
+  for (int s = 0; s < S; ++s) {
+    const float w = (float)(exp((double)lp[s] - mx) / den);
+    if (w == 0.f) continue;  // block-uniform
+    __syncthreads();
+    nn_build_graph(GS, mode, key, nbits, s, thr_m, sc_m, alpha, tau, layout, tiny, d, tid);
+    __syncthreads();
+    if (mode == LIN_MODE_Z_SCORE) {
+      for (int e = tid; e < (int)dd; e += 256) om[e] += w * GS[e];
+      continue;
+    }
+    // ---- forward: mean ----
+    f32x4 macc[NU][NT];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) macc[u][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < H; ++h) {
+      __syncthreads();
+      nn_build_tw(TW, GS, th_m, h, H, np_.sig_param, g, tid);
+      __syncthreads();
+      f32x4 acc[NU][NT];
+      nn_gemm_x_tw<NT, NU>(X, TW, g, lane, wave, acc);
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+          const int j = tj * 16 + (lane & 15);
+          if (j < d && wave + 4 * u < nrt) {
+            const float b1 = np_.bias ? th_m[off.b1 + (size_t)j * H + h] : 0.f;
+            const float w2 = th_m[off.w2 + (size_t)j * H + h];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) macc[u][tj][r] += w2 * nn_act(np_.act, acc[u][tj][r] + b1);
+          }
+        }
+    }
+    // dmean = (1 - mask) (x - mean) / obs_noise  (kept in registers, C layout)
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = (wave + 4 * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
+          float dm = 0.f;
+          if (n < N && j < d && wave + 4 * u < nrt && !(any_mask && mask[(size_t)n * d + j]))
+            dm = (X[n * g.ldx + j] - macc[u][tj][r] - (np_.bias ? th_m[off.b2 + j] : 0.f)) * inv_on;
+          macc[u][tj][r] = dm;
+          if (n < g.np && j < g.ldw && wave + 4 * u < nrt) RS2[n * g.ldw + j] = dm;
+        }
+    __syncthreads();
+    if (mode == LIN_MODE_THETA && np_.bias)
+      for (int j = tid; j < d; j += 256) {  // d/db2_j = sum_n dmean_nj
+        float t = 0.f;
+        for (int n = 0; n < N; ++n) t += RS2[n * g.ldw + j];
+        om[off.b2 + j] += w * t;
+      }
+    // ---- backward, one hidden unit at a time ----
+    for (int h = 0; h < H; ++h) {
+      __syncthreads();
+      nn_build_tw(TW, GS, th_m, h, H, np_.sig_param, g, tid);
+      __syncthreads();
+      f32x4 acc[NU][NT];
+      nn_gemm_x_tw<NT, NU>(X, TW, g, lane, wave, acc);
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+          const int j = tj * 16 + (lane & 15);
+          const float b1 = (np_.bias && j < d) ? th_m[off.b1 + (size_t)j * H + h] : 0.f;
+          const float w2 = j < d ? th_m[off.w2 + (size_t)j * H + h] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = (wave + 4 * u) * 16 + (lane >> 4) * 4 + r;
+            if (n < g.np && wave + 4 * u < nrt) {
+              const float pre = acc[u][tj][r] + b1;
+              const float hv = nn_act(np_.act, pre);
+              const float dm = macc[u][tj][r];
+              RS[n * g.ldw + j] = dm * w2 * nn_dact(np_.act, pre, hv);  // dpre
+              RS2[n * g.ldw + j] = dm * hv;                              // for d/dW2
+            }
+          }
+        }
+      __syncthreads();
+      if (mode == LIN_MODE_THETA)
+        for (int j = tid; j < d; j += 256) {
+          float t1 = 0.f, t2 = 0.f;
+          for (int n = 0; n < N; ++n) {
+            t1 += RS[n * g.ldw + j];
+            t2 += RS2[n * g.ldw + j];
+          }
+          if (np_.bias) om[off.b1 + (size_t)j * H + h] += w * t1;
+          om[off.w2 + (size_t)j * H + h] += w * t2;
+        }
+      // xtr[a][j] = sum_n x[n][a] dpre[n][j]  (d/dT_h)
+#pragma unroll
+      for (int u = 0; u < NUD; ++u) {
+        const int ti = wave + 4 * u;
+        if (ti >= NT) break;
+        f32x4 t[NT];
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) t[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int ap = (lane >> 4) * g.ldx + ti * 16 + (lane & 15);
+        const int bq = (lane >> 4) * g.ldw + (lane & 15);
+        for (int k0 = 0; k0 < g.np; k0 += 4) {
+          const float a = X[ap + k0 * g.ldx];
+#pragma unroll
+          for (int tj = 0; tj < NT; ++tj) t[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, RS[bq + k0 * g.ldw + tj * 16], t[tj], 0, 0, 0);
+        }
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int a = ti * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
+            if (a < d && j < d) {
+              float xtr = t[tj][r];
+              asm volatile("" : "+v"(xtr));
+              const float gv = GS[a * d + j];
+              const float w1 = th_m[((size_t)j * d + a) * H + h];
+              if (mode == LIN_MODE_THETA) {
+                om[((size_t)j * d + a) * H + h] += w * gv * (xtr - w1 * inv_sp2);
+              } else if (a != j) {
+                om[a * d + j] += w * (lin_logn(w1, 0.f, np_.sig_param) + w1 * xtr) * tau * alpha * gv * (1.0f - gv);
+              }
+            }
+          }
+      }
+    }
+  }
+  __syncthreads();
+  // epilogue
+  const float bold = baseline ? baseline[m] : 0.f;
+  if (mode == LIN_MODE_THETA) {
+    // graph-independent prior gradient of the remaining leaves: -theta / sig_p^2 (the softmax weights sum to 1)
+    for (size_t e = off.b1 + tid; e < off.P; e += 256) om[e] += -th_m[e] * inv_sp2;
+    if (theta_copy)
+      for (size_t e = tid; e < P; e += 256) theta_copy[(size_t)m * out_stride + e] = th_m[e];
+  } else if (mode == LIN_MODE_Z_SCORE) {
+    const float scale = sf_baseline > 0.0 ? (float)exp(-(double)bold) : 1.0f;
+    for (int e = tid; e < (int)dd; e += 256) {
+      const int i = e / d, j = e - i * d;
+      const float p = (float)sigmoid_d((double)__fmul_rn(alpha, sc_m[e]));
+      om[e] = i == j ? 0.f : scale * alpha * (om[e] - p);
+    }
+  }
+  if (mode != LIN_MODE_THETA && baseline_out && tid == 0)
+    baseline_out[m] = (mode == LIN_MODE_Z_SCORE) ? (float)(sf_baseline * (sm / S) + (1.0 - sf_baseline) * (double)bold) : bold;
+}
+
+// theta init with the stax key discipline (nonlinearGaussian.py:155-186; stax.serial / Dense of jax.example_libraries):
+// subkey(m, j) = row m*d+j of split(key, M*d); per stax layer: rng, layer_rng = split(rng) (the activation layer consumes
+// one too); Dense: k1, k2 = split(layer_rng); W = normal(k1, (in, out)) * sig; b = normal(k2, (out,)) * sig.
+// one thread per (local particle, node)
+__global__ void k_init_theta_nn(float* __restrict__ theta, size_t P, Key2 key, int m0, int Mloc, int M_global, int d, int H, int bias,
+                                float sig, int layout) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Mloc * d) return;
+  const int m = t / d, j = t - m * d;
+  const NNOff off = nn_offsets(d, H, bias);
+  float* th = theta + (size_t)m * P;
+  Key2 rng = rng_split_row(key, (uint32_t)(M_global * d), (uint32_t)((m0 + m) * d + j), layout);
+  for (int layer = 0; layer < 3; ++layer) {
+    const Key2 lr = rng_split_row(rng, 2u, 1u, layout);
+    rng = rng_split_row(rng, 2u, 0u, layout);
+    if (layer == 1) continue;  // activation: no parameters
+    const int in = layer == 0 ? d : H, outn = layer == 0 ? H : 1;
+    const uint64_t nw = (uint64_t)in * outn;
+    float* W = layer == 0 ? th + off.w1 + (size_t)j * d * H : th + off.w2 + (size_t)j * H;
+    if (bias) {
+      const Key2 k1 = rng_split_row(lr, 2u, 0u, layout), k2 = rng_split_row(lr, 2u, 1u, layout);
+      for (uint64_t i = 0; i < nw; ++i) W[i] = rng_normal(rng_bits_at(k1, nw, i, layout)) * sig;
+      float* B = layer == 0 ? th + off.b1 + (size_t)j * H : th + off.b2 + j;
+      for (uint64_t i = 0; i < (uint64_t)outn; ++i) B[i] = rng_normal(rng_bits_at(k2, (uint64_t)outn, i, layout)) * sig;
+    } else {
+      for (uint64_t i = 0; i < nw; ++i) W[i] = rng_normal(rng_bits_at(lr, nw, i, layout)) * sig;
+    }
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+template <int NT>
+static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P) {
+  const int spb = 2;
+  const size_t lds1 = nn_lds_bytes(jl.d, jl.N, NT, false), lds2 = nn_lds_bytes(jl.d, jl.N, NT, true);
+  if (lds1 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_logprobs<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+  if (lds2 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_grad<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+  float* lp = mode == LIN_MODE_THETA ? jl.logprobs_th : jl.logprobs_z;
+  hipLaunchKernelGGL(k_nn_logprobs<NT>, dim3((jl.S + spb - 1) / spb, jl.Mloc), dim3(256), lds1, jl.stream, w->x, w->mask, jl.theta, P,
+                     jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, spb, jl.alpha, jl.tau, jl.layout, jl.tiny, np_,
+                     w->any_mask);
+  float* out = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off : jl.w_lik;
+  const size_t ostride = mode == LIN_MODE_THETA ? jl.pack_stride : (size_t)jl.d * jl.d;
+  float* tcopy = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr;
+  hipLaunchKernelGGL(k_nn_grad<NT>, dim3(jl.Mloc), dim3(256), lds2, jl.stream, w->x, w->mask, jl.theta, P, jl.scores, jl.thr, lp, out,
+                     ostride, tcopy, jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode, jl.m0,
+                     jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask);
+}
+
+static inline void joint_nn_dispatch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P) {
+  switch ((jl.d + 15) / 16) {
+    case 1: joint_nn_launch<1>(w, jl, carry, mode, np_, P); break;
+    case 2: joint_nn_launch<2>(w, jl, carry, mode, np_, P); break;
+    case 3: joint_nn_launch<3>(w, jl, carry, mode, np_, P); break;
+    case 4: joint_nn_launch<4>(w, jl, carry, mode, np_, P); break;
+    case 5: joint_nn_launch<5>(w, jl, carry, mode, np_, P); break;
+    case 6: joint_nn_launch<6>(w, jl, carry, mode, np_, P); break;
+    default: joint_nn_launch<7>(w, jl, carry, mode, np_, P); break;
+  }
+}

@@ -344,3 +344,61 @@ def test_score_graphs_and_mixture(c_oracle64):
     mixj = jd.get_mixture(g, th)
     assert abs(np.exp(mixj.logp).sum() - 1) < 1e-6
     assert np.isfinite(neg_ave_log_likelihood(dist=mixj, eltwise_log_likelihood=jd.eltwise_log_likelihood_observ, x=dataj.x_ho))
+
+
+@pytest.mark.parametrize("d,M,S,Sa,H,act,bias,est,interv,steps", [
+    (5, 3, 16, 4, 4, "relu", True, "reparam", True, (1, 2)),
+    (6, 3, 16, 4, 3, "tanh", False, "score", False, (1, 2)),
+    (20, 4, 32, 8, 5, "relu", True, "reparam", False, (2,)),
+    (20, 3, 16, 4, 5, "leakyrelu", True, "reparam", True, (3,)),
+])
+def test_joint_densenn_step_stages(c_oracle64, d, M, S, Sa, H, act, bias, est, interv, steps):
+    N = 60
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(N, d)).astype(np.float32)
+    mask = (rng.random((N, d)) < 0.1).astype(np.int32) if interv else None
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=N, edges_per_node=1 if d <= 6 else 2, joint=True,
+                      likelihood="densenn", grad_estimator_z=est, n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa,
+                      nn_hidden=(H,), nn_activation=act, nn_bias=bias, has_interventions=interv)
+    st = c_oracle64.new_state(cfg, prng.PRNGKey(6))
+    eng = _engine(cfg, x, mask)
+    eng.init_particles(prng.PRNGKey(6))
+    g0 = eng.get_state()
+    assert (g0["key"] == st["key"]).all() and rel_err(g0["theta"], st["theta"]) < 1e-6, "stax init stream"
+    for t in steps:
+        _sync_states(eng, st)
+        dbg = c_oracle64.step(cfg, x, mask, st, t, debug=True)
+        eng.run(t, 1)
+        g = eng.get_state()
+        assert (g["key"] == st["key"]).all()
+        assert rel_err(eng.read("LOGPROBS_THETA"), dbg["logprobs_th"]) < 2e-5
+        assert rel_err(eng.read("LOGPROBS_Z"), dbg["logprobs_z"]) < 2e-5
+        assert rel_err(eng.read("GRAD_THETA"), dbg["grad_theta"]) < 2e-3
+        assert rel_err(eng.read("W_LIK"), dbg["w_lik"]) < 2e-3
+        assert rel_err(eng.read("GRAD_Z"), dbg["grad_z"]) < 2e-3
+        assert rel_err(eng.read("PHI_THETA"), dbg["phi_theta"]) < 2e-3
+        assert rel_err(g["theta"], st["theta"]) < 1e-4
+        # piecewise-linear activations: a pre-activation within fp32 rounding of 0 flips relu' between the f32 device
+        # and the f64 oracle, and RMSprop turns the resulting small phi differences into O(stepsize) differences
+        assert rel_err(g["z"], st["z"]) < 5e-4
+    eng.close()
+
+
+def test_densenn_sample_and_scoring(c_oracle64):
+    from dibs_amd.inference import JointDiBS
+    from dibs_amd.inference.scoring import score_graphs
+    from dibs_amd.models import DenseNonlinearGaussian
+    from dibs_amd.target import make_nonlinear_gaussian_model
+    from dibs_amd import random
+    data, gm, lm = make_nonlinear_gaussian_model(key=random.PRNGKey(0), n_vars=8, graph_prior_str="er", n_observations=50)
+    dibs = JointDiBS(x=data.x, graph_model=gm, likelihood_model=lm, n_grad_mc_samples=16, n_acyclicity_mc_samples=4)
+    g, theta = dibs.sample(key=random.PRNGKey(1), n_particles=4, steps=4)
+    assert g.shape == (4, 8, 8) and theta[0][0].shape == (4, 8, 8, 5) and theta[0][1].shape == (4, 8, 5) and theta[1] == ()
+    assert theta[2][0].shape == (4, 8, 5, 1) and theta[2][1].shape == (4, 8, 1)
+    flat = lm.tree_to_flat(theta)
+    cfg = make_config(n_vars=8, n_particles=1, n_observations=50, joint=True, likelihood="densenn")
+    ref = c_oracle64.score_graphs(cfg, data.x_ho[:50], None, g, flat.astype(np.float64))
+    got = score_graphs(lm, g, flat, data.x_ho[:50], None)
+    assert rel_err(got, ref) < 2e-5
+    mix = dibs.get_mixture(g, theta)
+    assert abs(np.exp(mix.logp).sum() - 1) < 1e-6

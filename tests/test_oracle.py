@@ -144,3 +144,38 @@ def test_f32_port_tracks_f64_single_step(c_oracle32, c_oracle64):
     c_oracle64.step(cfg, data.x, None, a, 0)
     c_oracle32.step(cfg, data.x, None, b, 0)
     assert rel_err(b["z"], a["z"]) < 1e-4  # the tolerance north_star states for fp32
+
+
+@pytest.mark.parametrize("est,bias,act", [("reparam", True, "relu"), ("score", False, "tanh"), ("reparam", True, "leakyrelu")])
+def test_joint_densenn_step_cport_vs_autograd(c_oracle64, est, bias, act):
+    """DenseNonlinearGaussian (nonlinearGaussian.py:155-186, 248-326): stax-style init stream, forward and the manual
+    backprop of the C port against autograd; interventions on."""
+    from dibs_amd.models import DenseNonlinearGaussian
+    d, M, N, H = 5, 3, 40, 4
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(N, d)).astype(np.float32).astype(np.float64)
+    mask = (rng.random((N, d)) < 0.1).astype(np.int32)
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=N, edges_per_node=1, joint=True, likelihood="densenn",
+                      grad_estimator_z=est, n_grad_mc_samples=8, n_acyclicity_mc_samples=2, nn_hidden=(H,),
+                      nn_activation=act, nn_bias=bias, has_interventions=True)
+    ocfg = O.Config(joint=True, likelihood="densenn", alpha_linear=0.05, grad_estimator_z=est, prior=O.GraphPrior("er", 1),
+                    n_grad_mc_samples=8, n_acyclicity_mc_samples=2,
+                    nn=O.DenseNNParams(hidden_layers=(H,), activation=act, bias=bias))
+    flat = lambda th: np.stack([np.concatenate([leaf.numpy().reshape(-1) for leaf in th[m]]) for m in range(M)])
+    st = O.init_state(ocfg, prng.PRNGKey(3), M, d)
+    cs = c_oracle64.new_state(cfg, prng.PRNGKey(3))
+    assert np.array_equal(cs["theta"], flat(st.theta))
+    # the product's host-side sample_parameters follows the same key discipline
+    k, sub = prng.split(prng.PRNGKey(3))
+    ik, _ = prng.split(sub)
+    _, tsub = prng.split(ik)
+    nn = DenseNonlinearGaussian(n_vars=d, hidden_layers=(H,), activation=act, bias=bias)
+    assert np.array_equal(nn.tree_to_flat(nn.sample_parameters(key=tsub, n_vars=d, n_particles=M)), flat(st.theta).astype(np.float32))
+    for t in range(1, 3):
+        st, aux = O.svgd_step(ocfg, st, _xt(x), _xt(mask), t, return_aux=True)
+        dbg = c_oracle64.step(cfg, x, mask, cs, t, debug=True)
+        gth = np.stack([np.concatenate([leaf.numpy().reshape(-1) for leaf in aux["dtheta"][m]]) for m in range(M)])
+        assert rel_err(dbg["grad_theta"], gth) < 1e-9
+        assert rel_err(dbg["grad_z"], (aux["dz_lik"] + aux["dz_prior"]).numpy()) < 1e-6
+        assert rel_err(cs["z"], st.z.numpy()) < 1e-6
+        assert rel_err(cs["theta"], flat(st.theta)) < 1e-9
