@@ -142,7 +142,7 @@ def main():
         if not args.no_cpu_baseline:
             # ---- CPU baseline: the oracle's C port on this box's host cores, bounded sample ----
             from oracle.c_oracle import COracle
-            cores = os.cpu_count() or 1
+            cores = min(os.cpu_count() or 1, N_PARTICLES)   # OpenMP over particles: more threads than particles are idle
             co = COracle("f64")
             cfg1 = make_config(n_vars=D_VARS, n_particles=N_PARTICLES, n_observations=N_OBS, n_grad_mc_samples=S_MC,
                                n_acyclicity_mc_samples=SA_MC)
