@@ -48,6 +48,7 @@ struct dibs_engine {
   float *scores, *probs, *w_tot, *w_lik, *acyc_part, *w_acyc, *logprobs_z, *logprobs_th, *pack, *kz, *kt, *phi_z, *phi_th;
   uint32_t* thr;
   uint64_t* masks;
+  BgeQueues bq;
   double* node_scores;
   unsigned long long* counters;
   JointWork jw;
@@ -213,6 +214,10 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
   if (c.likelihood == DIBS_LIK_BGE) {
     HIP_OK(dalloc(&e->masks, Ml * e->S * e->d * e->W));
     HIP_OK(dalloc(&e->node_scores, Ml * e->S * e->d));
+    HIP_OK(dalloc(&e->bq.list16, Ml * e->S * e->d));
+    HIP_OK(dalloc(&e->bq.list32, Ml * e->S * e->d));
+    HIP_OK(dalloc(&e->bq.listg, Ml * e->S * e->d));
+    HIP_OK(dalloc(&e->bq.counts, (size_t)4));
   }
   if (c.joint) {
     if (joint_alloc(&e->jw, e->Mloc, e->d, e->N, e->S) != 0) return fail("joint work buffers: hipMalloc failed");
@@ -227,7 +232,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->w_tot, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
-                  e->node_scores, e->x, e->mask, e->R, e->gam, e->Nj};
+                  e->node_scores, e->x, e->mask, e->R, e->gam, e->Nj, e->bq.list16, e->bq.list32, e->bq.listg, e->bq.counts};
   for (void* p : ptrs)
     if (p) hipFree(p);
   joint_free(&e->jw);
@@ -432,6 +437,29 @@ static void drain_timers(dibs_engine* e) {
 // the host walks the chain (row 0), kernels derive row 1 + m.
 static Key2 next_carry(const dibs_engine* e, Key2 k) { return rng_split_row(k, (uint32_t)e->M + 1u, 0u, e->cfg.rng_layout); }
 
+// queued BGe problems (k_bge_big): three grid-stride launches sized for the device, R in LDS when there is one matrix
+static void launch_bge_big(dibs_engine* e, const BgeParams& bp, const uint64_t* masks, double* ns, const BgeQueues& q, int S,
+                           unsigned long long* cnt) {
+  const bool rl = bp.n_mats == 1;
+  const int d = e->d, W = e->W;
+#define BIG(G_, LIST_, IDX_, NBLK_)                                                                                       \
+  if (rl) {                                                                                                               \
+    const size_t lds = bge_big_lds_bytes(d, G_, true);                                                                    \
+    allow_lds(k_bge_big<G_, true>, lds);                                                                                  \
+    hipLaunchKernelGGL((k_bge_big<G_, true>), dim3(NBLK_), dim3(256), lds, e->stream, masks, ns, bp, LIST_, q.counts + IDX_, d, S, \
+                       W, cnt);                                                                                           \
+  } else {                                                                                                                \
+    const size_t lds = bge_big_lds_bytes(d, G_, false);                                                                   \
+    allow_lds(k_bge_big<G_, false>, lds);                                                                                 \
+    hipLaunchKernelGGL((k_bge_big<G_, false>), dim3(NBLK_), dim3(256), lds, e->stream, masks, ns, bp, LIST_, q.counts + IDX_, d, S, \
+                       W, cnt);                                                                                           \
+  }
+  BIG(16, q.list16, 0, 1024)
+  BIG(32, q.list32, 1, 1024)
+  BIG(64, q.listg, 2, 512)
+#undef BIG
+}
+
 template <int NT>
 static void launch_acyc(dibs_engine* e, Key2 carry, float alpha) {
   constexpr int DP = 16 * NT, LD = DP + 4;
@@ -470,16 +498,18 @@ static int step_local(dibs_engine* e, int t, float* pack) {
       KTimer tm(e, DIBS_K_BGE_NODES);
       BgeParams bp{e->R, e->gam, e->Nj, e->alpha_lambd, e->n_mats};
       unsigned long long* cnt = e->profiling ? e->counters : (unsigned long long*)nullptr;
+      hipMemsetAsync(e->bq.counts, 0, 4 * sizeof(unsigned int), e->stream);
       const size_t lds4 = bge_lds_bytes(e->d, e->S, e->W, 4), lds1 = bge_lds_bytes(e->d, e->S, e->W, 1);
       if (e->n_mats == 1 && lds4 <= 80 * 1024) {
         allow_lds(k_bge_nodes<4, true>, lds4);
         hipLaunchKernelGGL((k_bge_nodes<4, true>), dim3((e->d + 3) / 4, e->Mloc), dim3(256), lds4, e->stream, e->thr, e->masks,
-                           e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L, cnt);
+                           e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L, cnt, e->bq);
       } else {
         allow_lds(k_bge_nodes<1, true>, lds1);
         hipLaunchKernelGGL((k_bge_nodes<1, true>), dim3(e->d, e->Mloc), dim3(64), lds1, e->stream, e->thr, e->masks,
-                           e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L, cnt);
+                           e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L, cnt, e->bq);
       }
+      launch_bge_big(e, bp, e->masks, e->node_scores, e->bq, e->S, cnt);
     }
     {
       KTimer tm(e, DIBS_K_LIK_WEIGHTS);
@@ -790,6 +820,11 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
     HIP_OK(dalloc(&d_masks, (size_t)d * CH * W));
     HIP_OK(dalloc(&d_ns, (size_t)d * CH));
     std::vector<uint64_t> hm((size_t)d * CH * W);
+    BgeQueues sq;  // scratch queues for this call
+    HIP_OK(dalloc(&sq.list16, (size_t)d * CH));
+    HIP_OK(dalloc(&sq.list32, (size_t)d * CH));
+    HIP_OK(dalloc(&sq.listg, (size_t)d * CH));
+    HIP_OK(dalloc(&sq.counts, (size_t)4));
     for (int q0 = 0; q0 < n; q0 += CH) {
       const int S = n - q0 < CH ? n - q0 : CH;
       std::fill(hm.begin(), hm.end(), 0ull);
@@ -800,20 +835,26 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
       HIP_OK(hipMemcpy(d_masks, hm.data(), (size_t)d * S * W * 8, hipMemcpyHostToDevice));
       BgeParams bp{st.R, st.gam, st.Nj, st.alpha_lambd, st.n_mats};
       const size_t lds4 = bge_lds_bytes(d, S, W, 4), lds1 = bge_lds_bytes(d, S, W, 1);
+      hipMemsetAsync(sq.counts, 0, 4 * sizeof(unsigned int), e->stream);
       if (st.n_mats == 1 && lds4 <= 96 * 1024) {
         allow_lds(k_bge_nodes<4, false>, lds4);
         hipLaunchKernelGGL((k_bge_nodes<4, false>), dim3((d + 3) / 4, 1), dim3(256), lds4, e->stream, (const uint32_t*)nullptr,
-                           d_masks, d_ns, bp, Key2{0, 0}, 0, 1, d, S, W, 0, (unsigned long long*)nullptr);
+                           d_masks, d_ns, bp, Key2{0, 0}, 0, 1, d, S, W, 0, (unsigned long long*)nullptr, sq);
       } else {
         allow_lds(k_bge_nodes<1, false>, lds1);
         hipLaunchKernelGGL((k_bge_nodes<1, false>), dim3(d, 1), dim3(64), lds1, e->stream, (const uint32_t*)nullptr, d_masks,
-                           d_ns, bp, Key2{0, 0}, 0, 1, d, S, W, 0, (unsigned long long*)nullptr);
+                           d_ns, bp, Key2{0, 0}, 0, 1, d, S, W, 0, (unsigned long long*)nullptr, sq);
       }
+      launch_bge_big(e, bp, d_masks, d_ns, sq, S, (unsigned long long*)nullptr);
       hipLaunchKernelGGL(k_sum_nodes, dim3((S + 127) / 128), dim3(128), 0, e->stream, d_ns, d_out + q0, d, S);
       HIP_OK(hipStreamSynchronize(e->stream));
     }
     hipFree(d_masks);
     hipFree(d_ns);
+    hipFree(sq.list16);
+    hipFree(sq.list32);
+    hipFree(sq.listg);
+    hipFree(sq.counts);
   } else if (c.likelihood == DIBS_LIK_LINGAUSS) {
     if (!theta) { hipFree(d_out); return fail("theta required"); }
     JointWork jw;

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void k_lin_grad(const float* __restrict__ x, c
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int ti = wave + 4 * u;
-      if (ti >= NT) break;
+      if (ti >= NT) continue;  // (not `break`: keeps the trip count constant so the loop unrolls)
       f32x4 t[NT];
 #pragma unroll
       for (int tj = 0; tj < NT; ++tj) t[tj] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -123,8 +123,8 @@ __host__ __device__ inline int bge_lbuf_floats(int d) {
 }
 __host__ __device__ inline int bge_idx_len(int d) { return d + 4 > 36 ? d + 4 : 36; }  // >= 32: the 32-lane tier zero-fills 32 slots
 __host__ __device__ inline size_t bge_wave_bytes(int d, int S, int W) {
-  // masks[S*W] u64 | Lbuf | thr[d] | idx[4][idx_len] | three u16 queues [S]
-  size_t b = (size_t)S * W * 8 + (size_t)bge_lbuf_floats(d) * 4 + (size_t)d * 4 + (size_t)4 * bge_idx_len(d) * 4 + (size_t)S * 6;
+  // masks[S*W] u64 | thr[d]
+  size_t b = (size_t)S * W * 8 + (size_t)d * 4;
   return (b + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t bge_lds_bytes(int d, int S, int W, int waves) {
@@ -147,89 +147,19 @@ __device__ __forceinline__ double bge_assemble(const BgeParams& bp, int j, int l
   return bp.gam[(size_t)j * (d + 1) + l] + 0.5 * (Nn + al - d + l) * ld_pa - 0.5 * (Nn + al - d + l + 1) * ld_all;
 }
 
-// Cooperative tier: G lanes per problem (lane = row), 64 / G problems per wave.  Row r of L lives in the owning
-// lane's registers; the pivot row is re-read from LDS (one ds_read_b128 per four columns, broadcast inside the group);
-// every lane recomputes the pivot d_k from that row, so a column step depends on LDS only through the previous
-// column's store.  The gathered row A[r][:] and the diagonal are preloaded.
-template <int G>
-__device__ __forceinline__ double bge_chol_groups(const float* __restrict__ Rs, float* __restrict__ Lb, int* __restrict__ idxs,
-                                                  const uint64_t* __restrict__ mk, const unsigned short* __restrict__ list,
-                                                  int cnt, int W, int d, int j, int lane, const BgeParams& bp, double Nn,
-                                                  double* __restrict__ ns_out) {
-  constexpr int NP = 64 / G, LD = G + 4;
-  const int grp = lane / G, r = lane % G;
-  const int ilen = bge_idx_len(d);
-  int* myidx = idxs + grp * ilen;
-  float* Lh = Lb + grp * G * LD;
-  double flops = 0.0;
-  for (int q = 0; q < cnt; q += NP) {
-    const bool has = q + grp < cnt;
-    const int sP = has ? (int)list[q + grp] : 0;
-    int l = 0;
-    myidx[r] = 0;  // slots >= n must hold a valid index
-    wave_lds_fence();
-    if (has) {
-      for (int w = 0; w < W; ++w) {
-        const uint64_t word = mk[sP * W + w];
-        for (int bb = r; bb < 64; bb += G)
-          if ((word >> bb) & 1ull) myidx[l + __popcll(word & ((1ull << bb) - 1ull))] = w * 64 + bb;
-        l += __popcll(word);
-      }
-      if (r == 0) myidx[l] = j;
-    }
-    const int n = has ? l + 1 : 0;
-    int nmax = 0;
-#pragma unroll
-    for (int g = 0; g < NP; ++g) {
-      const int t = __shfl(n, g * G, 64);
-      nmax = t > nmax ? t : nmax;
-    }
-    wave_lds_fence();
-    const int ir = (r < n) ? myidx[r] : 0;
-    float Ar[G], Dk[G], Lr[G];
-#pragma unroll
-    for (int k = 0; k < G; ++k) {
-      const int ik = myidx[k];
-      Ar[k] = Rs[ir * d + ik];
-      Dk[k] = Rs[ik * d + ik];
-      Lr[k] = 0.f;
-    }
-    float mypiv = 1.f;
-#pragma unroll
-    for (int k = 0; k < G; ++k) {
-      if (k >= nmax) break;
-      float acc = Ar[k], pv = Dk[k];
-#pragma unroll
-      for (int p4 = 0; p4 < (k + 3) / 4; ++p4) {
-        const float4 v = *reinterpret_cast<const float4*>(Lh + k * LD + p4 * 4);
-        if (p4 * 4 + 0 < k) { acc = fmaf(-Lr[p4 * 4 + 0], v.x, acc); pv = fmaf(-v.x, v.x, pv); }
-        if (p4 * 4 + 1 < k) { acc = fmaf(-Lr[p4 * 4 + 1], v.y, acc); pv = fmaf(-v.y, v.y, pv); }
-        if (p4 * 4 + 2 < k) { acc = fmaf(-Lr[p4 * 4 + 2], v.z, acc); pv = fmaf(-v.z, v.z, pv); }
-        if (p4 * 4 + 3 < k) { acc = fmaf(-Lr[p4 * 4 + 3], v.w, acc); pv = fmaf(-v.w, v.w, pv); }
-      }
-      if (r == k) mypiv = pv;
-      const float lv = acc * rsqrtf(pv);
-      Lr[k] = lv;
-      if (r > k) Lh[r * LD + k] = lv;
-      wave_lds_fence();
-    }
-    double lg = (r < l) ? log((double)mypiv) : 0.0;
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);
-    const double schur = (double)__shfl(mypiv, grp * G + (l < G ? l : 0), 64);
-    if (r == 0 && has) {
-      ns_out[sP] = bge_assemble(bp, j, l, d, Nn, lg, schur);
-      flops += (double)n * n * n / 3.0;
-    }
-  }
-  return flops;
-}
+// Work queues for the problems that do not fit the per-lane tier: code = (m * d + j) * S + s.
+struct BgeQueues {
+  uint32_t* list16;      // 9 <= n <= 16
+  uint32_t* list32;      // 17 <= n <= 32
+  uint32_t* listg;       // n > 32
+  unsigned int* counts;  // [3], zeroed before every launch of k_bge_nodes
+};
 
 template <int WAVES, bool SAMPLE>
 __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __restrict__ thr, uint64_t* __restrict__ masks,
                                                           double* __restrict__ node_scores, BgeParams bp, Key2 carry,
                                                           int m0, int M_global, int d, int S, int W, int layout,
-                                                          unsigned long long* __restrict__ counters) {
+                                                          unsigned long long* __restrict__ counters, BgeQueues qs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = blockIdx.y;
@@ -239,12 +169,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
   const size_t r_bytes = (((size_t)d * d * 4) + 15) & ~(size_t)15;
   unsigned char* wbase = smem_raw + r_bytes + (size_t)wave * bge_wave_bytes(d, S, W);
   uint64_t* mk = reinterpret_cast<uint64_t*>(wbase);
-  float* Lb = reinterpret_cast<float*>(mk + (size_t)S * W);
-  uint32_t* thrs = reinterpret_cast<uint32_t*>(Lb + bge_lbuf_floats(d));
-  int* idxs = reinterpret_cast<int*>(thrs + d);  // [4][bge_idx_len(d)]
-  unsigned short* list16 = reinterpret_cast<unsigned short*>(idxs + 4 * bge_idx_len(d));
-  unsigned short* list32 = list16 + S;
-  unsigned short* listg = list32 + S;
+  uint32_t* thrs = reinterpret_cast<uint32_t*>(mk + (size_t)S * W);
 
   {  // R: shared by the block (WAVES > 1 requires n_mats == 1)
     const float* Rg = bp.R + (bp.n_mats > 1 ? (size_t)(blockIdx.x * WAVES) * d * d : 0);
@@ -323,9 +248,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
   double* ns_out = node_scores + ((size_t)m * d + j) * S;
   const double score_l0 = bge_assemble(bp, j, 0, d, Nn, 0.0, (double)Rs[j * d + j]);
   double flops = 0.0;
-  int n16 = 0, n32 = 0, ng = 0;
 
-  // ---- 2a. n <= 8: one problem per lane, registers only -----------------------------------------
+  // ---- 2. n <= 8: one problem per lane, registers only; larger problems are queued for k_bge_big -----------
   for (int s0 = 0; s0 < S; s0 += 64) {
     const int s = s0 + lane;
     const bool valid = s < S;
@@ -375,78 +299,205 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
       ns_out[s] = bge_assemble(bp, j, l, d, Nn, log(prod), schur);
       flops += (double)n * n * n / 3.0;
     }
-    // queue the rest by tier: n <= 16 (4 per wave), n <= 32 (2 per wave), generic
+    // queue the rest by tier (wave-aggregated atomics; the order inside a queue does not affect any result)
     const bool t16 = valid && !small && l <= 15, t32 = valid && !small && !t16 && l <= 31, tg = valid && !small && l > 31;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t code = (uint32_t)(((size_t)m * d + j) * S + s);
     const unsigned long long b16 = __ballot(t16), b32 = __ballot(t32), bg = __ballot(tg);
-    if (t16) list16[n16 + __popcll(b16 & lt)] = (unsigned short)s;
-    if (t32) list32[n32 + __popcll(b32 & lt)] = (unsigned short)s;
-    if (tg) listg[ng + __popcll(bg & lt)] = (unsigned short)s;
-    n16 += __popcll(b16);
-    n32 += __popcll(b32);
-    ng += __popcll(bg);
-  }
-  wave_lds_fence();
-
-  // ---- 2b. larger problems, cooperatively ---------------------------------------------------------
-  if (n16) flops += bge_chol_groups<16>(Rs, Lb, idxs, mk, list16, n16, W, d, j, lane, bp, Nn, ns_out);
-  if (n32) flops += bge_chol_groups<32>(Rs, Lb, idxs, mk, list32, n32, W, d, j, lane, bp, Nn, ns_out);
-  for (int q = 0; q < ng; ++q) {
-    // ---- generic: one problem per wave, lane owns rows r and r + 64, L in LDS ----
-    const int sA = listg[q];
-    int l = 0;
-    int* myidx = idxs;
-    for (int w = 0; w < W; ++w) {
-      const uint64_t word = mk[sA * W + w];
-      if ((word >> lane) & 1ull) myidx[l + __popcll(word & ((1ull << lane) - 1ull))] = w * 64 + lane;
-      l += __popcll(word);
+    if (b16) {
+      unsigned int base = 0;
+      if (lane == __ffsll((long long)b16) - 1) base = atomicAdd(&qs.counts[0], (unsigned int)__popcll(b16));
+      base = __shfl(base, __ffsll((long long)b16) - 1, 64);
+      if (t16) qs.list16[base + __popcll(b16 & lt)] = code;
     }
-    if (lane == 0) myidx[l] = j;
-    const int n = l + 1, ldl = d | 1;
-    wave_lds_fence();
-    float mypiv[2] = {1.f, 1.f};
-    for (int kk = 0; kk < n; ++kk) {
-      const int ik = myidx[kk];
-      float accs[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int r = lane + h * 64;
-        float acc = 0.f;
-        if (r >= kk && r < n) {
-          acc = Rs[myidx[r] * d + ik];
-          const float* lr = Lb + (size_t)r * ldl;
-          const float* lk = Lb + (size_t)kk * ldl;
-          for (int p = 0; p < kk; ++p) acc = fmaf(-lr[p], lk[p], acc);
-        }
-        accs[h] = acc;
-        if (r == kk) mypiv[h] = acc;
-      }
-      const float piv = __shfl(kk < 64 ? accs[0] : accs[1], kk & 63, 64);
-      const float inv = rsqrtf(piv);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int r = lane + h * 64;
-        if (r > kk && r < n) Lb[(size_t)r * ldl + kk] = accs[h] * inv;
-      }
-      wave_lds_fence();
+    if (b32) {
+      unsigned int base = 0;
+      if (lane == __ffsll((long long)b32) - 1) base = atomicAdd(&qs.counts[1], (unsigned int)__popcll(b32));
+      base = __shfl(base, __ffsll((long long)b32) - 1, 64);
+      if (t32) qs.list32[base + __popcll(b32 & lt)] = code;
     }
-    double lg = 0.0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = lane + h * 64;
-      if (r < l) lg += log((double)mypiv[h]);
+    if (bg) {
+      unsigned int base = 0;
+      if (lane == __ffsll((long long)bg) - 1) base = atomicAdd(&qs.counts[2], (unsigned int)__popcll(bg));
+      base = __shfl(base, __ffsll((long long)bg) - 1, 64);
+      if (tg) qs.listg[base + __popcll(bg & lt)] = code;
     }
-    const double ld_pa = wave_sum_d(lg);
-    const double schur = (double)__shfl(l < 64 ? mypiv[0] : mypiv[1], l & 63, 64);
-    if (lane == 0) {
-      ns_out[sA] = bge_assemble(bp, j, l, d, Nn, ld_pa, schur);
-      flops += (double)n * n * n / 3.0;
-    }
-    wave_lds_fence();
   }
   if (counters) {
     const double tot = wave_sum_d(flops);
     if (lane == 0) atomicAdd(counters, (unsigned long long)tot);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3b  queued BGe problems, spread evenly over the GPU (a hub node makes ALL samples of one (m, j) large; handled inside
+//      k_bge_nodes they serialise in one wave and the kernel time is that tail).
+//      G = 16 / 32: G lanes per problem (lane = row), 64 / G problems per wave.  Row r of L lives in the owning lane's
+//      registers; the pivot row is re-read from LDS (one ds_read_b128 per four columns, broadcast inside the group); every
+//      lane recomputes the pivot d_k from that row, so a column step depends on LDS only through the previous column's store.
+//      G = 64: one problem per wave, lane owns rows r and r + 64, L in LDS (any n <= 128).
+// grid = any (grid-stride over the queue), block = 256; dynamic LDS: bge_big_lds_bytes()
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t bge_big_wave_bytes(int d, int G) {
+  const int ilen = bge_idx_len(d);
+  const size_t lb = G == 64 ? (size_t)d * (d | 1) : (size_t)(64 / G) * G * (G + 4);
+  return (((lb + 3) & ~(size_t)3) * 4 + (size_t)(G == 64 ? 1 : 64 / G) * ilen * 4 + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t bge_big_lds_bytes(int d, int G, bool r_in_lds) {
+  const size_t r = r_in_lds ? ((((size_t)d * d * 4) + 15) & ~(size_t)15) : 0;
+  return r + 4 * bge_big_wave_bytes(d, G);
+}
+
+template <int G, bool R_LDS>
+__global__ __launch_bounds__(256) void k_bge_big(const uint64_t* __restrict__ masks, double* __restrict__ node_scores, BgeParams bp,
+                                                 const uint32_t* __restrict__ list, const unsigned int* __restrict__ count_ptr,
+                                                 int d, int S, int W, unsigned long long* __restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned int cnt = *count_ptr;
+  if ((unsigned int)(blockIdx.x * 4 * (G < 64 ? 64 / G : 1)) >= cnt) return;  // nothing queued for this block (block-uniform)
+  float* Rs = reinterpret_cast<float*>(smem_raw);
+  const size_t r_bytes = R_LDS ? ((((size_t)d * d * 4) + 15) & ~(size_t)15) : 0;
+  if (R_LDS) {
+    for (int e = tid; e < d * d; e += 256) Rs[e] = bp.R[e];
+    __syncthreads();
+  }
+  unsigned char* wbase = smem_raw + r_bytes + (size_t)wave * bge_big_wave_bytes(d, G);
+  const int ilen = bge_idx_len(d);
+  double flops = 0.0;
+  if constexpr (G < 64) {
+    constexpr int NP = 64 / G, LD = G + 4;
+    float* Lb = reinterpret_cast<float*>(wbase);
+    int* idxs = reinterpret_cast<int*>(Lb + ((NP * G * LD + 3) & ~3));
+    const int grp = lane / G, r = lane % G;
+    int* myidx = idxs + grp * ilen;
+    float* Lh = Lb + grp * G * LD;
+    for (unsigned int q = (blockIdx.x * 4 + wave) * NP; q < cnt; q += gridDim.x * 4 * NP) {
+      const bool has = q + grp < cnt;
+      const uint32_t code = has ? list[q + grp] : 0u;
+      const int s = code % S, mj = code / S, j = mj % d;
+      const float* R = R_LDS ? Rs : bp.R + (bp.n_mats > 1 ? (size_t)j * d * d : 0);
+      int l = 0;
+      myidx[r] = 0;  // slots >= n must hold a valid index
+      wave_lds_fence();
+      if (has) {
+        for (int w = 0; w < W; ++w) {
+          const uint64_t word = masks[(size_t)code * W + w];
+          for (int bb = r; bb < 64; bb += G)
+            if ((word >> bb) & 1ull) myidx[l + __popcll(word & ((1ull << bb) - 1ull))] = w * 64 + bb;
+          l += __popcll(word);
+        }
+        if (r == 0) myidx[l] = j;
+      }
+      const int n = has ? l + 1 : 0;
+      int nmax = 0;
+#pragma unroll
+      for (int g = 0; g < NP; ++g) {
+        const int t = __shfl(n, g * G, 64);
+        nmax = t > nmax ? t : nmax;
+      }
+      wave_lds_fence();
+      const int ir = (r < n) ? myidx[r] : 0;
+      float Ar[G], Dk[G], Lr[G];
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        const int ik = myidx[k];
+        Ar[k] = R[ir * d + ik];
+        Dk[k] = R[ik * d + ik];
+        Lr[k] = 0.f;
+      }
+      float mypiv = 1.f;
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        // constant trip count (a `break` here keeps hipcc from unrolling and L would be indexed through GPR-index mode);
+        // columns beyond the largest problem of this wave are skipped by a wave-uniform branch
+        if (k < nmax) {
+          float acc = Ar[k], pv = Dk[k];
+#pragma unroll
+          for (int p4 = 0; p4 < (k + 3) / 4; ++p4) {
+            const float4 v = *reinterpret_cast<const float4*>(Lh + k * LD + p4 * 4);
+            if (p4 * 4 + 0 < k) { acc = fmaf(-Lr[p4 * 4 + 0], v.x, acc); pv = fmaf(-v.x, v.x, pv); }
+            if (p4 * 4 + 1 < k) { acc = fmaf(-Lr[p4 * 4 + 1], v.y, acc); pv = fmaf(-v.y, v.y, pv); }
+            if (p4 * 4 + 2 < k) { acc = fmaf(-Lr[p4 * 4 + 2], v.z, acc); pv = fmaf(-v.z, v.z, pv); }
+            if (p4 * 4 + 3 < k) { acc = fmaf(-Lr[p4 * 4 + 3], v.w, acc); pv = fmaf(-v.w, v.w, pv); }
+          }
+          if (r == k) mypiv = pv;
+          const float lv = acc * rsqrtf(pv);
+          Lr[k] = lv;
+          if (r > k) Lh[r * LD + k] = lv;
+          wave_lds_fence();
+        }
+      }
+      double lg = (r < l) ? log((double)mypiv) : 0.0;
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);
+      const double schur = (double)__shfl(mypiv, grp * G + (l < G ? l : 0), 64);
+      if (r == 0 && has) {
+        node_scores[(size_t)mj * S + s] = bge_assemble(bp, j, l, d, bp.Nj[j], lg, schur);
+        flops += (double)n * n * n / 3.0;
+      }
+    }
+  } else {
+    float* Lb = reinterpret_cast<float*>(wbase);
+    int* myidx = reinterpret_cast<int*>(Lb + (((size_t)d * (d | 1) + 3) & ~(size_t)3));
+    const int ldl = d | 1;
+    for (unsigned int q = blockIdx.x * 4 + wave; q < cnt; q += gridDim.x * 4) {
+      const uint32_t code = list[q];
+      const int s = code % S, mj = code / S, j = mj % d;
+      const float* R = R_LDS ? Rs : bp.R + (bp.n_mats > 1 ? (size_t)j * d * d : 0);
+      int l = 0;
+      for (int w = 0; w < W; ++w) {
+        const uint64_t word = masks[(size_t)code * W + w];
+        if ((word >> lane) & 1ull) myidx[l + __popcll(word & ((1ull << lane) - 1ull))] = w * 64 + lane;
+        l += __popcll(word);
+      }
+      if (lane == 0) myidx[l] = j;
+      const int n = l + 1;
+      wave_lds_fence();
+      float mypiv[2] = {1.f, 1.f};
+      for (int kk = 0; kk < n; ++kk) {
+        const int ik = myidx[kk];
+        float accs[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = lane + h * 64;
+          float acc = 0.f;
+          if (r >= kk && r < n) {
+            acc = R[myidx[r] * d + ik];
+            const float* lr = Lb + (size_t)r * ldl;
+            const float* lk = Lb + (size_t)kk * ldl;
+            for (int p = 0; p < kk; ++p) acc = fmaf(-lr[p], lk[p], acc);
+          }
+          accs[h] = acc;
+          if (r == kk) mypiv[h] = acc;
+        }
+        const float piv = __shfl(kk < 64 ? accs[0] : accs[1], kk & 63, 64);
+        const float inv = rsqrtf(piv);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = lane + h * 64;
+          if (r > kk && r < n) Lb[(size_t)r * ldl + kk] = accs[h] * inv;
+        }
+        wave_lds_fence();
+      }
+      double lg = 0.0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = lane + h * 64;
+        if (r < l) lg += log((double)mypiv[h]);
+      }
+      const double ld_pa = wave_sum_d(lg);
+      const double schur = (double)__shfl(l < 64 ? mypiv[0] : mypiv[1], l & 63, 64);
+      if (lane == 0) {
+        node_scores[(size_t)mj * S + s] = bge_assemble(bp, j, l, d, bp.Nj[j], ld_pa, schur);
+        flops += (double)n * n * n / 3.0;
+      }
+      wave_lds_fence();
+    }
+  }
+  if (counters) {
+    const double tot = wave_sum_d(flops);
+    if (lane == 0 && tot > 0.0) atomicAdd(counters, (unsigned long long)tot);
   }
 }
 
