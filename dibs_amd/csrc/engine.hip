@@ -514,7 +514,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     {
       KTimer tm(e, DIBS_K_LIK_WEIGHTS);
       const int ny = e->d < 4 ? e->d : 4;
-      const size_t base = (((size_t)e->S * 12 + 15) & ~(size_t)15);
+      const size_t base = (((size_t)e->S * 28 + 15) & ~(size_t)15);
       const size_t mbytes = (size_t)e->S * ((e->d + ny - 1) / ny) * e->W * 8;
       const int in_lds = base + mbytes <= 64 * 1024;
       const size_t lds = base + (in_lds ? mbytes : 0);
@@ -573,7 +573,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
       const double p = c.graph_prior_edges_per_node * e->d / ((e->d * (e->d - 1)) / 2.0);
       er_c = (float)(log(p) - log(1 - p));
     }
-    hipLaunchKernelGGL(k_wtotal, dim3(e->Mloc, 4), dim3(256), 0, e->stream, e->probs, e->w_lik, e->acyc_part, e->acyc_nblk,
+    hipLaunchKernelGGL(k_wtotal, dim3(e->Mloc, (e->d * e->d + 255) / 256), dim3(256), 0, e->stream, e->probs, e->w_lik, e->acyc_part, e->acyc_nblk,
                        e->w_acyc, e->w_tot, e->d, e->Sa, alpha, beta, c.graph_prior, er_c);
     const size_t lds = ((size_t)e->d * e->d + (size_t)2 * e->d * e->k) * 4;
     allow_lds(k_zgrad, lds);

@@ -525,8 +525,9 @@ __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restr
   // block (m, y) handles the columns j = y, y + gridDim.y, ... of particle m; every block recomputes l_s / softmax
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* lp = reinterpret_cast<double*>(smem_raw);
-  float* wt = reinterpret_cast<float*>(lp + S);
-  uint64_t* mkl = reinterpret_cast<uint64_t*>(smem_raw + (((size_t)S * 12 + 15) & ~(size_t)15));
+  double* lp2 = lp + S;  // [2][S] partial sums
+  float* wt = reinterpret_cast<float*>(lp2 + 2 * S);
+  uint64_t* mkl = reinterpret_cast<uint64_t*>(smem_raw + (((size_t)S * 28 + 15) & ~(size_t)15));
   __shared__ double red[8];
   const int m = blockIdx.x, y = blockIdx.y, ny = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ncol = (d - y + ny - 1) / ny;  // columns of this block
@@ -536,12 +537,33 @@ __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restr
       const int c = e / (S * W), rest = e - c * (S * W);
       mkl[e] = mg[(size_t)(y + c * ny) * S * W + rest];
     }
-  for (int s = tid; s < S; s += 256) {
-    const double* ns = node_scores + (size_t)m * d * S + s;
-    double t = 0.0;
-    for (int j = 0; j < d; ++j) t += ns[(size_t)j * S];
-    lp[s] = t;
-    if (y == 0) logprobs[(size_t)m * S + s] = (float)t;
+  {
+    // l_s = sum_j node score: two threads per sample when they fit, loads batched eight deep; the partial sums are
+    // combined in a fixed order (deterministic)
+    const int nsplit = (2 * S <= 256) ? 2 : 1;
+    const int jw = (d + nsplit - 1) / nsplit;
+    const double* nsm = node_scores + (size_t)m * d * S;
+    for (int idx = tid; idx < nsplit * S; idx += 256) {
+      const int part = idx / S, s = idx - part * S;
+      const int j0 = part * jw, j1 = (j0 + jw < d) ? j0 + jw : d;
+      double t = 0.0;
+      int j = j0;
+      for (; j + 8 <= j1; j += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = nsm[(size_t)(j + u) * S + s];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+      }
+      for (; j < j1; ++j) t += nsm[(size_t)j * S + s];
+      lp2[part * S + s] = t;
+    }
+    __syncthreads();
+    for (int s = tid; s < S; s += 256) {
+      const double t = nsplit == 2 ? lp2[s] + lp2[S + s] : lp2[s];
+      lp[s] = t;
+      if (y == 0) logprobs[(size_t)m * S + s] = (float)t;
+    }
   }
   __syncthreads();
   double mx = -INFINITY, sm = 0.0;
@@ -576,8 +598,15 @@ __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restr
       const int w = i >> 6;
       const uint64_t bit = 1ull << (i & 63);
       const uint64_t* col = masks_in_lds ? mkl + (size_t)c * S * W : mg + (size_t)j * S * W;
-      for (int s = 0; s < S; ++s)
-        if (col[(size_t)s * W + w] & bit) acc += wt[s];
+      int s = 0;
+      for (; s + 8 <= S; s += 8) {  // eight mask words in flight; additions stay in sample order
+        uint64_t mw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mw[u] = col[(size_t)(s + u) * W + w];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (mw[u] & bit) ? wt[s + u] : 0.f;
+      }
+      for (; s < S; ++s) acc += (col[(size_t)s * W + w] & bit) ? wt[s] : 0.f;
       out = scale * alpha * (acc - probs[(size_t)m * d * d + i * d + j]);
     }
     w_lik[(size_t)m * d * d + i * d + j] = out;
@@ -774,7 +803,15 @@ __global__ __launch_bounds__(256) void k_wtotal(const float* __restrict__ probs,
   for (int e = blockIdx.y * 256 + tid; e < (int)dd; e += 256 * gridDim.y) {
     const int i = e / d, j = e - i * d;
     float ac = 0.f;
-    for (int q = 0; q < n_part; ++q) ac += acyc_part[((size_t)m * n_part + q) * dd + e];
+    int q = 0;
+    for (; q + 4 <= n_part; q += 4) {  // loads in flight together, additions in fixed order
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = acyc_part[((size_t)m * n_part + q + u) * dd + e];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ac += v[u];
+    }
+    for (; q < n_part; ++q) ac += acyc_part[((size_t)m * n_part + q) * dd + e];
     ac *= inv_sa;
     w_acyc[m * dd + e] = ac;
     float pr = 0.f;
@@ -880,7 +917,7 @@ __global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, si
 //     reference: svgd.py:194-224, 591-670, 265, 718-719; jax.example_libraries.optimizers.rmsprop
 // grid = (ceil(len / 256), ceil(Mloc / TA)), block = 256
 // ------------------------------------------------------------------------------------------------
-#define PHI_TA 8
+#define PHI_TA 4
 __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pack, size_t pack_stride, size_t val_off,
                                                     size_t grad_off, int len, const float* __restrict__ kz,
                                                     const float* __restrict__ kt, int seg_is_theta, float* __restrict__ x,
@@ -891,6 +928,7 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
   float* krep = smem + (size_t)PHI_TA * M;  // [TA][M]  kernel whose gradient gives the repulsion
   const int tid = threadIdx.x;
   const int a0 = blockIdx.y * PHI_TA;
+  const bool two = kt != nullptr;   // marginal: the repulsion kernel is the weight kernel, one table
   for (int e = tid; e < PHI_TA * M; e += 256) {
     const int a = a0 + e / M, b = e % M;
     float s = 0.f, r = 0.f;
@@ -901,7 +939,7 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
       r = seg_is_theta ? t1 : z1;
     }
     ksum[e] = s;
-    krep[e] = r;
+    if (two) krep[e] = r;
   }
   __syncthreads();
   const int i = blockIdx.x * 256 + tid;
@@ -914,6 +952,7 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
     acc[q] = 0.f;
   }
   const float c2h = 2.0f / h;
+  const float* krp = two ? krep : ksum;
   int b = 0;
   for (; b + 4 <= M; b += 4) {  // four rows in flight (the order of the additions stays b = 0, 1, 2, ...)
     float g[4], xb[4];
@@ -925,13 +964,13 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int q = 0; q < PHI_TA; ++q) acc[q] += ksum[q * M + b + u] * g[u] - c2h * krep[q * M + b + u] * (xb[u] - xa[q]);
+      for (int q = 0; q < PHI_TA; ++q) acc[q] += ksum[q * M + b + u] * g[u] - c2h * krp[q * M + b + u] * (xb[u] - xa[q]);
   }
   for (; b < M; ++b) {
     const float g = pack[(size_t)b * pack_stride + grad_off + i];
     const float xb = pack[(size_t)b * pack_stride + val_off + i];
 #pragma unroll
-    for (int q = 0; q < PHI_TA; ++q) acc[q] += ksum[q * M + b] * g - c2h * krep[q * M + b] * (xb - xa[q]);
+    for (int q = 0; q < PHI_TA; ++q) acc[q] += ksum[q * M + b] * g - c2h * krp[q * M + b] * (xb - xa[q]);
   }
 #pragma unroll
   for (int q = 0; q < PHI_TA; ++q) {
