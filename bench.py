@@ -61,17 +61,20 @@ def main():
                                                        n_observations=N_OBS)
     cfg = make_config(n_vars=D_VARS, n_particles=N_PARTICLES, n_observations=N_OBS, n_grad_mc_samples=S_MC,
                       n_acyclicity_mc_samples=SA_MC, rank=rank, n_ranks=N, device_id=local_rank)
-    stream = torch.cuda.current_stream().cuda_stream if N > 1 else None
-    eng = Engine(cfg, stream=stream)
+    # N > 1: engine kernels and the RCCL all-gather share one dedicated (non-default) torch stream
+    tstream = torch.cuda.Stream() if N > 1 else None
+    eng = Engine(cfg, stream=tstream.cuda_stream if tstream is not None else None)
     eng.set_data(data.x)
     eng.init_particles(random.PRNGKey(1))
 
     if N > 1:
         from dibs_amd.distributed import make_buffers, run_sharded
-        send, recv = make_buffers(eng, N, torch.device("cuda", local_rank), torch.float32)
+        with torch.cuda.stream(tstream):
+            send, recv = make_buffers(eng, N, torch.device("cuda", local_rank), torch.float32)
 
         def run(t0, n):
-            run_sharded(eng, t0, n, send, recv)   # phase A -> one all-gather (RCCL) -> phase B, per step
+            with torch.cuda.stream(tstream):
+                run_sharded(eng, t0, n, send, recv)   # phase A -> one all-gather (RCCL) -> phase B, per step
     else:
         def run(t0, n):
             eng.run(t0, n)

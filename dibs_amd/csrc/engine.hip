@@ -171,7 +171,9 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
     int best = 1;
     long best_cost = -1;
     for (int cpb = 1; cpb <= e->Sa; ++cpb) {
-      const long nblk = (long)((e->Sa + cpb - 1) / cpb) * e->Mloc;
+      // (sized for the GLOBAL particle count: the grouping of the Sa chains into partial sums must not depend on how the
+      //  particles are sharded, or results would differ between rank counts in the last float bit)
+      const long nblk = (long)((e->Sa + cpb - 1) / cpb) * e->M;
       const long cost = ((nblk + slots - 1) / slots) * cpb;
       if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cpb; }
     }

@@ -14,6 +14,13 @@ Engine (dibs_amd.engine) in production, the oracle adapter in the CPU gloo test.
 import numpy as np
 
 
+def make_stream():
+    """A dedicated (non-default) torch stream: engine kernels and the collective must share ONE stream so that phase A ->
+    all-gather -> phase B are ordered.  torch's default stream has handle 0, which the engine cannot adopt."""
+    import torch
+    return torch.cuda.Stream()
+
+
 def make_buffers(engine, world_size, device, dtype):
     import torch
     n = engine.gather_elems_per_rank()
@@ -46,18 +53,20 @@ def sample_sharded(dibs, *, key, n_particles, steps, n_dim_particles=None, callb
         raise ValueError("n_particles must be divisible by the number of ranks")
     n_dim = n_dim_particles or dibs.n_vars
     dev = torch.cuda.current_device()
-    eng = dibs._new_engine(n_particles, n_dim, rank=rank, n_ranks=world, device_id=dev,
-                           stream=torch.cuda.current_stream().cuda_stream)
+    stream = make_stream()
+    eng = dibs._new_engine(n_particles, n_dim, rank=rank, n_ranks=world, device_id=dev, stream=stream.cuda_stream)
     try:
         eng.init_particles(random.as_key(key))
         if dibs.latent_prior_std is None:
             dibs.latent_prior_std = float(np.float32(1.0) / np.sqrt(np.float32(n_dim)))
-        send, recv = make_buffers(eng, world, torch.device("cuda", dev), torch.float32)
         callback_every = callback_every or steps
-        for t in (range(0, steps, callback_every) if steps else range(0)):
-            run_sharded(eng, t, callback_every, send, recv, group)
-            if callback:
-                callback(dibs=dibs, t=t + callback_every, engine=eng)
+        with torch.cuda.stream(stream):
+            send, recv = make_buffers(eng, world, torch.device("cuda", dev), torch.float32)
+            for t in (range(0, steps, callback_every) if steps else range(0)):
+                run_sharded(eng, t, callback_every, send, recv, group)
+                if callback:
+                    callback(dibs=dibs, t=t + callback_every, engine=eng)
+        stream.synchronize()
         eng.sync()
         st = eng.get_state()
         z = torch.from_numpy(st["z"]).cuda()

@@ -17,6 +17,10 @@ class Engine:
         self.lib = _lib.load()
         self.cfg = cfg
         self._h = C.c_void_p()
+        if stream is not None and int(stream) == 0:
+            # handle 0 is HIP's legacy default stream; the C ABI reads NULL as "create your own stream", which would leave
+            # the engine unordered with the caller's work (torch.cuda.current_stream() is 0 unless a Stream is active)
+            raise ValueError("pass the handle of a non-default stream (e.g. torch.cuda.Stream().cuda_stream) or None")
         _lib.check(self.lib.dibs_engine_create(C.byref(cfg), C.c_void_p(stream) if stream else None, C.byref(self._h)))
         self.M, self.d, self.k = cfg.n_particles, cfg.n_vars, cfg.n_dim
         self.Mloc = cfg.n_particles // cfg.n_ranks

@@ -198,7 +198,7 @@ def test_headline_size_properties():
     grads = []
     for r in range(2):
         c2 = make_config(n_vars=50, n_particles=128, n_observations=100, rank=r, n_ranks=2)
-        e2 = Engine(c2)
+        e2 = Engine(c2)  # own stream; e2.sync() below orders the read-back
         e2.set_data(data.x)
         e2.init_particles(prng.PRNGKey(1))
         n = e2.gather_elems_per_rank()
@@ -402,3 +402,50 @@ def test_densenn_sample_and_scoring(c_oracle64):
     assert rel_err(got, ref) < 2e-5
     mix = dibs.get_mixture(g, theta)
     assert abs(np.exp(mix.logp).sum() - 1) < 1e-6
+
+
+@pytest.mark.parametrize("joint", [False, True])
+def test_sharded_engines_match_single_rank(joint):
+    """The N > 1 path of bench.py / dibs_amd.distributed on ONE GPU: engines for rank 0..R-1 of R in one process, the
+    all-gather replaced by a device-side concat.  Must be bit-identical to the single-rank engine (PRNG rows are global,
+    phi sums over b in global order)."""
+    import torch
+    from dibs_amd.engine import Engine
+    d, M, R, steps = 20, 16, 4, 5
+    data, _, _ = make_data(d, seed=3, joint=joint)
+    kw = dict(joint=True, likelihood="lingauss") if joint else {}
+    cfg1 = make_config(n_vars=d, n_particles=M, n_observations=100, n_grad_mc_samples=32, n_acyclicity_mc_samples=8, **kw)
+    ref = _engine(cfg1, data.x)
+    ref.init_particles(prng.PRNGKey(8))
+    ref.run(0, steps)
+    sref = ref.get_state()
+    ref.close()
+    tstream = torch.cuda.Stream()  # a real (non-default) stream shared by the engines and the "collective"
+    stream = tstream.cuda_stream
+    engs = []
+    for r in range(R):
+        c = make_config(n_vars=d, n_particles=M, n_observations=100, n_grad_mc_samples=32, n_acyclicity_mc_samples=8,
+                        rank=r, n_ranks=R, **kw)
+        e = Engine(c, stream=stream)
+        e.set_data(data.x)
+        e.init_particles(prng.PRNGKey(8))
+        engs.append(e)
+    n = engs[0].gather_elems_per_rank()
+    with torch.cuda.stream(tstream):
+        sends = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(R)]
+        recv = torch.zeros(n * R, dtype=torch.float32, device="cuda")
+        for t in range(steps):
+            for r in range(R):
+                engs[r].step_local(t, sends[r].data_ptr())
+            torch.cat(sends, out=recv)  # stands in for dist.all_gather_into_tensor(recv, send)
+            for r in range(R):
+                engs[r].step_update(t, recv.data_ptr())
+    torch.cuda.synchronize()
+    states = [e.get_state() for e in engs]
+    z = np.concatenate([s["z"] for s in states])
+    assert np.array_equal(z, sref["z"]), "sharded device run must be bit-identical to the single-rank run"
+    assert all((s["key"] == sref["key"]).all() for s in states)
+    if joint:
+        assert np.array_equal(np.concatenate([s["theta"] for s in states]), sref["theta"])
+    for e in engs:
+        e.close()
