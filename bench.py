@@ -120,22 +120,34 @@ def main():
         dom = max(timers, key=lambda k_: timers[k_][0])
         dom_ms, dom_n = timers[dom]
         avg_s = dom_ms / dom_n * 1e-3
-        dense_bge = N_PARTICLES * S_MC * D_VARS * 2 * D_VARS ** 3 / 3.0
-        acyc_flops = N_PARTICLES * SA_MC * binary_powering_matmuls(D_VARS - 1) * 2 * D_VARS ** 3
-        per_launch = {"bge_nodes": bge_flops / max(dom_n, 1) if dom == "bge_nodes" else None, "acyc": acyc_flops}
-        flops = per_launch.get(dom)
-        roof = {"kernel": dom, "bound": "mfma", "pipe": "valu_f32" if dom == "bge_nodes" else "mfma_f32",
-                "avg_launch_us": avg_s * 1e6, "launches": dom_n, "share_of_step": dom_ms / total_ms,
-                "unit": "TFLOP/s", "peak": PEAK_F32_TFLOPS, "traffic": None}
-        if flops:
-            roof["achieved"] = flops / avg_s / 1e12
-            roof["frac"] = roof["achieved"] / PEAK_F32_TFLOPS
-            roof["flops_per_launch"] = flops
-            if dom == "bge_nodes":
-                roof["flops_model"] = "executed: sum over sampled parent sets of (l+1)^3/3 (compact Cholesky)"
-                roof["dense_equivalent_tflops"] = dense_bge / avg_s / 1e12  # SURVEY 8(d) count: masked d x d LU, twice
+        # SURVEY.md 8(d) algorithmic flop counts per step (= per launch: each kernel is launched once per step)
+        dense_bge = N_PARTICLES * S_MC * D_VARS * 2 * D_VARS ** 3 / 3.0          # F_lik(BGe), dense-Cholesky count
+        acyc_flops = N_PARTICLES * SA_MC * binary_powering_matmuls(D_VARS - 1) * 2 * D_VARS ** 3   # F_acyc
+        rocprof_names = {"acyc": "k_acyc<4>", "bge_nodes": "k_bge_nodes<4, true>", "bge_big": "k_bge_big<16|32|64, true> (3 launches)"}
+        roof = {"kernel": dom, "rocprof_kernel": rocprof_names.get(dom, "k_" + dom), "bound": "mfma",
+                "pipe": "mfma_f32" if dom == "acyc" else "valu_f32", "avg_launch_us": avg_s * 1e6, "launches": dom_n,
+                "share_of_step": dom_ms / total_ms, "unit": "TFLOP/s", "peak": PEAK_F32_TFLOPS, "traffic": None}
+        if dom == "acyc":
+            roof["flops_per_launch"] = acyc_flops
+            roof["flops_model"] = "M*Sa*c(d-1)*2*d^3, c(49)=7 matmuls of binary powering (SURVEY 8(d) F_acyc)"
+            roof["achieved"] = acyc_flops / avg_s / 1e12
+        elif dom in ("bge_nodes", "bge_big"):
+            # the BGe kernels skip the dense count by factorising only R[pa U j]; both figures are given
+            roof["flops_per_launch"] = dense_bge
+            roof["flops_model"] = ("M*S*d*2*d^3/3 dense count (SURVEY 8(d) F_lik) over the whole BGe group; the kernels execute "
+                                   "sum (l+1)^3/3 instead, see executed_tflops")
+            grp_s = (timers["bge_nodes"][0] + timers["bge_big"][0]) / dom_n * 1e-3
+            roof["achieved"] = dense_bge / grp_s / 1e12
+            roof["executed_tflops"] = bge_flops / max(dom_n, 1) / grp_s / 1e12
         else:
-            roof["achieved"], roof["frac"] = None, None
+            roof["achieved"] = None
+        roof["frac"] = roof["achieved"] / PEAK_F32_TFLOPS if roof["achieved"] else None
+        pmc = os.path.join(ROOT, "profiles", "round1_pmc_hbm.json")   # separate rocprofv3 --pmc passes of this command
+        if os.path.exists(pmc):
+            rec = json.load(open(pmc)).get(dom)
+            if rec:
+                roof["traffic"] = rec["hbm_bytes_per_launch"]
+                roof["traffic_source"] = "profiles/round1_pmc_hbm.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes)"
         out["roofline"] = roof
         bytes_step = 16.0 * N_PARTICLES * (2 * D_VARS * D_VARS)
         out["hbm_algorithmic"] = {"bytes_per_step": bytes_step, "achieved_GBps": bytes_step * steps_per_s / 1e9,

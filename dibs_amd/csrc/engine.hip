@@ -123,17 +123,15 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
     if (!(p > 0.0 && p < 1.0)) return fail("Erdos-Renyi prior: edge probability must be in (0, 1)");
   }
   {
-    const size_t D4 = (size_t)c.n_vars * c.n_dim * 2 * 4;
-    if (D4 > LDS_LIMIT - 1024) return fail("n_vars * n_dim too large for the kernel-matrix LDS tile");
     if ((size_t)2 * 8 * c.n_particles * 4 > LDS_LIMIT) return fail("n_particles too large (kernel rows must fit in LDS)");
     if (((size_t)c.n_vars * c.n_vars + (size_t)2 * c.n_vars * c.n_dim) * 4 > LDS_LIMIT) return fail("n_vars * n_dim too large");
   }
   {  // LDS budgets of the likelihood kernels (x, theta / graph, per-sample operand and residuals are LDS-resident)
     const int nt = (c.n_vars + 15) / 16;
     if (c.likelihood == DIBS_LIK_LINGAUSS && lin_lds_bytes(c.n_vars, c.n_observations, nt, true) > LDS_LIMIT)
-      return fail("LinearGaussian: n_vars / n_observations too large for the LDS-resident kernels (n_vars <= 80 at 100 observations)");
+      return fail("LinearGaussian: n_vars / n_observations too large for the LDS-resident kernels (n_vars <= 112 at 100 observations)");
     if (c.likelihood == DIBS_LIK_DENSENN && nn_lds_bytes(c.n_vars, c.n_observations, nt, true) > LDS_LIMIT)
-      return fail("DenseNonlinearGaussian: n_vars / n_observations too large for the LDS-resident kernels (n_vars <= 64 at 100 observations)");
+      return fail("DenseNonlinearGaussian: n_vars / n_observations too large for the LDS-resident kernels (n_vars <= 112 at 100 observations)");
   }
   int ndev = 0;
   HIP_OK(hipGetDeviceCount(&ndev));
@@ -496,11 +494,11 @@ static int step_local(dibs_engine* e, int t, float* pack) {
                        e->dpad, e->ldk);
   }
   if (c.likelihood == DIBS_LIK_BGE) {
+    BgeParams bp{e->R, e->gam, e->Nj, e->alpha_lambd, e->n_mats};
+    unsigned long long* cnt = e->profiling ? e->counters : (unsigned long long*)nullptr;
+    hipMemsetAsync(e->bq.counts, 0, 4 * sizeof(unsigned int), e->stream);
     {
       KTimer tm(e, DIBS_K_BGE_NODES);
-      BgeParams bp{e->R, e->gam, e->Nj, e->alpha_lambd, e->n_mats};
-      unsigned long long* cnt = e->profiling ? e->counters : (unsigned long long*)nullptr;
-      hipMemsetAsync(e->bq.counts, 0, 4 * sizeof(unsigned int), e->stream);
       const size_t lds4 = bge_lds_bytes(e->d, e->S, e->W, 4), lds1 = bge_lds_bytes(e->d, e->S, e->W, 1);
       if (e->n_mats == 1 && lds4 <= 80 * 1024) {
         allow_lds(k_bge_nodes<4, true>, lds4);
@@ -511,6 +509,9 @@ static int step_local(dibs_engine* e, int t, float* pack) {
         hipLaunchKernelGGL((k_bge_nodes<1, true>), dim3(e->d, e->Mloc), dim3(64), lds1, e->stream, e->thr, e->masks,
                            e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L, cnt, e->bq);
       }
+    }
+    {
+      KTimer tm(e, DIBS_K_BGE_BIG);
       launch_bge_big(e, bp, e->masks, e->node_scores, e->bq, e->S, cnt);
     }
     {
@@ -569,7 +570,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     }
   }
   {
-    KTimer tm(e, DIBS_K_ZGRAD);
+    KTimer tm(e, DIBS_K_WTOTAL);
     float er_c = 0.f;
     if (c.graph_prior == DIBS_PRIOR_ER) {
       const double p = c.graph_prior_edges_per_node * e->d / ((e->d * (e->d - 1)) / 2.0);
@@ -577,6 +578,9 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     }
     hipLaunchKernelGGL(k_wtotal, dim3(e->Mloc, (e->d * e->d + 255) / 256), dim3(256), 0, e->stream, e->probs, e->w_lik, e->acyc_part, e->acyc_nblk,
                        e->w_acyc, e->w_tot, e->d, e->Sa, alpha, beta, c.graph_prior, er_c);
+  }
+  {
+    KTimer tm(e, DIBS_K_ZGRAD);
     const size_t lds = ((size_t)e->d * e->d + (size_t)2 * e->d * e->k) * 4;
     allow_lds(k_zgrad, lds);
     const int zs = e->d < 4 ? e->d : 4;
@@ -593,12 +597,13 @@ static int step_update(dibs_engine* e, int t, const float* pack) {
   const dibs_config& c = e->cfg;
   {
     KTimer tm(e, DIBS_K_KMAT);
-    allow_lds(k_kmat, (size_t)(e->D > e->P ? e->D : e->P) * 4);
+    auto kmat_lds = [](size_t len) { return (size_t)(((len < KMAT_CH ? len : (size_t)KMAT_CH) + 3) & ~(size_t)3) * 4; };
+    allow_lds(k_kmat, kmat_lds(e->D > e->P ? e->D : e->P));
     const dim3 kg(e->Mloc, (e->M + KMAT_BT - 1) / KMAT_BT);
-    hipLaunchKernelGGL(k_kmat, kg, dim3(256), (size_t)((e->D + 3) & ~3) * 4, e->stream, pack, (size_t)e->E, (size_t)0,
+    hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->D), e->stream, pack, (size_t)e->E, (size_t)0,
                        (int)e->D, e->kz, e->m0, e->M, (float)c.scale_latent, (float)c.h_latent);
     if (c.joint)
-      hipLaunchKernelGGL(k_kmat, kg, dim3(256), (size_t)((e->P + 3) & ~3) * 4, e->stream, pack, (size_t)e->E,
+      hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->P), e->stream, pack, (size_t)e->E,
                          (size_t)(2 * e->D), (int)e->P, e->kt, e->m0, e->M, (float)c.scale_theta, (float)c.h_theta);
   }
   {

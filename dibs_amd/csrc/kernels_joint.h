@@ -54,10 +54,10 @@ __host__ __device__ inline LinGeom lin_geom(int d, int N, int NT) {
   g.ldw = dp + 2;
   return g;
 }
-// LDS: X[np][ldx] | TH[d*d] | WG[max(kp, np)][ldw]  (WG doubles as the residual matrix in the gradient kernel)
+// LDS: X[np][ldx] | WG[kp][ldw] | (gradient kernel) RS[np][ldw]; theta is read from global (L2-resident, d*d floats per particle)
 __host__ __device__ inline size_t lin_lds_bytes(int d, int N, int NT, bool with_res) {
   const LinGeom g = lin_geom(d, N, NT);
-  size_t f = (size_t)g.np * g.ldx + (size_t)d * d + (size_t)g.kp * g.ldw;
+  size_t f = (size_t)g.np * g.ldx + (size_t)g.kp * g.ldw;
   if (with_res) f += (size_t)g.np * g.ldw;
   return ((f * 4 + 15) & ~(size_t)15) + 64 * 8;
 }
@@ -88,18 +88,16 @@ __device__ __forceinline__ Key2 lin_mode_key(int mode, Key2 carry, int M_global,
 }
 
 template <int NT>
-__device__ __forceinline__ void lin_load_common(float* X, float* TH, const float* __restrict__ x, const float* __restrict__ theta_m,
-                                                const LinGeom g, int tid) {
+__device__ __forceinline__ void lin_load_common(float* X, const float* __restrict__ x, const LinGeom g, int tid) {
   for (int e = tid; e < g.np * g.ldx; e += 256) {
     const int n = e / g.ldx, c = e - n * g.ldx;
     X[e] = (n < g.N && c < g.d) ? x[(size_t)n * g.d + c] : 0.f;
   }
-  for (int e = tid; e < g.d * g.d; e += 256) TH[e] = theta_m[e];
 }
 
 // WG = g o theta for sample s (zero padded); returns this thread's share of sum_ij g_ij logN(theta_ij)
 template <int NT>
-__device__ __forceinline__ float lin_build_wg(float* WG, const float* TH, int mode, Key2 key, uint64_t nbits, int s,
+__device__ __forceinline__ float lin_build_wg(float* WG, const float* __restrict__ TH, int mode, Key2 key, uint64_t nbits, int s,
                                               const uint32_t* thr_m, const float* sc_m, float alpha, float tau, int layout,
                                               int tiny, float mu, float sig, const LinGeom g, int tid) {
   float prior = 0.f;
@@ -158,12 +156,12 @@ __global__ __launch_bounds__(256) void k_lin_logprobs(const float* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const LinGeom g = lin_geom(d, N, NT);
   float* X = smem;
-  float* TH = X + (size_t)g.np * g.ldx;
-  float* WG = TH + (size_t)d * d;
-  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)d * d + (size_t)g.kp * g.ldw) + 3) & ~(size_t)3));
+  float* WG = X + (size_t)g.np * g.ldx;
+  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)g.kp * g.ldw) + 3) & ~(size_t)3));
   const int m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t dd = (size_t)d * d;
-  lin_load_common<NT>(X, TH, x, theta + (size_t)m * dd, g, tid);
+  const float* __restrict__ TH = theta + (size_t)m * dd;
+  lin_load_common<NT>(X, x, g, tid);
   const Key2 key = lin_mode_key(mode, carry, M_global, m0 + m, layout);
   const uint64_t nbits = (uint64_t)S * dd;
   const float inv2 = 0.5f / obs_noise;
@@ -207,13 +205,13 @@ __global__ __launch_bounds__(256) void k_lin_grad(const float* __restrict__ x, c
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const LinGeom g = lin_geom(d, N, NT);
   float* X = smem;
-  float* TH = X + (size_t)g.np * g.ldx;
-  float* WG = TH + (size_t)d * d;
+  float* WG = X + (size_t)g.np * g.ldx;
   float* RS = WG + (size_t)g.kp * g.ldw;  // residuals [np][ldw]
-  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)d * d + (size_t)g.kp * g.ldw + (size_t)g.np * g.ldw) + 3) & ~(size_t)3));
+  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)g.kp * g.ldw + (size_t)g.np * g.ldw) + 3) & ~(size_t)3));
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t dd = (size_t)d * d;
-  lin_load_common<NT>(X, TH, x, theta + (size_t)m * dd, g, tid);
+  const float* __restrict__ TH = theta + (size_t)m * dd;
+  lin_load_common<NT>(X, x, g, tid);
   for (int e = tid; e < g.np * g.ldw; e += 256) RS[e] = 0.f;
   const Key2 key = lin_mode_key(mode, carry, M_global, m0 + m, layout);
   const uint64_t nbits = (uint64_t)S * dd;

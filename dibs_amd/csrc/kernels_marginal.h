@@ -871,41 +871,58 @@ __global__ __launch_bounds__(256) void k_zgrad(const float* __restrict__ z, cons
 // grid = Mloc, block = 256; dynamic LDS = len * 4
 // ------------------------------------------------------------------------------------------------
 #define KMAT_BT 16
+#define KMAT_CH 32768  // floats of z_a staged in LDS at a time (128 KiB); longer vectors (DenseNN theta at d = 100) go in chunks
 __global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, size_t pack_stride, size_t seg_off, int len,
                                               float* __restrict__ kout, int m0, int M, float scale, float h) {
   // block (a, bt): particle a (local) against b = bt * KMAT_BT .. +KMAT_BT-1; wave w takes b = b0 + w, b0 + w + 4, ...
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int a = blockIdx.x, b0 = blockIdx.y * KMAT_BT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* za = pack + (size_t)(m0 + a) * pack_stride + seg_off;
-  const int len4 = len >> 2;
-  for (int e = tid; e < len4; e += 256) reinterpret_cast<float4*>(smem)[e] = reinterpret_cast<const float4*>(za)[e];
-  for (int e = (len4 << 2) + tid; e < len; e += 256) smem[e] = za[e];
-  __syncthreads();
-  for (int b = b0 + wave; b < b0 + KMAT_BT && b < M; b += 4) {
-    const float* zb = pack + (size_t)b * pack_stride + seg_off;
-    const float4* zb4 = reinterpret_cast<const float4*>(zb);
-    const float4* za4 = reinterpret_cast<const float4*>(smem);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int e = lane;
-    for (; e + 192 < len4; e += 256) {
-      const float4 q0 = zb4[e], q1 = zb4[e + 64], q2 = zb4[e + 128], q3 = zb4[e + 192];
-      const float4 p0 = za4[e], p1 = za4[e + 64], p2 = za4[e + 128], p3 = za4[e + 192];
-      float t;
-      t = p0.x - q0.x; s0 = fmaf(t, t, s0); t = p0.y - q0.y; s0 = fmaf(t, t, s0); t = p0.z - q0.z; s0 = fmaf(t, t, s0); t = p0.w - q0.w; s0 = fmaf(t, t, s0);
-      t = p1.x - q1.x; s1 = fmaf(t, t, s1); t = p1.y - q1.y; s1 = fmaf(t, t, s1); t = p1.z - q1.z; s1 = fmaf(t, t, s1); t = p1.w - q1.w; s1 = fmaf(t, t, s1);
-      t = p2.x - q2.x; s2 = fmaf(t, t, s2); t = p2.y - q2.y; s2 = fmaf(t, t, s2); t = p2.z - q2.z; s2 = fmaf(t, t, s2); t = p2.w - q2.w; s2 = fmaf(t, t, s2);
-      t = p3.x - q3.x; s3 = fmaf(t, t, s3); t = p3.y - q3.y; s3 = fmaf(t, t, s3); t = p3.z - q3.z; s3 = fmaf(t, t, s3); t = p3.w - q3.w; s3 = fmaf(t, t, s3);
+  double acc[KMAT_BT / 4];
+#pragma unroll
+  for (int q = 0; q < KMAT_BT / 4; ++q) acc[q] = 0.0;
+  for (int c0 = 0; c0 < len; c0 += KMAT_CH) {
+    const int clen = len - c0 < KMAT_CH ? len - c0 : KMAT_CH;
+    const int len4 = clen >> 2;
+    if (c0) __syncthreads();
+    for (int e = tid; e < len4; e += 256) reinterpret_cast<float4*>(smem)[e] = reinterpret_cast<const float4*>(za + c0)[e];
+    for (int e = (len4 << 2) + tid; e < clen; e += 256) smem[e] = za[c0 + e];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < KMAT_BT / 4; ++q) {
+      const int b = b0 + wave + 4 * q;
+      if (b >= M) continue;
+      const float* zb = pack + (size_t)b * pack_stride + seg_off + c0;
+      const float4* zb4 = reinterpret_cast<const float4*>(zb);
+      const float4* za4 = reinterpret_cast<const float4*>(smem);
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int e = lane;
+      for (; e + 192 < len4; e += 256) {
+        const float4 q0 = zb4[e], q1 = zb4[e + 64], q2 = zb4[e + 128], q3 = zb4[e + 192];
+        const float4 p0 = za4[e], p1 = za4[e + 64], p2 = za4[e + 128], p3 = za4[e + 192];
+        float t;
+        t = p0.x - q0.x; s0 = fmaf(t, t, s0); t = p0.y - q0.y; s0 = fmaf(t, t, s0); t = p0.z - q0.z; s0 = fmaf(t, t, s0); t = p0.w - q0.w; s0 = fmaf(t, t, s0);
+        t = p1.x - q1.x; s1 = fmaf(t, t, s1); t = p1.y - q1.y; s1 = fmaf(t, t, s1); t = p1.z - q1.z; s1 = fmaf(t, t, s1); t = p1.w - q1.w; s1 = fmaf(t, t, s1);
+        t = p2.x - q2.x; s2 = fmaf(t, t, s2); t = p2.y - q2.y; s2 = fmaf(t, t, s2); t = p2.z - q2.z; s2 = fmaf(t, t, s2); t = p2.w - q2.w; s2 = fmaf(t, t, s2);
+        t = p3.x - q3.x; s3 = fmaf(t, t, s3); t = p3.y - q3.y; s3 = fmaf(t, t, s3); t = p3.z - q3.z; s3 = fmaf(t, t, s3); t = p3.w - q3.w; s3 = fmaf(t, t, s3);
+      }
+      for (; e < len4; e += 64) {
+        const float4 q0 = zb4[e], p0 = za4[e];
+        float t;
+        t = p0.x - q0.x; s0 = fmaf(t, t, s0); t = p0.y - q0.y; s0 = fmaf(t, t, s0); t = p0.z - q0.z; s0 = fmaf(t, t, s0); t = p0.w - q0.w; s0 = fmaf(t, t, s0);
+      }
+      for (int e1 = (len4 << 2) + lane; e1 < clen; e1 += 64) {
+        const float t = smem[e1] - zb[e1];
+        s1 = fmaf(t, t, s1);
+      }
+      acc[q] += (double)s0 + (double)s1 + (double)s2 + (double)s3;
     }
-    for (; e < len4; e += 64) {
-      const float4 q0 = zb4[e], p0 = za4[e];
-      float t;
-      t = p0.x - q0.x; s0 = fmaf(t, t, s0); t = p0.y - q0.y; s0 = fmaf(t, t, s0); t = p0.z - q0.z; s0 = fmaf(t, t, s0); t = p0.w - q0.w; s0 = fmaf(t, t, s0);
-    }
-    for (int e1 = (len4 << 2) + lane; e1 < len; e1 += 64) {
-      const float t = smem[e1] - zb[e1];
-      s1 = fmaf(t, t, s1);
-    }
-    const double tot = wave_sum_d((double)s0 + (double)s1 + (double)s2 + (double)s3);
+  }
+#pragma unroll
+  for (int q = 0; q < KMAT_BT / 4; ++q) {
+    const int b = b0 + wave + 4 * q;
+    if (b >= M) continue;
+    const double tot = wave_sum_d(acc[q]);
     if (lane == 0) kout[(size_t)a * M + b] = (float)((double)scale * exp(-tot / (double)h));
   }
 }

@@ -46,11 +46,14 @@ __host__ __device__ inline NNOff nn_offsets(int d, int H, int bias) {
   return o;
 }
 
-// LDS (floats): X[np][ldx] | GS[d*d] | TW[kp][ldw] | (grad kernel) RS[np][ldw] | RS2[np][ldw] | red
+// LDS (floats): X[np][ldx] | GS[d*d] | TR[max(kp, np)][ldw] | (grad kernel) CS[4][ldw] | red
+// TR holds the forward operand T_h (rows < kp) and, after a barrier, the backward operand dpre_h (rows < np): the two are
+// never live together, which is what lets d = 100 / N = 100 fit in 160 KiB.
+__host__ __device__ inline int nn_tr_rows(const LinGeom g) { return g.kp > g.np ? g.kp : g.np; }
 __host__ __device__ inline size_t nn_lds_bytes(int d, int N, int NT, bool grad) {
   const LinGeom g = lin_geom(d, N, NT);
-  size_t f = (size_t)g.np * g.ldx + (size_t)d * d + (size_t)g.kp * g.ldw;
-  if (grad) f += (size_t)2 * g.np * g.ldw;
+  size_t f = (size_t)g.np * g.ldx + (size_t)d * d + (size_t)nn_tr_rows(g) * g.ldw;
+  if (grad) f += (size_t)4 * g.ldw;
   return ((f * 4 + 15) & ~(size_t)15) + 64 * 8;
 }
 
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void k_nn_logprobs(const float* __restrict__ x
   float* X = smem;
   float* GS = X + (size_t)g.np * g.ldx;
   float* TW = GS + (size_t)d * d;
-  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)d * d + (size_t)g.kp * g.ldw) + 3) & ~(size_t)3));
+  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)d * d + (size_t)nn_tr_rows(g) * g.ldw) + 3) & ~(size_t)3));
   const int m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t dd = (size_t)d * d;
   const int H = np_.H;
@@ -215,10 +218,10 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
   constexpr int NU = 2, NUD = (NT + 3) / 4;
   float* X = smem;
   float* GS = X + (size_t)g.np * g.ldx;
-  float* TW = GS + (size_t)d * d;
-  float* RS = TW + (size_t)g.kp * g.ldw;   // dpre_h  [np][ldw]
-  float* RS2 = RS + (size_t)g.np * g.ldw;  // dmean, then dmean * act(pre_h)
-  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)d * d + (size_t)g.kp * g.ldw + (size_t)2 * g.np * g.ldw) + 3) & ~(size_t)3));
+  float* TW = GS + (size_t)d * d;                  // T_h [kp][ldw] (forward operand) ...
+  float* RS = TW;                                  // ... and dpre_h [np][ldw] (backward operand), same storage
+  float* CS = TW + (size_t)nn_tr_rows(g) * g.ldw;  // per-wave column sums [4][ldw]
+  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)d * d + (size_t)nn_tr_rows(g) * g.ldw + (size_t)4 * g.ldw) + 3) & ~(size_t)3));
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t dd = (size_t)d * d;
   const int H = np_.H;
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
     const int n = e / g.ldx, c = e - n * g.ldx;
     X[e] = (n < N && c < d) ? x[(size_t)n * d + c] : 0.f;
   }
-  for (int e = tid; e < 2 * g.np * g.ldw; e += 256) RS[e] = 0.f;
+  for (int e = tid; e < 4 * g.ldw; e += 256) CS[e] = 0.f;
   // outputs start at zero (theta mode: P entries; z modes: d*d)
   const size_t n_out = mode == LIN_MODE_THETA ? P : dd;
   for (size_t e = tid; e < n_out; e += 256) om[e] = 0.f;
@@ -299,11 +302,12 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
           }
         }
     }
-    // dmean = (1 - mask) (x - mean) / obs_noise  (kept in registers, C layout)
+    // dmean = (1 - mask) (x - mean) / obs_noise  (kept in registers, C layout; zero on padding rows / columns)
 #pragma unroll
-    for (int u = 0; u < NU; ++u)
+    for (int tj = 0; tj < NT; ++tj) {
+      float t = 0.f;
 #pragma unroll
-      for (int tj = 0; tj < NT; ++tj)
+      for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int n = (wave + 4 * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
@@ -311,15 +315,16 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
           if (n < N && j < d && wave + 4 * u < nrt && !(any_mask && mask[(size_t)n * d + j]))
             dm = (X[n * g.ldx + j] - macc[u][tj][r] - (np_.bias ? th_m[off.b2 + j] : 0.f)) * inv_on;
           macc[u][tj][r] = dm;
-          if (n < g.np && j < g.ldw && wave + 4 * u < nrt) RS2[n * g.ldw + j] = dm;
+          t += dm;
         }
+      t += __shfl_xor(t, 16);
+      t += __shfl_xor(t, 32);
+      if (lane < 16) CS[wave * g.ldw + tj * 16 + lane] = t;
+    }
     __syncthreads();
     if (mode == LIN_MODE_THETA && np_.bias)
-      for (int j = tid; j < d; j += 256) {  // d/db2_j = sum_n dmean_nj
-        float t = 0.f;
-        for (int n = 0; n < N; ++n) t += RS2[n * g.ldw + j];
-        om[off.b2 + j] += w * t;
-      }
+      for (int j = tid; j < d; j += 256)  // d/db2_j = sum_n dmean_nj
+        om[off.b2 + j] += w * (CS[j] + CS[g.ldw + j] + CS[2 * g.ldw + j] + CS[3 * g.ldw + j]);
     // ---- backward, one hidden unit at a time ----
     for (int h = 0; h < H; ++h) {
       __syncthreads();
@@ -327,13 +332,15 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
       __syncthreads();
       f32x4 acc[NU][NT];
       nn_gemm_x_tw<NT, NU>(X, TW, g, lane, wave, acc);
+      __syncthreads();  // every wave is done reading T_h: its storage now takes dpre_h
 #pragma unroll
-      for (int u = 0; u < NU; ++u)
+      for (int tj = 0; tj < NT; ++tj) {
+        const int j = tj * 16 + (lane & 15);
+        const float b1 = (np_.bias && j < d) ? th_m[off.b1 + (size_t)j * H + h] : 0.f;
+        const float w2 = j < d ? th_m[off.w2 + (size_t)j * H + h] : 0.f;
+        float t2 = 0.f;
 #pragma unroll
-        for (int tj = 0; tj < NT; ++tj) {
-          const int j = tj * 16 + (lane & 15);
-          const float b1 = (np_.bias && j < d) ? th_m[off.b1 + (size_t)j * H + h] : 0.f;
-          const float w2 = j < d ? th_m[off.w2 + (size_t)j * H + h] : 0.f;
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int n = (wave + 4 * u) * 16 + (lane >> 4) * 4 + r;
@@ -342,20 +349,20 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
               const float hv = nn_act(np_.act, pre);
               const float dm = macc[u][tj][r];
               RS[n * g.ldw + j] = dm * w2 * nn_dact(np_.act, pre, hv);  // dpre
-              RS2[n * g.ldw + j] = dm * hv;                              // for d/dW2
+              t2 += dm * hv;                                              // for d/dW2
             }
           }
-        }
+        t2 += __shfl_xor(t2, 16);
+        t2 += __shfl_xor(t2, 32);
+        if (lane < 16) CS[wave * g.ldw + j] = t2;
+      }
       __syncthreads();
       if (mode == LIN_MODE_THETA)
         for (int j = tid; j < d; j += 256) {
-          float t1 = 0.f, t2 = 0.f;
-          for (int n = 0; n < N; ++n) {
-            t1 += RS[n * g.ldw + j];
-            t2 += RS2[n * g.ldw + j];
-          }
+          float t1 = 0.f;
+          for (int n = 0; n < N; ++n) t1 += RS[n * g.ldw + j];
           if (np_.bias) om[off.b1 + (size_t)j * H + h] += w * t1;
-          om[off.w2 + (size_t)j * H + h] += w * t2;
+          om[off.w2 + (size_t)j * H + h] += w * (CS[j] + CS[g.ldw + j] + CS[2 * g.ldw + j] + CS[3 * g.ldw + j]);
         }
       // xtr[a][j] = sum_n x[n][a] dpre[n][j]  (d/dT_h)
 #pragma unroll

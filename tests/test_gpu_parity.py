@@ -240,6 +240,8 @@ def test_sample_api_contract():
     (5, 3, 16, 4, "score", "sf", True, (1, 3)),
     (20, 6, 64, 16, "reparam", "er", True, (1, 4)),
     (50, 4, 128, 32, "reparam", "er", False, (2,)),
+    (100, 3, 32, 8, "reparam", "er", True, (2,)),     # d of BASELINE config 5: largest LDS footprint of the LinG kernels
+    (112, 2, 16, 4, "score", "sf", False, (1,)),      # engine maximum
 ])
 def test_joint_lingauss_step_stages(c_oracle64, d, M, S, Sa, est, prior, interv, steps):
     data, _, _ = make_data(d, seed=2, joint=True)
@@ -346,14 +348,15 @@ def test_score_graphs_and_mixture(c_oracle64):
     assert np.isfinite(neg_ave_log_likelihood(dist=mixj, eltwise_log_likelihood=jd.eltwise_log_likelihood_observ, x=dataj.x_ho))
 
 
-@pytest.mark.parametrize("d,M,S,Sa,H,act,bias,est,interv,steps", [
-    (5, 3, 16, 4, 4, "relu", True, "reparam", True, (1, 2)),
-    (6, 3, 16, 4, 3, "tanh", False, "score", False, (1, 2)),
-    (20, 4, 32, 8, 5, "relu", True, "reparam", False, (2,)),
-    (20, 3, 16, 4, 5, "leakyrelu", True, "reparam", True, (3,)),
+@pytest.mark.parametrize("d,M,S,Sa,H,act,bias,est,interv,steps,N", [
+    (5, 3, 16, 4, 4, "relu", True, "reparam", True, (1, 2), 60),
+    (6, 3, 16, 4, 3, "tanh", False, "score", False, (1, 2), 60),
+    (20, 4, 32, 8, 5, "relu", True, "reparam", False, (2,), 60),
+    (20, 3, 16, 4, 5, "leakyrelu", True, "reparam", True, (3,), 60),
+    (100, 2, 16, 4, 5, "tanh", True, "reparam", True, (2,), 100),   # BASELINE config 5 geometry: d=100, hidden (5,), interv_mask
+    (100, 2, 8, 4, 5, "relu", True, "score", True, (1,), 100),
 ])
-def test_joint_densenn_step_stages(c_oracle64, d, M, S, Sa, H, act, bias, est, interv, steps):
-    N = 60
+def test_joint_densenn_step_stages(c_oracle64, d, M, S, Sa, H, act, bias, est, interv, steps, N):
     rng = np.random.default_rng(1)
     x = rng.normal(size=(N, d)).astype(np.float32)
     mask = (rng.random((N, d)) < 0.1).astype(np.int32) if interv else None
