@@ -9,7 +9,7 @@ import subprocess
 from ._abi import DibsConfig
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "_build", "libdibs_hip.so")
+LIB_PATH = os.environ.get("DIBS_HIP_LIB") or os.path.join(_CSRC, "_build", "libdibs_hip.so")  # env: explicit library path
 _lib = None
 
 EXPORTS = [

@@ -29,7 +29,7 @@ struct dibs_engine {
   dibs_config cfg;
   int d, k, M, Mloc, m0, N, S, Sa, W;
   int64_t D, P, E;  // z elems / theta elems per particle, packed row stride (floats)
-  int dpad, ldk, acyc_nt, acyc_cpb, acyc_nblk;
+  int dpad, ldk, acyc_nt, acyc_cpb, acyc_nblk, acyc_units;
   float sigz;
   hipStream_t stream;
   bool own_stream;
@@ -123,7 +123,7 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
     if (!(p > 0.0 && p < 1.0)) return fail("Erdos-Renyi prior: edge probability must be in (0, 1)");
   }
   {
-    if ((size_t)2 * 8 * c.n_particles * 4 > LDS_LIMIT) return fail("n_particles too large (kernel rows must fit in LDS)");
+    if ((size_t)2 * 4 * c.n_particles * 4 + 4096 > LDS_LIMIT) return fail("n_particles too large (kernel rows must fit in LDS)");
     if (((size_t)c.n_vars * c.n_vars + (size_t)2 * c.n_vars * c.n_dim) * 4 > LDS_LIMIT) return fail("n_vars * n_dim too large");
   }
   {  // LDS budgets of the likelihood kernels (x, theta / graph, per-sample operand and residuals are LDS-resident)
@@ -166,19 +166,23 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
     const size_t lds = (size_t)(3 * e->dpad + 1) * (e->dpad + 4) * 4;
     const int per_cu = (int)(LDS_LIMIT / lds) < 1 ? 1 : (int)(LDS_LIMIT / lds);
     const int slots = 256 * (per_cu > 8 ? 8 : per_cu);
+    // a work unit is a PAIR of chains when the PRNG layout lets one Threefry call serve both (see k_acyc), else one chain
+    const bool paired = c.rng_layout == DIBS_RNG_LEGACY && (e->Sa & 1) == 0 && (uint64_t)e->Sa * e->d * e->d < 0xFFFFFFFFull;
+    const int n_units = paired ? e->Sa / 2 : e->Sa;
+    e->acyc_units = n_units;
     int best = 1;
     long best_cost = -1;
-    for (int cpb = 1; cpb <= e->Sa; ++cpb) {
+    for (int cpb = 1; cpb <= n_units; ++cpb) {
       // (sized for the GLOBAL particle count: the grouping of the Sa chains into partial sums must not depend on how the
       //  particles are sharded, or results would differ between rank counts in the last float bit)
-      const long nblk = (long)((e->Sa + cpb - 1) / cpb) * e->M;
+      const long nblk = (long)((n_units + cpb - 1) / cpb) * e->M;
       const long cost = ((nblk + slots - 1) / slots) * cpb;
       if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cpb; }
     }
     e->acyc_cpb = best;
     if (const char* ov = getenv("DIBS_ACYC_CPB")) e->acyc_cpb = atoi(ov) > 0 ? atoi(ov) : best;  // tuning override
   }
-  e->acyc_nblk = (e->Sa + e->acyc_cpb - 1) / e->acyc_cpb;
+  e->acyc_nblk = (e->acyc_units + e->acyc_cpb - 1) / e->acyc_cpb;
   e->sigz = c.latent_prior_std > 0 ? (float)c.latent_prior_std : 1.0f / sqrtf((float)e->k);
   if (stream) {
     e->stream = (hipStream_t)stream;
@@ -222,6 +226,7 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
   if (c.joint) {
     if (joint_alloc(&e->jw, e->Mloc, e->d, e->N, e->S) != 0) return fail("joint work buffers: hipMalloc failed");
   }
+  hipDeviceSynchronize();  // the zero fills above ran on the null stream; the engine's own stream does not wait for it
   *out = e;
   return 0;
 }
@@ -437,27 +442,21 @@ static void drain_timers(dibs_engine* e) {
 // the host walks the chain (row 0), kernels derive row 1 + m.
 static Key2 next_carry(const dibs_engine* e, Key2 k) { return rng_split_row(k, (uint32_t)e->M + 1u, 0u, e->cfg.rng_layout); }
 
-// queued BGe problems (k_bge_big): three grid-stride launches sized for the device, R in LDS when there is one matrix
+// queued BGe problems (k_bge_big): one grid-stride launch over the three tiers, R in LDS when there is one matrix
 static void launch_bge_big(dibs_engine* e, const BgeParams& bp, const uint64_t* masks, double* ns, const BgeQueues& q, int S,
                            unsigned long long* cnt) {
   const bool rl = bp.n_mats == 1;
   const int d = e->d, W = e->W;
-#define BIG(G_, LIST_, IDX_, NBLK_)                                                                                       \
-  if (rl) {                                                                                                               \
-    const size_t lds = bge_big_lds_bytes(d, G_, true);                                                                    \
-    allow_lds(k_bge_big<G_, true>, lds);                                                                                  \
-    hipLaunchKernelGGL((k_bge_big<G_, true>), dim3(NBLK_), dim3(256), lds, e->stream, masks, ns, bp, LIST_, q.counts + IDX_, d, S, \
-                       W, cnt);                                                                                           \
-  } else {                                                                                                                \
-    const size_t lds = bge_big_lds_bytes(d, G_, false);                                                                   \
-    allow_lds(k_bge_big<G_, false>, lds);                                                                                 \
-    hipLaunchKernelGGL((k_bge_big<G_, false>), dim3(NBLK_), dim3(256), lds, e->stream, masks, ns, bp, LIST_, q.counts + IDX_, d, S, \
-                       W, cnt);                                                                                           \
+  const int n16 = 1024, n32 = 1024, ng = 512;
+  size_t lds = 0;
+  for (int G : {16, 32, 64}) lds = bge_big_lds_bytes(d, G, rl) > lds ? bge_big_lds_bytes(d, G, rl) : lds;
+  if (rl) {
+    allow_lds(k_bge_big<true>, lds);
+    hipLaunchKernelGGL(k_bge_big<true>, dim3(n16 + n32 + ng), dim3(256), lds, e->stream, masks, ns, bp, q, n16, n32, d, S, W, cnt);
+  } else {
+    allow_lds(k_bge_big<false>, lds);
+    hipLaunchKernelGGL(k_bge_big<false>, dim3(n16 + n32 + ng), dim3(256), lds, e->stream, masks, ns, bp, q, n16, n32, d, S, W, cnt);
   }
-  BIG(16, q.list16, 0, 1024)
-  BIG(32, q.list32, 1, 1024)
-  BIG(64, q.listg, 2, 512)
-#undef BIG
 }
 
 template <int NT>
@@ -496,8 +495,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
   if (c.likelihood == DIBS_LIK_BGE) {
     BgeParams bp{e->R, e->gam, e->Nj, e->alpha_lambd, e->n_mats};
     unsigned long long* cnt = e->profiling ? e->counters : (unsigned long long*)nullptr;
-    hipMemsetAsync(e->bq.counts, 0, 4 * sizeof(unsigned int), e->stream);
-    {
+    {  // (queue counters: zero at creation, reset by k_lik_weights_score at the end of every step)
       KTimer tm(e, DIBS_K_BGE_NODES);
       const size_t lds4 = bge_lds_bytes(e->d, e->S, e->W, 4), lds1 = bge_lds_bytes(e->d, e->S, e->W, 1);
       if (e->n_mats == 1 && lds4 <= 80 * 1024) {
@@ -524,7 +522,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
       allow_lds(k_lik_weights_score, lds);
       hipLaunchKernelGGL(k_lik_weights_score, dim3(e->Mloc, ny), dim3(256), lds, e->stream, e->node_scores, e->masks,
                          e->probs, e->logprobs_z, e->w_lik, e->baseline, e->baseline2, alpha, c.score_function_baseline,
-                         e->d, e->S, e->W, in_lds);
+                         e->d, e->S, e->W, in_lds, e->bq.counts);
       std::swap(e->baseline, e->baseline2);
     }
   } else if (c.likelihood == DIBS_LIK_LINGAUSS) {
@@ -608,17 +606,22 @@ static int step_update(dibs_engine* e, int t, const float* pack) {
   }
   {
     KTimer tm(e, DIBS_K_PHI_UPDATE);
-    const size_t lds = (size_t)2 * PHI_TA * e->M * 4;
-    allow_lds(k_phi_update, lds);
-    const int gy = (e->Mloc + PHI_TA - 1) / PHI_TA;
-    hipLaunchKernelGGL(k_phi_update, dim3((unsigned)((e->D + 255) / 256), gy), dim3(256), lds, e->stream, pack, (size_t)e->E,
-                       (size_t)0, (size_t)e->D, (int)e->D, e->kz, e->kt, 0, e->z, e->vz, e->phi_z, e->m0, e->Mloc, e->M,
-                       (float)c.h_latent, (float)c.stepsize, c.optimizer == DIBS_OPT_RMSPROP);
-    if (c.joint)
-      hipLaunchKernelGGL(k_phi_update, dim3((unsigned)((e->P + 255) / 256), gy), dim3(256), lds, e->stream, pack,
-                         (size_t)e->E, (size_t)(2 * e->D), (size_t)(2 * e->D + e->P), (int)e->P, e->kz, e->kt, 1, e->theta,
-                         e->vtheta, e->phi_th, e->m0, e->Mloc, e->M, (float)c.h_theta, (float)c.stepsize,
-                         c.optimizer == DIBS_OPT_RMSPROP);
+    auto phi = [&](size_t val_off, size_t grad_off, size_t len, int is_theta, float* x, float* v, float* phi_out, float h) {
+      // particles per block: as many as keep >= 512 blocks in flight and the [M][TA] tables within 48 KiB of LDS
+      const long cols = (long)((len + 63) / 64);
+      int ta = 16;
+      while (ta > 4 && (cols * ((e->Mloc + ta - 1) / ta) < 512 || (size_t)2 * ta * e->M * 4 > 48 * 1024)) ta >>= 1;
+      const size_t lds = ((size_t)2 * ta * e->M + (size_t)4 * ta * 64) * 4;
+      const dim3 g((unsigned)cols, (e->Mloc + ta - 1) / ta);
+#define PHI_LAUNCH(TA_)                                                                                                        \
+      allow_lds(k_phi_update<TA_>, lds);                                                                                         \
+      hipLaunchKernelGGL(k_phi_update<TA_>, g, dim3(256), lds, e->stream, pack, (size_t)e->E, val_off, grad_off, (int)len, e->kz, \
+                         e->kt, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize, c.optimizer == DIBS_OPT_RMSPROP);
+      if (ta == 16) { PHI_LAUNCH(16) } else if (ta == 8) { PHI_LAUNCH(8) } else { PHI_LAUNCH(4) }
+#undef PHI_LAUNCH
+    };
+    phi((size_t)0, (size_t)e->D, (size_t)e->D, 0, e->z, e->vz, e->phi_z, (float)c.h_latent);
+    if (c.joint) phi((size_t)(2 * e->D), (size_t)(2 * e->D + e->P), (size_t)e->P, 1, e->theta, e->vtheta, e->phi_th, (float)c.h_theta);
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(err));

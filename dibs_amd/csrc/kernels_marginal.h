@@ -123,8 +123,8 @@ __host__ __device__ inline int bge_lbuf_floats(int d) {
 }
 __host__ __device__ inline int bge_idx_len(int d) { return d + 4 > 36 ? d + 4 : 36; }  // >= 32: the 32-lane tier zero-fills 32 slots
 __host__ __device__ inline size_t bge_wave_bytes(int d, int S, int W) {
-  // masks[S*W] u64 | thr[d]
-  size_t b = (size_t)S * W * 8 + (size_t)d * 4;
+  // masks[S*W] u64 | thr[d] | lim[d]
+  size_t b = (size_t)S * W * 8 + (size_t)2 * d * 4;
   return (b + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t bge_lds_bytes(int d, int S, int W, int waves) {
@@ -175,10 +175,26 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
     const float* Rg = bp.R + (bp.n_mats > 1 ? (size_t)(blockIdx.x * WAVES) * d * d : 0);
     for (int e = tid; e < d * d; e += 64 * WAVES) Rs[e] = Rg[e];
   }
-  if (active && SAMPLE)
-    for (int i = lane; i < d; i += 64) thrs[i] = thr[((size_t)m * d + i) * d + j];
+  // lim = 512 * thr:  y < lim  <=>  (y >> 9) < thr.  thr == 2^23 (p == 1.0f) has no 32-bit lim; those rows are forced on.
+  uint32_t* lims = thrs + d;
+  uint64_t force0 = 0, force1 = 0;
+  if (active && SAMPLE) {
+    for (int i0 = 0; i0 < d; i0 += 64) {
+      const int i = i0 + lane;
+      const uint32_t t = i < d ? thr[((size_t)m * d + i) * d + j] : 0u;
+      if (i < d) {
+        thrs[i] = t;
+        lims[i] = t >= 0x800000u ? 0xFFFFFFFFu : t << 9;
+      }
+      const uint64_t f = __ballot(t >= 0x800000u);
+      if (i0 == 0) force0 = f; else force1 = f;
+    }
+  }
   __syncthreads();
   if (!active) return;
+#if defined(BGE_EXP) && BGE_EXP >= 3
+  return;
+#endif
   if (!SAMPLE) {  // scoring of given graphs (dibs_score_graphs): the parent sets come from the caller
     const uint64_t* mg = masks + ((size_t)m * d + j) * S * W;
     for (int e = lane; e < S * W; e += 64) mk[e] = mg[e];
@@ -196,23 +212,48 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
       uint64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
       const uint64_t cbase = (uint64_t)p * dd + j;
       if (layout == 0 && nbits < 0xFFFFFFFFull) {
-        // legacy layout, 32-bit counters: element c pairs with c + n/2 in one Threefry call
-        uint32_t c0 = (uint32_t)cbase;
-        const uint32_t half32 = (uint32_t)(nbits >> 1);
-        uint32_t lo = 0, hi = 0, lo2 = 0, hi2 = 0, lo3 = 0, hi3 = 0, lo4 = 0, hi4 = 0;  // bits 0-31, 32-63 (a) / (b)
-        for (int i = 0; i < d; ++i, c0 += (uint32_t)d) {
-          uint32_t y0, y1;
-          threefry2x32(kg.a, kg.b, c0, c0 + half32, y0, y1);
-          const uint32_t t = thrs[i];
-          const uint32_t ba = (uint32_t)((y0 >> 9) < t) << (i & 31), bb = (uint32_t)((y1 >> 9) < t) << (i & 31);
-          const int w32 = i >> 5;
-          if (w32 == 0) { lo |= ba; lo2 |= bb; } else if (w32 == 1) { hi |= ba; hi2 |= bb; }
-          else if (w32 == 2) { lo3 |= ba; lo4 |= bb; } else { hi3 |= ba; hi4 |= bb; }
+        // legacy layout, 32-bit counters: element c pairs with c + n/2 in one Threefry call.  The kernel is bound by VALU
+        // issue and this loop is most of it: per output bit one compare and one add-with-carry (word = 2 * word + bit,
+        // i.e. rows arrive MSB first and the word is bit-reversed once at the end).
+        const TfKeys tk = tf_keys(kg);
+        uint32_t c0 = (uint32_t)cbase, c1 = (uint32_t)cbase + (uint32_t)(nbits >> 1);
+        uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int w32 = 0; w32 < 4; ++w32) {
+          const int i0 = w32 * 32;
+          if (i0 < d) {
+            const int i1 = d < i0 + 32 ? d : i0 + 32;
+            uint32_t A = 0u, B = 0u;
+            int i = i0;
+#if defined(BGE_EXP) && BGE_EXP >= 1
+            i = i1;
+#endif
+            for (; i + 1 < i1; i += 2, c0 += 2u * (uint32_t)d, c1 += 2u * (uint32_t)d) {
+              uint32_t y0, y1, y2, y3;
+              threefry2x32_uk2(tk, c0, c1, c0 + (uint32_t)d, c1 + (uint32_t)d, y0, y1, y2, y3);
+              const uint32_t L = lims[i], L2 = lims[i + 1];
+              asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(A) : "v"(y0), "v"(L) : "vcc");
+              asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(B) : "v"(y1), "v"(L) : "vcc");
+              asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(A) : "v"(y2), "v"(L2) : "vcc");
+              asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(B) : "v"(y3), "v"(L2) : "vcc");
+            }
+            if (i < i1) {
+              uint32_t y0, y1;
+              threefry2x32_uk(tk, c0, c1, y0, y1);
+              const uint32_t L = lims[i];
+              asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(A) : "v"(y0), "v"(L) : "vcc");
+              asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(B) : "v"(y1), "v"(L) : "vcc");
+              c0 += (uint32_t)d;
+              c1 += (uint32_t)d;
+            }
+            wa[w32] = __brev(A) >> (32 - (i1 - i0));
+            wb[w32] = __brev(B) >> (32 - (i1 - i0));
+          }
         }
-        a0 = ((uint64_t)hi << 32) | lo;
-        b0 = ((uint64_t)hi2 << 32) | lo2;
-        a1 = ((uint64_t)hi3 << 32) | lo3;
-        b1 = ((uint64_t)hi4 << 32) | lo4;
+        a0 = (((uint64_t)wa[1] << 32) | wa[0]) | force0;
+        b0 = (((uint64_t)wb[1] << 32) | wb[0]) | force0;
+        a1 = (((uint64_t)wa[3] << 32) | wa[2]) | force1;
+        b1 = (((uint64_t)wb[3] << 32) | wb[2]) | force1;
       } else {
         for (int i = 0; i < d; ++i) {
           uint32_t y0, y1;
@@ -244,6 +285,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
     for (int e = lane; e < S * W; e += 64) mg[e] = mk[e];
   }
 
+#if defined(BGE_EXP) && BGE_EXP >= 2
+  return;
+#endif
   const double Nn = bp.Nj[j];
   double* ns_out = node_scores + ((size_t)m * d + j) * S;
   const double score_l0 = bge_assemble(bp, j, 0, d, Nn, 0.0, (double)Rs[j * d + j]);
@@ -325,7 +369,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
   }
   if (counters) {
     const double tot = wave_sum_d(flops);
-    if (lane == 0) atomicAdd(counters, (unsigned long long)tot);
+    if (lane == 0 && tot > 0.0) atomicAdd(counters, (unsigned long long)tot);  // (same-address atomics serialise: skip the zeros)
   }
 }
 
@@ -349,13 +393,11 @@ __host__ __device__ inline size_t bge_big_lds_bytes(int d, int G, bool r_in_lds)
 }
 
 template <int G, bool R_LDS>
-__global__ __launch_bounds__(256) void k_bge_big(const uint64_t* __restrict__ masks, double* __restrict__ node_scores, BgeParams bp,
-                                                 const uint32_t* __restrict__ list, const unsigned int* __restrict__ count_ptr,
-                                                 int d, int S, int W, unsigned long long* __restrict__ counters) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void bge_big_body(unsigned char* smem_raw, const uint64_t* __restrict__ masks, double* __restrict__ node_scores,
+                                             const BgeParams& bp, const uint32_t* __restrict__ list, unsigned int cnt, int d, int S, int W,
+                                             unsigned long long* __restrict__ counters, int vblock, int vgrid) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const unsigned int cnt = *count_ptr;
-  if ((unsigned int)(blockIdx.x * 4 * (G < 64 ? 64 / G : 1)) >= cnt) return;  // nothing queued for this block (block-uniform)
+  if ((unsigned int)(vblock * 4 * (G < 64 ? 64 / G : 1)) >= cnt) return;  // nothing queued for this block (block-uniform)
   float* Rs = reinterpret_cast<float*>(smem_raw);
   const size_t r_bytes = R_LDS ? ((((size_t)d * d * 4) + 15) & ~(size_t)15) : 0;
   if (R_LDS) {
@@ -372,7 +414,7 @@ __global__ __launch_bounds__(256) void k_bge_big(const uint64_t* __restrict__ ma
     const int grp = lane / G, r = lane % G;
     int* myidx = idxs + grp * ilen;
     float* Lh = Lb + grp * G * LD;
-    for (unsigned int q = (blockIdx.x * 4 + wave) * NP; q < cnt; q += gridDim.x * 4 * NP) {
+    for (unsigned int q = (vblock * 4 + wave) * NP; q < cnt; q += vgrid * 4 * NP) {
       const bool has = q + grp < cnt;
       const uint32_t code = has ? list[q + grp] : 0u;
       const int s = code % S, mj = code / S, j = mj % d;
@@ -441,7 +483,7 @@ __global__ __launch_bounds__(256) void k_bge_big(const uint64_t* __restrict__ ma
     float* Lb = reinterpret_cast<float*>(wbase);
     int* myidx = reinterpret_cast<int*>(Lb + (((size_t)d * (d | 1) + 3) & ~(size_t)3));
     const int ldl = d | 1;
-    for (unsigned int q = blockIdx.x * 4 + wave; q < cnt; q += gridDim.x * 4) {
+    for (unsigned int q = vblock * 4 + wave; q < cnt; q += vgrid * 4) {
       const uint32_t code = list[q];
       const int s = code % S, mj = code / S, j = mj % d;
       const float* R = R_LDS ? Rs : bp.R + (bp.n_mats > 1 ? (size_t)j * d * d : 0);
@@ -501,6 +543,20 @@ __global__ __launch_bounds__(256) void k_bge_big(const uint64_t* __restrict__ ma
   }
 }
 
+// one launch for the three queues: blocks [0, n16) work on list16 with 16-lane groups, [n16, n16 + n32) on list32, the rest on
+// the generic one-problem-per-wave tier.  In the steady state of a run all queues are empty and every block returns at once;
+// three separate launches cost three launch latencies for nothing.
+template <bool R_LDS>
+__global__ __launch_bounds__(256) void k_bge_big(const uint64_t* __restrict__ masks, double* __restrict__ node_scores, BgeParams bp,
+                                                 BgeQueues qs, int n16, int n32, int d, int S, int W,
+                                                 unsigned long long* __restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int b = blockIdx.x, ng = gridDim.x - n16 - n32;
+  if (b < n16) bge_big_body<16, R_LDS>(smem_raw, masks, node_scores, bp, qs.list16, qs.counts[0], d, S, W, counters, b, n16);
+  else if (b < n16 + n32) bge_big_body<32, R_LDS>(smem_raw, masks, node_scores, bp, qs.list32, qs.counts[1], d, S, W, counters, b - n16, n32);
+  else bge_big_body<64, R_LDS>(smem_raw, masks, node_scores, bp, qs.listg, qs.counts[2], d, S, W, counters, b - n16 - n32, ng);
+}
+
 // out[s] = sum_j node_scores[j][s]   (scoring of given graphs)
 __global__ void k_sum_nodes(const double* __restrict__ node_scores, float* __restrict__ out, int d, int S) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -521,7 +577,10 @@ __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restr
                                                            const float* __restrict__ probs, float* __restrict__ logprobs,
                                                            float* __restrict__ w_lik, const float* __restrict__ baseline,
                                                            float* __restrict__ baseline_out, float alpha,
-                                                           double sf_baseline, int d, int S, int W, int masks_in_lds) {
+                                                           double sf_baseline, int d, int S, int W, int masks_in_lds,
+                                                           unsigned int* __restrict__ queue_counts) {
+  // the BGe queues of this step have been consumed (stream order): reset their counters for the next step
+  if (queue_counts && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) queue_counts[threadIdx.x] = 0u;
   // block (m, y) handles the columns j = y, y + gridDim.y, ... of particle m; every block recomputes l_s / softmax
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* lp = reinterpret_cast<double*>(smem_raw);
@@ -630,7 +689,10 @@ __device__ __forceinline__ int acyc_pc(int c) { return (c & 15) * NT + (c >> 4);
 // C = A * B.  Operands are OFFSETS (in floats) into the kernel's LDS array so that every access is a ds_* instruction
 // (a runtime-selected generic pointer would turn them into flat accesses).  The next k-step's fragments are loaded
 // while the current MFMAs issue.
-template <int NT>
+// ODD: the number of k-steps (kp / 4) is odd.  A template parameter, not a runtime `if` around the last MFMA: the accumulators
+// must not meet a control-flow join between an MFMA and the s_nop that covers its latency -- hipcc places register copies
+// for the join right behind the (opaque) asm MFMA and reads the accumulator too early.
+template <int NT, bool ODD>
 __device__ __forceinline__ void lds_matmul(float* __restrict__ lds, int c_off, int a_off, int b_off, int kp, int lane,
                                            int wave) {
   constexpr int DP = 16 * NT, LD = DP + 4;
@@ -645,7 +707,7 @@ __device__ __forceinline__ void lds_matmul(float* __restrict__ lds, int c_off, i
     // two-stage register pipeline over the kp / 4 k-steps (step s: k0 = 4 s); the loads of the following step are
     // issued before the MFMAs of the current one.  A step index == nsteps is loaded but never used (addresses stay
     // inside the LDS allocation: one slack row is allocated behind the last buffer).
-    const int nsteps = ((kp + 7) >> 3) << 1;  // even number of k-steps; the operands are zero beyond d
+    const int ksteps = kp >> 2, nsteps = ksteps & ~1;  // the pipelined loop takes the steps in pairs; an odd last step follows it
     float a0, a1, b0[NT], b1[NT];
 #define ACYC_LOAD(A_, B_, S_)                                                     \
     {                                                                             \
@@ -663,7 +725,7 @@ __device__ __forceinline__ void lds_matmul(float* __restrict__ lds, int c_off, i
     // Hazards hipcc cannot see around asm: accumulator init -> first MFMA (s_nop below) and last MFMA -> accumulator
     // read (s_nop after the loop); back-to-back MFMAs on the same accumulator need none.
 #define ACYC_MFMA(A_, B_) \
-    _Pragma("unroll") for (int tj = 0; tj < NT; ++tj) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tj]) : "v"(A_), "v"(B_[tj]));
+    _Pragma("unroll") for (int tj = 0; tj < NT; ++tj) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[tj]) : "v"(A_), "v"(B_[tj]));
     ACYC_LOAD(a0, b0, 0)
     asm volatile("s_nop 4" ::: "memory");
 #pragma unroll 1
@@ -673,8 +735,9 @@ __device__ __forceinline__ void lds_matmul(float* __restrict__ lds, int c_off, i
       ACYC_LOAD(a0, b0, st + 2)
       ACYC_MFMA(a1, b1)
     }
+    if constexpr (ODD) { ACYC_MFMA(a0, b0) }  // (its fragments were loaded by the last pass, or by the prologue when ksteps == 1)
 #pragma unroll
-    for (int tj = 0; tj < NT; ++tj) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[tj]));  // last MFMA -> accumulator read
+    for (int tj = 0; tj < NT; ++tj) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[tj]));  // last MFMA -> accumulator read
 #undef ACYC_LOAD
 #undef ACYC_MFMA
 #pragma unroll
@@ -708,80 +771,115 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
   const Key2 km = rng_split_row(carry, (uint32_t)M_global + 1u, (uint32_t)(m0 + m) + 1u, layout);  // dibs.py:595: key used directly
   const uint64_t dd = (uint64_t)d * d, nbits = (uint64_t)Sa * dd;
   const int kp = (d + 3) & ~3;
+  const bool kodd = (kp >> 2) & 1;
   const float inv_d = 1.0f / (float)d;
   const float* sm = scores + (size_t)m * dd;
-  // thread t owns column pj = t % DP and rows pi0 + q * RSTEP of the d x d matrix (same elements in every chain, so the
-  // per-element constants and the soft-graph entries stay in registers; no division by the runtime d)
-  constexpr int RSTEP = 256 / DP, EPT = (DP + RSTEP - 1) / RSTEP;
+  // thread t owns column pj = t % DP and rows pi0 + q * R of the d x d matrix: the same elements in every chain, and all
+  // LDS offsets are compile-time functions of q (a d-dependent mapping would keep more lanes busy at d = 50 but its
+  // offsets end up as loop-invariant VGPRs and cost an occupancy step).  Registers that stay live across the matmuls
+  // decide the occupancy, so only `out` and the second chain's soft graph are kept; exp(-alpha s) is recomputed when
+  // noise is drawn and g for the epilogue is read back from buffer 0.
+  constexpr int R = 256 / DP, EPT = (DP + R - 1) / R;
   const int pj = tid % DP, pi0 = tid / DP;
-  const bool pact = pi0 < RSTEP && pj < d;
+  const bool pact = pi0 < R && pj < d;
+  const int pcj = acyc_pc<NT>(pj);
   const bool fast = tau == 1.0f;   // sigmoid(eps + a) with eps = log(u / (1 - u))  ==  u / (u + (1 - u) exp(-a)): no log / exp per draw
   const float ulo = tiny ? 1.17549435e-38f : 1.1920929e-07f;
-  float out[EPT], ea[EPT], gq[EPT];
+  const float fd = (float)d;
+  // legacy PRNG layout: element e of the [Sa, d, d] noise tensor shares its Threefry call with element e + Sa*d*d/2, i.e.
+  // chain sa with chain sa + Sa/2 at the same (i, j).  A block therefore takes both chains of a pair (`paired`; the host
+  // sizes the grid in pairs) and draws the noise of both with one call per element -- the noise is most of this kernel's
+  // VALU work, and VALU work does not overlap with the f32 MFMAs.
+  const bool paired = layout == 0 && (Sa & 1) == 0 && nbits < 0xFFFFFFFFull;
+  const int n_units = paired ? (Sa >> 1) : Sa;
+  const TfKeys tk = tf_keys(km);
+  float out[EPT], gnext[EPT];
 #pragma unroll
   for (int q = 0; q < EPT; ++q) {
-    const int i = pi0 + q * RSTEP;
     out[q] = 0.f;
-    gq[q] = 0.f;
-    ea[q] = (pact && i < d && i != pj) ? (fast ? expf(-alpha * sm[i * d + pj]) : alpha * sm[i * d + pj]) : 0.f;
+    gnext[q] = 0.f;
   }
   for (int e = tid; e < BUF; e += 256) smem[e] = 0.f;  // padding of buffer 0: zeroed once, never written afterwards
 
   for (int c = 0; c < cpb; ++c) {
-    const int sa = blk * cpb + c;
-    if (sa >= Sa) break;
-    __syncthreads();
-    // buffer 0: M = I + G~/d  (permuted columns)
+    const int unit = blk * cpb + c;
+    if (unit >= n_units) break;
+    for (int hf = 0; hf < (paired ? 2 : 1); ++hf) {
+      const int sa = paired ? unit + hf * (Sa >> 1) : unit;
+      const float* sml = sm;
+      asm volatile("" : "+s"(sml));  // opaque per pass: otherwise exp(-alpha s) is hoisted out of the loops into EPT live VGPRs
+      __syncthreads();
+      // buffer 0: M = I + G~/d  (permuted columns)
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-      const int i = pi0 + q * RSTEP;
-      if (pact && i < d) {
-        float v = 1.0f, g = 0.f;
-        if (i != pj) {
-          const uint32_t bits = rng_bits_at(km, nbits, (uint64_t)sa * dd + (uint64_t)(i * d + pj), layout);
-          if (fast) {
-            const float u = rng_uniform(bits, ulo, 1.0f);
-            g = u / (u + (1.0f - u) * ea[q]);
-          } else {
-            g = 1.0f / (1.0f + expf(-tau * (rng_logistic(bits, tiny) + ea[q])));
+      for (int q = 0; q < EPT; ++q) {
+        const int i = pi0 + q * R;
+        if (pact && i < d) {
+          float v = 1.0f;
+          if (i != pj) {
+            float g;
+            if (paired && hf == 1) {
+              g = gnext[q];
+            } else {
+              const float as = alpha * sml[i * d + pj];
+              const float ea = fast ? expf(-as) : as;
+              uint32_t y0, y1 = 0u;
+              if (paired) {
+                const uint32_t c0 = (uint32_t)((uint64_t)sa * dd) + (uint32_t)(i * d + pj);
+                threefry2x32_uk(tk, c0, c0 + (uint32_t)(nbits >> 1), y0, y1);
+              } else {
+                y0 = rng_bits_at(km, nbits, (uint64_t)sa * dd + (uint64_t)(i * d + pj), layout);
+              }
+              if (fast) {
+                const float u0 = rng_uniform(y0, ulo, 1.0f), u1 = rng_uniform(y1, ulo, 1.0f);
+                g = u0 / (u0 + (1.0f - u0) * ea);
+                gnext[q] = u1 / (u1 + (1.0f - u1) * ea);
+              } else {
+                g = 1.0f / (1.0f + expf(-tau * (rng_logistic(y0, tiny) + ea)));
+                gnext[q] = 1.0f / (1.0f + expf(-tau * (rng_logistic(y1, tiny) + ea)));
+              }
+            }
+            v = g * inv_d;
           }
-          v = g * inv_d;
+          smem[i * LD + pcj] = v;
         }
-        gq[q] = g;
-        smem[i * LD + acyc_pc<NT>(pj)] = v;
       }
-    }
-    __syncthreads();
-    // left-to-right binary powering of e = d - 1; the running power ping-pongs between buffers 1 and 2
-    const int ex = d - 1;
-    int cur = 0;
-    if (ex >= 1) {
-      const int hb = 31 - __builtin_clz((unsigned)ex);
-      for (int b = hb - 1; b >= 0; --b) {
-        int dst = (cur == BUF) ? 2 * BUF : BUF;
-        lds_matmul<NT>(smem, dst, cur, cur, kp, lane, wave);
-        __syncthreads();
-        cur = dst;
-        if ((ex >> b) & 1) {
-          dst = (cur == BUF) ? 2 * BUF : BUF;
-          lds_matmul<NT>(smem, dst, cur, 0, kp, lane, wave);
+      __syncthreads();
+      // left-to-right binary powering of e = d - 1; the running power ping-pongs between buffers 1 and 2
+      const int ex = d - 1;
+      int cur = 0;
+      if (ex >= 1) {
+        const int hb = 31 - __builtin_clz((unsigned)ex);
+        for (int b = hb - 1; b >= 0; --b) {
+          int dst = (cur == BUF) ? 2 * BUF : BUF;
+          if (kodd) lds_matmul<NT, true>(smem, dst, cur, cur, kp, lane, wave);
+          else lds_matmul<NT, false>(smem, dst, cur, cur, kp, lane, wave);
           __syncthreads();
           cur = dst;
+          if ((ex >> b) & 1) {
+            dst = (cur == BUF) ? 2 * BUF : BUF;
+            if (kodd) lds_matmul<NT, true>(smem, dst, cur, 0, kp, lane, wave);
+            else lds_matmul<NT, false>(smem, dst, cur, 0, kp, lane, wave);
+            __syncthreads();
+            cur = dst;
+          }
         }
       }
-    }
-    // out[i][j] += (M^{d-1})[j][i] * tau * alpha * g (1 - g)   (i != j; g = 0 on the diagonal)
+      // out[i][j] += (M^{d-1})[j][i] * tau * alpha * g (1 - g)   (i != j);  g = d * M[i][j] from buffer 0
 #pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-      const int i = pi0 + q * RSTEP;
-      if (pact && i < d) out[q] += smem[cur + pj * LD + acyc_pc<NT>(i)] * tau * alpha * gq[q] * (1.0f - gq[q]);
+      for (int q = 0; q < EPT; ++q) {
+        const int i = pi0 + q * R;
+        if (pact && i < d && i != pj) {
+          const float g = smem[i * LD + pcj] * fd;
+          out[q] += smem[cur + pj * LD + acyc_pc<NT>(i)] * tau * alpha * g * (1.0f - g);
+        }
+      }
     }
   }
   if (pact) {
     float* po = part + ((size_t)m * gridDim.x + blk) * dd;
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
-      const int i = pi0 + q * RSTEP;
+      const int i = pi0 + q * R;
       if (i < d) po[i * d + pj] = out[q];
     }
   }
@@ -934,20 +1032,24 @@ __global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, si
 //     reference: svgd.py:194-224, 591-670, 265, 718-719; jax.example_libraries.optimizers.rmsprop
 // grid = (ceil(len / 256), ceil(Mloc / TA)), block = 256
 // ------------------------------------------------------------------------------------------------
-#define PHI_TA 4
+// block = 64 consecutive elements x TA local particles; wave w sums over the quarter b in [w Mq, (w+1) Mq) of the particles and
+// the four partial sums are added in wave order (the order is a function of M only: results do not depend on TA or the rank
+// count).  Every [z_b | grad_b] element read from L2 serves TA particles; the kernel tables sit in LDS as [b][TA].
+template <int TA>
 __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pack, size_t pack_stride, size_t val_off,
                                                     size_t grad_off, int len, const float* __restrict__ kz,
                                                     const float* __restrict__ kt, int seg_is_theta, float* __restrict__ x,
                                                     float* __restrict__ v, float* __restrict__ phi_out, int m0, int Mloc,
                                                     int M, float h, float stepsize, int rmsprop) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* ksum = smem;                       // [TA][M]  kz + kt
-  float* krep = smem + (size_t)PHI_TA * M;  // [TA][M]  kernel whose gradient gives the repulsion
-  const int tid = threadIdx.x;
-  const int a0 = blockIdx.y * PHI_TA;
-  const bool two = kt != nullptr;   // marginal: the repulsion kernel is the weight kernel, one table
-  for (int e = tid; e < PHI_TA * M; e += 256) {
-    const int a = a0 + e / M, b = e % M;
+  float* ksum = smem;                   // [M][TA]  kz + kt
+  float* krep = smem + (size_t)TA * M;  // [M][TA]  (2 / h) * kernel whose gradient gives the repulsion
+  float* part = krep + (size_t)TA * M;  // [4][TA][64] partial sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int a0 = blockIdx.y * TA;
+  const float c2h = 2.0f / h;
+  for (int e = tid; e < TA * M; e += 256) {
+    const int b = e / TA, q = e - b * TA, a = a0 + q;
     float s = 0.f, r = 0.f;
     if (a < Mloc) {
       const float z1 = kz[(size_t)a * M + b];
@@ -956,52 +1058,70 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
       r = seg_is_theta ? t1 : z1;
     }
     ksum[e] = s;
-    if (two) krep[e] = r;
+    krep[e] = c2h * r;
   }
   __syncthreads();
-  const int i = blockIdx.x * 256 + tid;
-  if (i >= len) return;
-  float xa[PHI_TA], acc[PHI_TA];
+  const int i = blockIdx.x * 64 + lane;
+  const bool ok = i < len;
+  float xa[TA], acc[TA];
 #pragma unroll
-  for (int q = 0; q < PHI_TA; ++q) {
+  for (int q = 0; q < TA; ++q) {
     const int a = a0 + q;
-    xa[q] = a < Mloc ? pack[(size_t)(m0 + a) * pack_stride + val_off + i] : 0.f;
+    xa[q] = (ok && a < Mloc) ? pack[(size_t)(m0 + a) * pack_stride + val_off + i] : 0.f;
     acc[q] = 0.f;
   }
-  const float c2h = 2.0f / h;
-  const float* krp = two ? krep : ksum;
-  int b = 0;
-  for (; b + 4 <= M; b += 4) {  // four rows in flight (the order of the additions stays b = 0, 1, 2, ...)
-    float g[4], xb[4];
+  const int Mq = (M + 3) >> 2;
+  const int b_lo = wave * Mq, b_hi = (b_lo + Mq < M) ? b_lo + Mq : M;
+  if (ok) {
+    int b = b_lo;
+    // the rows come from the far cache levels (~2 us per dependent round trip): 16 rows (32 loads) are issued together
+    for (; b + 16 <= b_hi; b += 16) {
+      float g[16], xb[16];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      g[u] = pack[(size_t)(b + u) * pack_stride + grad_off + i];
-      xb[u] = pack[(size_t)(b + u) * pack_stride + val_off + i];
+      for (int u = 0; u < 16; ++u) {
+        g[u] = pack[(size_t)(b + u) * pack_stride + grad_off + i];
+        xb[u] = pack[(size_t)(b + u) * pack_stride + val_off + i];
+      }
+      asm volatile("" ::: "memory");  // keep the 32 loads ahead of the arithmetic (hipcc would interleave them to save VGPRs)
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int q4 = 0; q4 < TA / 4; ++q4) {
+          const float4 ks = *reinterpret_cast<const float4*>(ksum + (size_t)(b + u) * TA + q4 * 4);
+          const float4 kr = *reinterpret_cast<const float4*>(krep + (size_t)(b + u) * TA + q4 * 4);
+          acc[q4 * 4 + 0] = fmaf(-kr.x, xb[u] - xa[q4 * 4 + 0], fmaf(ks.x, g[u], acc[q4 * 4 + 0]));
+          acc[q4 * 4 + 1] = fmaf(-kr.y, xb[u] - xa[q4 * 4 + 1], fmaf(ks.y, g[u], acc[q4 * 4 + 1]));
+          acc[q4 * 4 + 2] = fmaf(-kr.z, xb[u] - xa[q4 * 4 + 2], fmaf(ks.z, g[u], acc[q4 * 4 + 2]));
+          acc[q4 * 4 + 3] = fmaf(-kr.w, xb[u] - xa[q4 * 4 + 3], fmaf(ks.w, g[u], acc[q4 * 4 + 3]));
+        }
     }
+    for (; b < b_hi; ++b) {
+      const float g = pack[(size_t)b * pack_stride + grad_off + i];
+      const float xb = pack[(size_t)b * pack_stride + val_off + i];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int q = 0; q < PHI_TA; ++q) acc[q] += ksum[q * M + b + u] * g[u] - c2h * krp[q * M + b + u] * (xb[u] - xa[q]);
-  }
-  for (; b < M; ++b) {
-    const float g = pack[(size_t)b * pack_stride + grad_off + i];
-    const float xb = pack[(size_t)b * pack_stride + val_off + i];
-#pragma unroll
-    for (int q = 0; q < PHI_TA; ++q) acc[q] += ksum[q * M + b] * g - c2h * krp[q * M + b] * (xb - xa[q]);
+      for (int q = 0; q < TA; ++q) acc[q] = fmaf(-krep[(size_t)b * TA + q], xb - xa[q], fmaf(ksum[(size_t)b * TA + q], g, acc[q]));
+    }
   }
 #pragma unroll
-  for (int q = 0; q < PHI_TA; ++q) {
-    const int a = a0 + q;
-    if (a >= Mloc) break;
-    const float phi = -acc[q] / (float)M;
+  for (int q = 0; q < TA; ++q) part[(wave * TA + q) * 64 + lane] = acc[q];
+  __syncthreads();
+  if (!ok) return;
+#pragma unroll
+  for (int qq = 0; qq < TA / 4; ++qq) {
+    const int q = wave + 4 * qq, a = a0 + q;
+    if (a >= Mloc) continue;
+    const float tot = ((part[(0 * TA + q) * 64 + lane] + part[(1 * TA + q) * 64 + lane]) + part[(2 * TA + q) * 64 + lane]) +
+                      part[(3 * TA + q) * 64 + lane];
+    const float phi = -tot / (float)M;
+    const float xv = pack[(size_t)(m0 + a) * pack_stride + val_off + i];
     const size_t o = (size_t)a * len + i;
     if (phi_out) phi_out[o] = phi;
     if (rmsprop) {
       const float vv = v[o] * 0.9f + phi * phi * 0.1f;
       v[o] = vv;
-      x[o] = xa[q] - stepsize * phi / sqrtf(vv + 1e-8f);
+      x[o] = xv - stepsize * phi / sqrtf(vv + 1e-8f);
     } else {
-      x[o] = xa[q] - stepsize * phi;
+      x[o] = xv - stepsize * phi;
     }
   }
 }

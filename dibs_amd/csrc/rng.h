@@ -33,6 +33,81 @@ DIBS_HD void threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, ui
   o1 = x1;
 }
 
+// Threefry for wave-uniform keys, as one fixed instruction sequence (67 VALU ops): the key schedule lives in SGPRs,
+// each injection is folded into the following round's add (v_add3_u32), and the optimiser cannot re-derive the first rounds
+// as extra induction variables (it did, at +50 % instructions, when this ran inside a counter loop).  The sampling kernels are
+// bound by VALU issue, so the instruction count of this routine is their speed.
+struct TfKeys {
+  uint32_t k0, k1, k2, k2p1, k0p2, k1p3, k2p4, k0p5;
+};
+__device__ __forceinline__ TfKeys tf_keys(Key2 key) {
+  TfKeys K;
+#if defined(__HIP_DEVICE_COMPILE__)
+  K.k0 = __builtin_amdgcn_readfirstlane(key.a);
+  K.k1 = __builtin_amdgcn_readfirstlane(key.b);
+#else
+  K.k0 = key.a;
+  K.k1 = key.b;
+#endif
+  K.k2 = K.k0 ^ K.k1 ^ 0x1BD11BDAu;
+  K.k2p1 = K.k2 + 1u;
+  K.k0p2 = K.k0 + 2u;
+  K.k1p3 = K.k1 + 3u;
+  K.k2p4 = K.k2 + 4u;
+  K.k0p5 = K.k0 + 5u;
+  return K;
+}
+#define TF_RA(r) "v_add_u32 %0, %0, %1\n\tv_alignbit_b32 %1, %1, %1, " #r "\n\tv_xor_b32 %1, %1, %0\n\t"
+#define TF_RI(ka, kb, r) "v_add_u32 %1, " kb ", %1\n\tv_add3_u32 %0, %0, " ka ", %1\n\tv_alignbit_b32 %1, %1, %1, " #r "\n\tv_xor_b32 %1, %1, %0\n\t"
+__device__ __forceinline__ void threefry2x32_uk(const TfKeys& K, uint32_t c0, uint32_t c1, uint32_t& o0, uint32_t& o1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t x0 = c0, x1 = c1;
+  // alignbit(x, x, 32 - r) == rotl(x, r)
+  asm volatile(
+      TF_RI("%2", "%3", 19) TF_RA(17) TF_RA(6) TF_RA(26)          /* x = c + (k0, k1); rounds 13 15 26 6 */
+      TF_RI("%3", "%5", 15) TF_RA(3) TF_RA(16) TF_RA(8)           /* += (k1, k2 + 1);  rounds 17 29 16 24 */
+      TF_RI("%4", "%6", 19) TF_RA(17) TF_RA(6) TF_RA(26)          /* += (k2, k0 + 2) */
+      TF_RI("%2", "%7", 15) TF_RA(3) TF_RA(16) TF_RA(8)           /* += (k0, k1 + 3) */
+      TF_RI("%3", "%8", 19) TF_RA(17) TF_RA(6) TF_RA(26)          /* += (k1, k2 + 4) */
+      "v_add_u32 %0, %4, %0\n\tv_add_u32 %1, %9, %1"            /* += (k2, k0 + 5) */
+      : "+v"(x0), "+v"(x1)
+      : "s"(K.k0), "s"(K.k1), "s"(K.k2), "s"(K.k2p1), "s"(K.k0p2), "s"(K.k1p3), "s"(K.k2p4), "s"(K.k0p5));
+  o0 = x0;
+  o1 = x1;
+#else  // host pass of the single-source compile: never executed
+  threefry2x32(K.k0, K.k1, c0, c1, o0, o1);
+#endif
+}
+#undef TF_RA
+#undef TF_RI
+// two independent calls interleaved instruction by instruction (dependent VALU ops of one chain do not issue back to back
+// at full rate; two chains per wave fill the gaps)
+#define TF2_RA(r) "v_add_u32 %0, %0, %1\n\tv_add_u32 %2, %2, %3\n\tv_alignbit_b32 %1, %1, %1, " #r "\n\tv_alignbit_b32 %3, %3, %3, " #r \
+                  "\n\tv_xor_b32 %1, %1, %0\n\tv_xor_b32 %3, %3, %2\n\t"
+#define TF2_RI(ka, kb, r) "v_add_u32 %1, " kb ", %1\n\tv_add_u32 %3, " kb ", %3\n\tv_add3_u32 %0, %0, " ka ", %1\n\tv_add3_u32 %2, %2, " ka ", %3\n\t" \
+                          "v_alignbit_b32 %1, %1, %1, " #r "\n\tv_alignbit_b32 %3, %3, %3, " #r "\n\tv_xor_b32 %1, %1, %0\n\tv_xor_b32 %3, %3, %2\n\t"
+__device__ __forceinline__ void threefry2x32_uk2(const TfKeys& K, uint32_t ca0, uint32_t ca1, uint32_t cb0, uint32_t cb1, uint32_t& oa0,
+                                                 uint32_t& oa1, uint32_t& ob0, uint32_t& ob1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t x0 = ca0, x1 = ca1, z0 = cb0, z1 = cb1;
+  asm volatile(
+      TF2_RI("%4", "%5", 19) TF2_RA(17) TF2_RA(6) TF2_RA(26)
+      TF2_RI("%5", "%7", 15) TF2_RA(3) TF2_RA(16) TF2_RA(8)
+      TF2_RI("%6", "%8", 19) TF2_RA(17) TF2_RA(6) TF2_RA(26)
+      TF2_RI("%4", "%9", 15) TF2_RA(3) TF2_RA(16) TF2_RA(8)
+      TF2_RI("%5", "%10", 19) TF2_RA(17) TF2_RA(6) TF2_RA(26)
+      "v_add_u32 %0, %6, %0\n\tv_add_u32 %2, %6, %2\n\tv_add_u32 %1, %11, %1\n\tv_add_u32 %3, %11, %3"
+      : "+v"(x0), "+v"(x1), "+v"(z0), "+v"(z1)
+      : "s"(K.k0), "s"(K.k1), "s"(K.k2), "s"(K.k2p1), "s"(K.k0p2), "s"(K.k1p3), "s"(K.k2p4), "s"(K.k0p5));
+  oa0 = x0; oa1 = x1; ob0 = z0; ob1 = z1;
+#else
+  threefry2x32(K.k0, K.k1, ca0, ca1, oa0, oa1);
+  threefry2x32(K.k0, K.k1, cb0, cb1, ob0, ob1);
+#endif
+}
+#undef TF2_RA
+#undef TF2_RI
+
 // element i of random_bits(key, n).  layout 0 = legacy (counts split in halves, concat(y0, y1)),
 // 1 = partitionable (counter (hi, lo) = i, y0 ^ y1).
 DIBS_HD uint32_t rng_bits_at(Key2 key, uint64_t n, uint64_t i, int layout) {

@@ -9,12 +9,18 @@ rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT -o $TAG -- "$@" 
 f=$(find $OUT -name "*counter_collection.csv" | head -1)
 python - "$f" <<'PY'
 import csv, sys, collections
+import os
 rows = list(csv.DictReader(open(sys.argv[1])))
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+lastn = int(os.environ.get("LASTN", "0"))   # LASTN=n: average only the last n dispatches of every kernel (steady state)
+series = collections.defaultdict(list)
 for r in rows:
-    k = r["Kernel_Name"].split("(")[0][:40]
-    agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-    cnt[(k, r["Counter_Name"])] += 1
+    series[(r["Kernel_Name"].split("(")[0][:40], r["Counter_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+for (k, c), v in series.items():
+    v.sort()
+    v = v[-lastn:] if lastn else v
+    agg[k][c] = sum(x for _, x in v)
+    cnt[(k, c)] = len(v)
 for k in agg:
     print(k, {c: f"{v / cnt[(k, c)]:.4g}" for c, v in agg[k].items()})
 PY
