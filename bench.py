@@ -123,7 +123,7 @@ def main():
         # SURVEY.md 8(d) algorithmic flop counts per step (= per launch: each kernel is launched once per step)
         dense_bge = N_PARTICLES * S_MC * D_VARS * 2 * D_VARS ** 3 / 3.0          # F_lik(BGe), dense-Cholesky count
         acyc_flops = N_PARTICLES * SA_MC * binary_powering_matmuls(D_VARS - 1) * 2 * D_VARS ** 3   # F_acyc
-        rocprof_names = {"acyc": "k_acyc<4>", "bge_nodes": "k_bge_nodes<4, true>", "bge_big": "k_bge_big<16|32|64, true> (3 launches)"}
+        rocprof_names = {"acyc": "k_acyc<4, true>", "bge_nodes": "k_bge_nodes<4, true>", "bge_big": "k_bge_big<16|32|64, true> (3 launches)"}
         roof = {"kernel": dom, "rocprof_kernel": rocprof_names.get(dom, "k_" + dom), "bound": "mfma",
                 "pipe": "mfma_f32" if dom == "acyc" else "valu_f32", "avg_launch_us": avg_s * 1e6, "launches": dom_n,
                 "share_of_step": dom_ms / total_ms, "unit": "TFLOP/s", "peak": PEAK_F32_TFLOPS, "traffic": None}

@@ -218,6 +218,7 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
   if (c.likelihood == DIBS_LIK_BGE) {
     HIP_OK(dalloc(&e->masks, Ml * e->S * e->d * e->W));
     HIP_OK(dalloc(&e->node_scores, Ml * e->S * e->d));
+    HIP_OK(dalloc(&e->bq.list12, Ml * e->S * e->d));
     HIP_OK(dalloc(&e->bq.list16, Ml * e->S * e->d));
     HIP_OK(dalloc(&e->bq.list32, Ml * e->S * e->d));
     HIP_OK(dalloc(&e->bq.listg, Ml * e->S * e->d));
@@ -237,7 +238,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->w_tot, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
-                  e->node_scores, e->x, e->mask, e->R, e->gam, e->Nj, e->bq.list16, e->bq.list32, e->bq.listg, e->bq.counts};
+                  e->node_scores, e->x, e->mask, e->R, e->gam, e->Nj, e->bq.list12, e->bq.list16, e->bq.list32, e->bq.listg, e->bq.counts};
   for (void* p : ptrs)
     if (p) hipFree(p);
   joint_free(&e->jw);
@@ -442,20 +443,20 @@ static void drain_timers(dibs_engine* e) {
 // the host walks the chain (row 0), kernels derive row 1 + m.
 static Key2 next_carry(const dibs_engine* e, Key2 k) { return rng_split_row(k, (uint32_t)e->M + 1u, 0u, e->cfg.rng_layout); }
 
-// queued BGe problems (k_bge_big): one grid-stride launch over the three tiers, R in LDS when there is one matrix
+// queued BGe problems (k_bge_big): one grid-stride launch over the four tiers, R in LDS when there is one matrix
 static void launch_bge_big(dibs_engine* e, const BgeParams& bp, const uint64_t* masks, double* ns, const BgeQueues& q, int S,
                            unsigned long long* cnt) {
   const bool rl = bp.n_mats == 1;
   const int d = e->d, W = e->W;
-  const int n16 = 1024, n32 = 1024, ng = 512;
-  size_t lds = 0;
-  for (int G : {16, 32, 64}) lds = bge_big_lds_bytes(d, G, rl) > lds ? bge_big_lds_bytes(d, G, rl) : lds;
+  const int n12 = 1024, n16 = 512, n32 = 512, ng = 256;
+  size_t lds = rl ? ((((size_t)d * d * 4) + 15) & ~(size_t)15) : 16;   // the per-lane tiers only keep R
+  for (int G : {32, 64}) lds = bge_big_lds_bytes(d, G, rl) > lds ? bge_big_lds_bytes(d, G, rl) : lds;
   if (rl) {
     allow_lds(k_bge_big<true>, lds);
-    hipLaunchKernelGGL(k_bge_big<true>, dim3(n16 + n32 + ng), dim3(256), lds, e->stream, masks, ns, bp, q, n16, n32, d, S, W, cnt);
+    hipLaunchKernelGGL(k_bge_big<true>, dim3(n12 + n16 + n32 + ng), dim3(256), lds, e->stream, masks, ns, bp, q, n12, n16, n32, d, S, W, cnt);
   } else {
     allow_lds(k_bge_big<false>, lds);
-    hipLaunchKernelGGL(k_bge_big<false>, dim3(n16 + n32 + ng), dim3(256), lds, e->stream, masks, ns, bp, q, n16, n32, d, S, W, cnt);
+    hipLaunchKernelGGL(k_bge_big<false>, dim3(n12 + n16 + n32 + ng), dim3(256), lds, e->stream, masks, ns, bp, q, n12, n16, n32, d, S, W, cnt);
   }
 }
 
@@ -463,10 +464,18 @@ template <int NT>
 static void launch_acyc(dibs_engine* e, Key2 carry, float alpha) {
   constexpr int DP = 16 * NT, LD = DP + 4;
   const size_t lds = (size_t)(3 * DP + 1) * LD * 4;  // + one slack row (the k pipeline may load one step past the end)
-  allow_lds(k_acyc<NT>, lds);
-  hipLaunchKernelGGL(k_acyc<NT>, dim3(e->acyc_nblk, e->Mloc), dim3(256), lds, e->stream, e->scores, e->acyc_part, carry,
-                     e->m0, e->M, e->d, e->Sa, e->acyc_cpb, alpha, (float)e->cfg.tau, e->cfg.rng_layout,
-                     e->cfg.logistic_minval_tiny);
+  const bool paired = e->acyc_units != e->Sa;
+  if (paired) {
+    allow_lds(k_acyc<NT, true>, lds);
+    hipLaunchKernelGGL((k_acyc<NT, true>), dim3(e->acyc_nblk, e->Mloc), dim3(256), lds, e->stream, e->scores, e->acyc_part, carry,
+                       e->m0, e->M, e->d, e->Sa, e->acyc_cpb, alpha, (float)e->cfg.tau, e->cfg.rng_layout,
+                       e->cfg.logistic_minval_tiny);
+  } else {
+    allow_lds(k_acyc<NT, false>, lds);
+    hipLaunchKernelGGL((k_acyc<NT, false>), dim3(e->acyc_nblk, e->Mloc), dim3(256), lds, e->stream, e->scores, e->acyc_part, carry,
+                       e->m0, e->M, e->d, e->Sa, e->acyc_cpb, alpha, (float)e->cfg.tau, e->cfg.rng_layout,
+                       e->cfg.logistic_minval_tiny);
+  }
 }
 
 static int step_local(dibs_engine* e, int t, float* pack) {
@@ -831,6 +840,7 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
     HIP_OK(dalloc(&d_ns, (size_t)d * CH));
     std::vector<uint64_t> hm((size_t)d * CH * W);
     BgeQueues sq;  // scratch queues for this call
+    HIP_OK(dalloc(&sq.list12, (size_t)d * CH));
     HIP_OK(dalloc(&sq.list16, (size_t)d * CH));
     HIP_OK(dalloc(&sq.list32, (size_t)d * CH));
     HIP_OK(dalloc(&sq.listg, (size_t)d * CH));
@@ -861,6 +871,7 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
     }
     hipFree(d_masks);
     hipFree(d_ns);
+    hipFree(sq.list12);
     hipFree(sq.list16);
     hipFree(sq.list32);
     hipFree(sq.listg);

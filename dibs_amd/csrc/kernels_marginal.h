@@ -149,10 +149,11 @@ __device__ __forceinline__ double bge_assemble(const BgeParams& bp, int j, int l
 
 // Work queues for the problems that do not fit the per-lane tier: code = (m * d + j) * S + s.
 struct BgeQueues {
-  uint32_t* list16;      // 9 <= n <= 16
-  uint32_t* list32;      // 17 <= n <= 32
-  uint32_t* listg;       // n > 32
-  unsigned int* counts;  // [3], zeroed before every launch of k_bge_nodes
+  uint32_t* list12;      // 9 <= n <= 12   one problem per lane, registers only (k_bge_big, tier lane<12>)
+  uint32_t* list16;      // 13 <= n <= 16  one problem per lane (tier lane<16>)
+  uint32_t* list32;      // 17 <= n <= 32  32-lane groups, L in LDS
+  uint32_t* listg;       // n > 32         one problem per wave
+  unsigned int* counts;  // [4]: zero at creation, reset by k_lik_weights_score / the scoring path after every use
 };
 
 template <int WAVES, bool SAMPLE>
@@ -192,9 +193,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
   }
   __syncthreads();
   if (!active) return;
-#if defined(BGE_EXP) && BGE_EXP >= 3
-  return;
-#endif
   if (!SAMPLE) {  // scoring of given graphs (dibs_score_graphs): the parent sets come from the caller
     const uint64_t* mg = masks + ((size_t)m * d + j) * S * W;
     for (int e = lane; e < S * W; e += 64) mk[e] = mg[e];
@@ -225,9 +223,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
             const int i1 = d < i0 + 32 ? d : i0 + 32;
             uint32_t A = 0u, B = 0u;
             int i = i0;
-#if defined(BGE_EXP) && BGE_EXP >= 1
-            i = i1;
-#endif
             for (; i + 1 < i1; i += 2, c0 += 2u * (uint32_t)d, c1 += 2u * (uint32_t)d) {
               uint32_t y0, y1, y2, y3;
               threefry2x32_uk2(tk, c0, c1, c0 + (uint32_t)d, c1 + (uint32_t)d, y0, y1, y2, y3);
@@ -285,9 +280,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
     for (int e = lane; e < S * W; e += 64) mg[e] = mk[e];
   }
 
-#if defined(BGE_EXP) && BGE_EXP >= 2
-  return;
-#endif
   const double Nn = bp.Nj[j];
   double* ns_out = node_scores + ((size_t)m * d + j) * S;
   const double score_l0 = bge_assemble(bp, j, 0, d, Nn, 0.0, (double)Rs[j * d + j]);
@@ -344,28 +336,26 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
       flops += (double)n * n * n / 3.0;
     }
     // queue the rest by tier (wave-aggregated atomics; the order inside a queue does not affect any result)
-    const bool t16 = valid && !small && l <= 15, t32 = valid && !small && !t16 && l <= 31, tg = valid && !small && l > 31;
+    const bool big = valid && !small && l > 0;
+    const bool t12 = big && l <= 11, t16 = big && l >= 12 && l <= 15, t32 = big && l >= 16 && l <= 31, tg = big && l > 31;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const uint32_t code = (uint32_t)(((size_t)m * d + j) * S + s);
-    const unsigned long long b16 = __ballot(t16), b32 = __ballot(t32), bg = __ballot(tg);
-    if (b16) {
-      unsigned int base = 0;
-      if (lane == __ffsll((long long)b16) - 1) base = atomicAdd(&qs.counts[0], (unsigned int)__popcll(b16));
-      base = __shfl(base, __ffsll((long long)b16) - 1, 64);
-      if (t16) qs.list16[base + __popcll(b16 & lt)] = code;
+#define BGE_ENQUEUE(FLAG_, IDX_, LIST_)                                                                         \
+    {                                                                                                           \
+      const unsigned long long bal = __ballot(FLAG_);                                                           \
+      if (bal) {                                                                                                \
+        const int leader = __ffsll((long long)bal) - 1;                                                         \
+        unsigned int base = 0;                                                                                  \
+        if (lane == leader) base = atomicAdd(&qs.counts[IDX_], (unsigned int)__popcll(bal));                    \
+        base = __shfl(base, leader, 64);                                                                        \
+        if (FLAG_) LIST_[base + __popcll(bal & lt)] = code;                                                     \
+      }                                                                                                         \
     }
-    if (b32) {
-      unsigned int base = 0;
-      if (lane == __ffsll((long long)b32) - 1) base = atomicAdd(&qs.counts[1], (unsigned int)__popcll(b32));
-      base = __shfl(base, __ffsll((long long)b32) - 1, 64);
-      if (t32) qs.list32[base + __popcll(b32 & lt)] = code;
-    }
-    if (bg) {
-      unsigned int base = 0;
-      if (lane == __ffsll((long long)bg) - 1) base = atomicAdd(&qs.counts[2], (unsigned int)__popcll(bg));
-      base = __shfl(base, __ffsll((long long)bg) - 1, 64);
-      if (tg) qs.listg[base + __popcll(bg & lt)] = code;
-    }
+    BGE_ENQUEUE(t12, 0, qs.list12)
+    BGE_ENQUEUE(t16, 1, qs.list16)
+    BGE_ENQUEUE(t32, 2, qs.list32)
+    BGE_ENQUEUE(tg, 3, qs.listg)
+#undef BGE_ENQUEUE
   }
   if (counters) {
     const double tot = wave_sum_d(flops);
@@ -543,18 +533,79 @@ __device__ __forceinline__ void bge_big_body(unsigned char* smem_raw, const uint
   }
 }
 
-// one launch for the three queues: blocks [0, n16) work on list16 with 16-lane groups, [n16, n16 + n32) on list32, the rest on
-// the generic one-problem-per-wave tier.  In the steady state of a run all queues are empty and every block returns at once;
-// three separate launches cost three launch latencies for nothing.
+// Tier lane<NMAX>: one queued problem per LANE, the whole factorisation in registers (no LDS traffic, no barriers, every lane
+// busy because the queue is dense).  Rows n..NMAX-1 are identity rows, so the unrolled code is the same for every lane.
+template <int NMAX, bool R_LDS>
+__device__ __forceinline__ void bge_lane_body(unsigned char* smem_raw, const uint64_t* __restrict__ masks, double* __restrict__ node_scores,
+                                              const BgeParams& bp, const uint32_t* __restrict__ list, unsigned int cnt, int d, int S, int W,
+                                              unsigned long long* __restrict__ counters, int vblock, int vgrid) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  if ((unsigned int)(vblock * 256) >= cnt) return;  // nothing queued for this block (block-uniform)
+  float* Rs = reinterpret_cast<float*>(smem_raw);
+  if (R_LDS) {
+    for (int e = tid; e < d * d; e += 256) Rs[e] = bp.R[e];
+    __syncthreads();
+  }
+  double flops = 0.0;
+  for (unsigned int q = vblock * 256 + tid; q < cnt; q += vgrid * 256) {
+    const uint32_t code = list[q];
+    const int s = code % S, mj = code / S, j = mj % d;
+    const float* R = R_LDS ? Rs : bp.R + (bp.n_mats > 1 ? (size_t)j * d * d : 0);
+    uint64_t w0 = masks[(size_t)code * W], w1 = W > 1 ? masks[(size_t)code * W + 1] : 0ull;
+    const int l = __popcll(w0) + __popcll(w1), n = l + 1;
+    int idx[NMAX];
+#pragma unroll
+    for (int t = 0; t < NMAX; ++t) {
+      int b = 0;
+      if (w0) { b = __ffsll((long long)w0) - 1; w0 &= w0 - 1; }
+      else if (w1) { b = 64 + __ffsll((long long)w1) - 1; w1 &= w1 - 1; }
+      idx[t] = (t == l) ? j : b;
+    }
+    float A[NMAX][NMAX];
+#pragma unroll
+    for (int r = 0; r < NMAX; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) A[r][c] = (r < n) ? R[idx[r] * d + idx[c]] : (r == c ? 1.0f : 0.0f);
+    double prod = 1.0, schur = 1.0;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      float dk = A[k][k];
+#pragma unroll
+      for (int p = 0; p < k; ++p) dk = fmaf(-A[k][p], A[k][p], dk);
+      if (k < l) prod *= (double)dk;
+      if (k == l) schur = (double)dk;
+      const float inv = rsqrtf(dk);
+#pragma unroll
+      for (int r = k + 1; r < NMAX; ++r) {
+        float v = A[r][k];
+#pragma unroll
+        for (int p = 0; p < k; ++p) v = fmaf(-A[r][p], A[k][p], v);
+        A[r][k] = v * inv;
+      }
+    }
+    node_scores[(size_t)mj * S + s] = bge_assemble(bp, j, l, d, bp.Nj[j], log(prod), schur);
+    flops += (double)n * n * n / 3.0;
+  }
+  if (counters) {
+    const double tot = wave_sum_d(flops);
+    if (lane == 0 && tot > 0.0) atomicAdd(counters, (unsigned long long)tot);
+  }
+}
+
+// one launch for the four queues: consecutive block ranges work on list12 / list16 (one problem per lane), list32 (32-lane
+// groups) and the generic one-problem-per-wave tier.  In the steady state of a run all queues are empty and every block
+// returns at once; separate launches would cost their launch latencies for nothing.
 template <bool R_LDS>
-__global__ __launch_bounds__(256) void k_bge_big(const uint64_t* __restrict__ masks, double* __restrict__ node_scores, BgeParams bp,
-                                                 BgeQueues qs, int n16, int n32, int d, int S, int W,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_bge_big(const uint64_t* __restrict__ masks, double* __restrict__ node_scores, BgeParams bp,
+                                                 BgeQueues qs, int n12, int n16, int n32, int d, int S, int W,
                                                  unsigned long long* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int b = blockIdx.x, ng = gridDim.x - n16 - n32;
-  if (b < n16) bge_big_body<16, R_LDS>(smem_raw, masks, node_scores, bp, qs.list16, qs.counts[0], d, S, W, counters, b, n16);
-  else if (b < n16 + n32) bge_big_body<32, R_LDS>(smem_raw, masks, node_scores, bp, qs.list32, qs.counts[1], d, S, W, counters, b - n16, n32);
-  else bge_big_body<64, R_LDS>(smem_raw, masks, node_scores, bp, qs.listg, qs.counts[2], d, S, W, counters, b - n16 - n32, ng);
+  const int b = blockIdx.x, ng = gridDim.x - n12 - n16 - n32;
+  if (b < n12) bge_lane_body<12, R_LDS>(smem_raw, masks, node_scores, bp, qs.list12, qs.counts[0], d, S, W, counters, b, n12);
+  else if (b < n12 + n16) bge_lane_body<16, R_LDS>(smem_raw, masks, node_scores, bp, qs.list16, qs.counts[1], d, S, W, counters, b - n12, n16);
+  else if (b < n12 + n16 + n32)
+    bge_big_body<32, R_LDS>(smem_raw, masks, node_scores, bp, qs.list32, qs.counts[2], d, S, W, counters, b - n12 - n16, n32);
+  else bge_big_body<64, R_LDS>(smem_raw, masks, node_scores, bp, qs.listg, qs.counts[3], d, S, W, counters, b - n12 - n16 - n32, ng);
 }
 
 // out[s] = sum_j node_scores[j][s]   (scoring of given graphs)
@@ -761,7 +812,7 @@ __device__ __forceinline__ void lds_matmul(float* __restrict__ lds, int c_off, i
   }
 }
 
-template <int NT>
+template <int NT, bool PAIRED>
 __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, float* __restrict__ part, Key2 carry, int m0,
                                               int M_global, int d, int Sa, int cpb, float alpha, float tau, int layout,
                                               int tiny) {
@@ -790,7 +841,7 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
   // chain sa with chain sa + Sa/2 at the same (i, j).  A block therefore takes both chains of a pair (`paired`; the host
   // sizes the grid in pairs) and draws the noise of both with one call per element -- the noise is most of this kernel's
   // VALU work, and VALU work does not overlap with the f32 MFMAs.
-  const bool paired = layout == 0 && (Sa & 1) == 0 && nbits < 0xFFFFFFFFull;
+  constexpr bool paired = PAIRED;  // host: layout == legacy && Sa even && Sa * d * d < 2^32 (one code path per instantiation: SGPR pressure)
   const int n_units = paired ? (Sa >> 1) : Sa;
   const TfKeys tk = tf_keys(km);
   float out[EPT], gnext[EPT];
