@@ -185,6 +185,183 @@ __global__ __launch_bounds__(256) void k_lin_logprobs(const float* __restrict__ 
   }
 }
 
+// Same, for the legacy PRNG layout with an even number of samples and N <= 128: sample s and s + S/2 share their Threefry
+// calls (element e of the [S, d, d] draw is paired with e + S d d / 2), so a block takes both and builds both operands from
+// one call per element.  x does not depend on the sample: every wave keeps its MFMA A fragments (and the x values of its
+// output elements) in registers, so LDS holds the two per-sample operands only (row stride == 16 mod 32: conflict-free
+// B-fragment reads) and four blocks fit on a CU.
+// grid = (ceil(S / 2 / ppb), Mloc), block = 256
+template <int NT>
+__host__ __device__ constexpr int lin_ldw2() { return (NT & 1) ? 16 * NT : 16 * NT + 16; }
+__host__ __device__ inline size_t lin_lds_bytes_pair(int d, int NT) {
+  const int kp = (d + 3) & ~3, ldw2 = (NT & 1) ? 16 * NT : 16 * NT + 16;
+  return (((size_t)2 * kp * ldw2 * 4 + 15) & ~(size_t)15) + 64 * 8;
+}
+// EPQ > 0: every thread owns the elements e = tid + 256 q (q < EPQ, covers d*d <= 256 EPQ) of the d x d operand and keeps
+// their sample-independent factors (theta, logN(theta), exp(-alpha s) or the Bernoulli threshold, LDS offset) in registers
+// for all pairs of the block; EPQ == 0 recomputes them per pair (large d: the registers go to the x fragments instead).
+template <int NT, int EPQ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 4 ? 3 : 1, NT <= 4 ? 3 : 2))) void k_lin_logprobs_pair(const float* __restrict__ x, const int32_t* __restrict__ mask,
+                                                           const float* __restrict__ theta, const float* __restrict__ scores,
+                                                           const uint32_t* __restrict__ thr, float* __restrict__ logprobs, Key2 carry,
+                                                           int mode, int m0, int M_global, int d, int N, int S, int ppb, float alpha,
+                                                           float tau, int layout, int tiny, float obs_noise, float mu, float sig,
+                                                           int any_mask) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LDW = lin_ldw2<NT>(), NU = 2, KSMAX = 4 * NT;
+  const int kp = (d + 3) & ~3, ksteps = kp >> 2, nrt = (N + 15) >> 4;
+  float* WG0 = smem;
+  float* WG1 = WG0 + (size_t)kp * LDW;
+  double* red = reinterpret_cast<double*>(smem + (((size_t)2 * kp * LDW + 3) & ~(size_t)3));
+  const int m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int dd = d * d;
+  const float* __restrict__ TH = theta + (size_t)m * dd;
+  const uint32_t* __restrict__ thr_m = thr + (size_t)m * dd;
+  const float* __restrict__ sc_m = scores + (size_t)m * dd;
+  // A fragments: row n = (wave + 4u) * 16 + (lane & 15), k = 4 ks + (lane >> 4); output elements (C layout):
+  // n = (wave + 4u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15); wgt = 1 where the element counts in the likelihood
+  float xa[NU][KSMAX], xe[NU][NT][4];
+  uint32_t ok[NU];
+  float nvalid = 0.f;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int na = (wave + 4 * u) * 16 + (lane & 15);
+#pragma unroll
+    for (int ks = 0; ks < KSMAX; ++ks) {
+      const int kk = 4 * ks + (lane >> 4);
+      xa[u][ks] = (na < N && kk < d) ? x[(size_t)na * d + kk] : 0.f;
+    }
+    ok[u] = 0u;
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = (wave + 4 * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
+        const bool v = n < N && j < d && !(any_mask && mask[(size_t)n * d + j]);
+        xe[u][tj][r] = v ? x[(size_t)n * d + j] : 0.f;
+        ok[u] |= (uint32_t)v << (tj * 4 + r);
+        nvalid += v ? 1.0f : 0.0f;
+      }
+  }
+  const TfKeys tk = tf_keys(lin_mode_key(mode, carry, M_global, m0 + m, layout));
+  const uint32_t half = (uint32_t)(((uint64_t)S * dd) >> 1);
+  const int hS = S >> 1;
+  const float inv2 = 0.5f / obs_noise;
+  const float lognorm_x = -0.5f * logf(obs_noise) - 0.918938533204672742f;
+  const bool soft = mode == LIN_MODE_Z_REPARAM, fast = tau == 1.0f;
+  const float ulo = tiny ? 1.17549435e-38f : 1.1920929e-07f;
+  const int bq = (lane >> 4) * LDW + (lane & 15);
+  const float inv_d = 1.0f / (float)d;
+  for (int e = tid; e < 2 * kp * LDW; e += 256) smem[e] = 0.f;  // padding and diagonal: written once
+  // sample-independent factors of element e: offset in the operand, theta, logN(theta), aux = exp(-alpha s) | alpha s | thr
+  // (aux carries the Bernoulli threshold's bits in the hard-graph modes)
+  auto factors = [&](int e, int& off, float& th, float& ln, float& aux) {
+    const int i = (int)(((float)e + 0.5f) * inv_d), j = e - i * d;  // exact for e < 2^20
+    off = (i == j) ? -1 : i * LDW + j;
+    th = TH[e];
+    ln = lin_logn(th, mu, sig);
+    if (soft) {
+      const float as = alpha * sc_m[e];
+      aux = fast ? expf(-as) : as;
+    } else {
+      aux = __uint_as_float(thr_m[e]);
+    }
+  };
+  int offs[EPQ > 0 ? EPQ : 1];
+  float ths[EPQ > 0 ? EPQ : 1], lns[EPQ > 0 ? EPQ : 1], auxs[EPQ > 0 ? EPQ : 1];
+  if constexpr (EPQ > 0) {
+#pragma unroll
+    for (int q = 0; q < EPQ; ++q) {
+      const int e = tid + 256 * q;
+      offs[q] = -1;
+      ths[q] = lns[q] = auxs[q] = 0.f;
+      if (e < dd) factors(e, offs[q], ths[q], lns[q], auxs[q]);
+    }
+  }
+  float part[2];
+  // one element of the pair (s0, s0 + S/2): one Threefry call, both operands
+  auto element = [&](int e, uint32_t cbase, int off, float th, float ln, float aux) {
+    if (off < 0) return;
+    uint32_t y0, y1;
+    threefry2x32_uk(tk, cbase + (uint32_t)e, cbase + (uint32_t)e + half, y0, y1);
+    float g0, g1;
+    if (soft) {
+      if (fast) {  // sigmoid(eps + a), eps = log(u / (1 - u))  ==  u / (u + (1 - u) exp(-a))
+        const float u0 = rng_uniform(y0, ulo, 1.0f), u1 = rng_uniform(y1, ulo, 1.0f);
+        g0 = u0 / (u0 + (1.0f - u0) * aux);
+        g1 = u1 / (u1 + (1.0f - u1) * aux);
+      } else {
+        g0 = 1.0f / (1.0f + expf(-tau * (rng_logistic(y0, tiny) + aux)));
+        g1 = 1.0f / (1.0f + expf(-tau * (rng_logistic(y1, tiny) + aux)));
+      }
+    } else {
+      const uint32_t ta = __float_as_uint(aux);
+      g0 = (y0 >> 9) < ta ? 1.0f : 0.0f;
+      g1 = (y1 >> 9) < ta ? 1.0f : 0.0f;
+    }
+    WG0[off] = g0 * th;
+    WG1[off] = g1 * th;
+    part[0] = fmaf(g0, ln, part[0]);
+    part[1] = fmaf(g1, ln, part[1]);
+  };
+  for (int c = 0; c < ppb; ++c) {
+    const int s0 = blockIdx.x * ppb + c;
+    if (s0 >= hS) break;
+    __syncthreads();
+    part[0] = part[1] = nvalid * lognorm_x;
+    const uint32_t cbase = (uint32_t)((uint64_t)s0 * (uint64_t)dd);
+    if constexpr (EPQ > 0) {
+#pragma unroll
+      for (int q = 0; q < EPQ; ++q) element(tid + 256 * q, cbase, offs[q], ths[q], lns[q], auxs[q]);
+    } else {
+      for (int e = tid; e < dd; e += 256) {
+        int off;
+        float th, ln, aux;
+        factors(e, off, th, ln, aux);
+        element(e, cbase, off, th, ln, aux);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int hsel = 0; hsel < 2; ++hsel) {
+      const float* WG = hsel ? WG1 : WG0;
+      float sq = 0.f;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if (wave + 4 * u >= nrt) continue;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) acc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+          if (ks >= ksteps) continue;
+#pragma unroll
+          for (int tj = 0; tj < NT; ++tj)
+            acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][ks], tj * 16 < LDW ? WG[bq + ks * 4 * LDW + tj * 16] : 0.f, acc[tj], 0, 0, 0);
+        }
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pv = acc[tj][r];
+            asm volatile("" : "+v"(pv));
+            const float er = ((ok[u] >> (tj * 4 + r)) & 1u) ? xe[u][tj][r] - pv : 0.f;
+            sq = fmaf(er, er, sq);
+          }
+      }
+      part[hsel] = fmaf(-inv2, sq, part[hsel]);
+    }
+    const double t0 = wave_sum_d((double)part[0]), t1 = wave_sum_d((double)part[1]);
+    if (lane == 0) {
+      red[wave] = t0;
+      red[4 + wave] = t1;
+    }
+    __syncthreads();
+    if (tid == 0) logprobs[(size_t)m * S + s0] = (float)(red[0] + red[1] + red[2] + red[3]);
+    if (tid == 1) logprobs[(size_t)m * S + s0 + hS] = (float)(red[4] + red[5] + red[6] + red[7]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // softmax-weighted gradient: w = softmax(l); only samples with w_s != 0 are re-evaluated (in float the weights of
 // all but a few samples underflow to exactly 0 -- the oracle skips them the same way).
@@ -376,9 +553,29 @@ static void joint_lin_launch(JointWork* w, const JointLaunch& jl, Key2 carry, in
   if (lds1 > 48 * 1024) hipFuncSetAttribute((const void*)k_lin_logprobs<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
   if (lds2 > 48 * 1024) hipFuncSetAttribute((const void*)k_lin_grad<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
   float* lp = mode == LIN_MODE_THETA ? jl.logprobs_th : jl.logprobs_z;
-  hipLaunchKernelGGL(k_lin_logprobs<NT>, dim3((jl.S + spb - 1) / spb, jl.Mloc), dim3(256), lds1, jl.stream, w->x, w->mask, jl.theta,
-                     jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, spb, jl.alpha, jl.tau, jl.layout, jl.tiny,
-                     jl.obs_noise, jl.mean_edge, jl.sig_edge, w->any_mask);
+  const bool paired = jl.layout == 0 && (jl.S & 1) == 0 && (uint64_t)jl.S * jl.d * jl.d < 0xFFFFFFFFull && jl.N <= 128;
+  if (paired) {
+    const int ppb = 4;
+    const size_t ldsp = lin_lds_bytes_pair(jl.d, NT);
+    const dim3 grid((jl.S / 2 + ppb - 1) / ppb, jl.Mloc);
+    const int epq = (jl.d * jl.d + 255) / 256;
+#define LIN_PAIR_LAUNCH(EPQ_)                                                                                                      \
+    {                                                                                                                              \
+      if (ldsp > 48 * 1024) hipFuncSetAttribute((const void*)k_lin_logprobs_pair<NT, EPQ_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp); \
+      hipLaunchKernelGGL((k_lin_logprobs_pair<NT, EPQ_>), grid, dim3(256), ldsp, jl.stream, w->x, w->mask, jl.theta, jl.scores, jl.thr, lp,   \
+                         carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, ppb, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise,         \
+                         jl.mean_edge, jl.sig_edge, w->any_mask);                                                                  \
+    }
+    if (NT <= 4 && epq <= 4) LIN_PAIR_LAUNCH(4)
+    else if (NT <= 4 && epq <= 10) LIN_PAIR_LAUNCH(10)
+    else if (NT <= 4) LIN_PAIR_LAUNCH(16)
+    else LIN_PAIR_LAUNCH(0)
+#undef LIN_PAIR_LAUNCH
+  } else {
+    hipLaunchKernelGGL(k_lin_logprobs<NT>, dim3((jl.S + spb - 1) / spb, jl.Mloc), dim3(256), lds1, jl.stream, w->x, w->mask, jl.theta,
+                       jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, spb, jl.alpha, jl.tau, jl.layout, jl.tiny,
+                       jl.obs_noise, jl.mean_edge, jl.sig_edge, w->any_mask);
+  }
   float* out = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off : jl.w_lik;
   const size_t ostride = mode == LIN_MODE_THETA ? jl.pack_stride : (size_t)jl.d * jl.d;
   float* tcopy = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr;
