@@ -524,7 +524,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     {
       KTimer tm(e, DIBS_K_LIK_WEIGHTS);
       const int ny = e->d < 4 ? e->d : 4;
-      const size_t base = (((size_t)e->S * 28 + 15) & ~(size_t)15);
+      const size_t base = (((size_t)e->S * 36 + 15) & ~(size_t)15);
       const size_t mbytes = (size_t)e->S * ((e->d + ny - 1) / ny) * e->W * 8;
       const int in_lds = base + mbytes <= 64 * 1024;
       const size_t lds = base + (in_lds ? mbytes : 0);

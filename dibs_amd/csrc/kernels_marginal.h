@@ -637,8 +637,11 @@ __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restr
   double* lp = reinterpret_cast<double*>(smem_raw);
   double* lp2 = lp + S;  // [2][S] partial sums
   float* wt = reinterpret_cast<float*>(lp2 + 2 * S);
-  uint64_t* mkl = reinterpret_cast<uint64_t*>(smem_raw + (((size_t)S * 28 + 15) & ~(size_t)15));
+  float* nzw = wt + S;                          // non-zero softmax weights, in sample order ...
+  int* nzi = reinterpret_cast<int*>(nzw + S);   // ... and their sample indices
+  uint64_t* mkl = reinterpret_cast<uint64_t*>(smem_raw + (((size_t)S * 36 + 15) & ~(size_t)15));
   __shared__ double red[8];
+  __shared__ int nnz_s;
   const int m = blockIdx.x, y = blockIdx.y, ny = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ncol = (d - y + ny - 1) / ny;  // columns of this block
   const uint64_t* mg = masks + (size_t)m * d * S * W;  // [j][s][w]
@@ -658,14 +661,20 @@ __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restr
       const int j0 = part * jw, j1 = (j0 + jw < d) ? j0 + jw : d;
       double t = 0.0;
       int j = j0;
-      for (; j + 8 <= j1; j += 8) {
-        double v[8];
+      for (; j + 32 <= j1; j += 32) {  // (far-cache latency: as many loads in flight as registers allow; additions in j order)
+        double v[32];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = nsm[(size_t)(j + u) * S + s];
+        for (int u = 0; u < 32; ++u) v[u] = nsm[(size_t)(j + u) * S + s];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t += v[u];
+        for (int u = 0; u < 32; ++u) t += v[u];
       }
-      for (; j < j1; ++j) t += nsm[(size_t)j * S + s];
+      {
+        double v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = (j + u < j1) ? nsm[(size_t)(j + u) * S + s] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) t += (j + u < j1) ? v[u] : 0.0;
+      }
       lp2[part * S + s] = t;
     }
     __syncthreads();
@@ -698,6 +707,25 @@ __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restr
   for (int s = tid; s < S; s += 256) wt[s] = (float)(exp(lp[s] - mx) / den);
   __syncthreads();
   sm = red[0] + red[1] + red[2] + red[3];
+  // in float most softmax weights are exactly 0 while the particles still differ (one-hot in the limit): only samples with
+  // w_s != 0 are visited, in sample order, so the sum is bit-identical to the full loop
+  if (wave == 0) {
+    int base = 0;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      const int s = s0 + lane;
+      const float w = s < S ? wt[s] : 0.f;
+      const unsigned long long bal = __ballot(w != 0.f);
+      if (w != 0.f) {
+        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+        nzi[pos] = s;
+        nzw[pos] = w;
+      }
+      base += __popcll(bal);
+    }
+    if (lane == 0) nnz_s = base;
+  }
+  __syncthreads();
+  const int nnz = nnz_s;
   const float bold = baseline[m];
   const float scale = sf_baseline > 0.0 ? (float)exp(-(double)bold) : 1.0f;
   for (int e = tid; e < ncol * d; e += 256) {
@@ -708,15 +736,15 @@ __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restr
       const int w = i >> 6;
       const uint64_t bit = 1ull << (i & 63);
       const uint64_t* col = masks_in_lds ? mkl + (size_t)c * S * W : mg + (size_t)j * S * W;
-      int s = 0;
-      for (; s + 8 <= S; s += 8) {  // eight mask words in flight; additions stay in sample order
+      int q = 0;
+      for (; q + 8 <= nnz; q += 8) {  // eight mask words in flight; additions stay in sample order
         uint64_t mw[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) mw[u] = col[(size_t)(s + u) * W + w];
+        for (int u = 0; u < 8; ++u) mw[u] = col[(size_t)nzi[q + u] * W + w];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += (mw[u] & bit) ? wt[s + u] : 0.f;
+        for (int u = 0; u < 8; ++u) acc += (mw[u] & bit) ? nzw[q + u] : 0.f;
       }
-      for (; s < S; ++s) acc += (col[(size_t)s * W + w] & bit) ? wt[s] : 0.f;
+      for (; q < nnz; ++q) acc += (col[(size_t)nzi[q] * W + w] & bit) ? nzw[q] : 0.f;
       out = scale * alpha * (acc - probs[(size_t)m * d * d + i * d + j]);
     }
     w_lik[(size_t)m * d * d + i * d + j] = out;
