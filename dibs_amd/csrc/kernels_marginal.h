@@ -1153,7 +1153,15 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
   const int b_lo = wave * Mq, b_hi = (b_lo + Mq < M) ? b_lo + Mq : M;
   if (ok) {
     int b = b_lo;
-    // the rows come from the far cache levels (~2 us per dependent round trip): 16 rows (32 loads) are issued together
+    // 16 rows (32 loads) are issued together; the FMA loop runs on packed f32 (v_pk_fma_f32: two particles per instruction --
+    // this loop is bound by VALU issue)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[TA / 2], xa2[TA / 2];
+#pragma unroll
+    for (int q2 = 0; q2 < TA / 2; ++q2) {
+      acc2[q2] = f32x2{acc[2 * q2], acc[2 * q2 + 1]};
+      xa2[q2] = f32x2{xa[2 * q2], xa[2 * q2 + 1]};
+    }
     for (; b + 16 <= b_hi; b += 16) {
       float g[16], xb[16];
 #pragma unroll
@@ -1163,16 +1171,22 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
       }
       asm volatile("" ::: "memory");  // keep the 32 loads ahead of the arithmetic (hipcc would interleave them to save VGPRs)
 #pragma unroll
-      for (int u = 0; u < 16; ++u)
+      for (int u = 0; u < 16; ++u) {
+        const f32x2 g2 = f32x2{g[u], g[u]}, xb2 = f32x2{xb[u], xb[u]};
 #pragma unroll
         for (int q4 = 0; q4 < TA / 4; ++q4) {
           const float4 ks = *reinterpret_cast<const float4*>(ksum + (size_t)(b + u) * TA + q4 * 4);
           const float4 kr = *reinterpret_cast<const float4*>(krep + (size_t)(b + u) * TA + q4 * 4);
-          acc[q4 * 4 + 0] = fmaf(-kr.x, xb[u] - xa[q4 * 4 + 0], fmaf(ks.x, g[u], acc[q4 * 4 + 0]));
-          acc[q4 * 4 + 1] = fmaf(-kr.y, xb[u] - xa[q4 * 4 + 1], fmaf(ks.y, g[u], acc[q4 * 4 + 1]));
-          acc[q4 * 4 + 2] = fmaf(-kr.z, xb[u] - xa[q4 * 4 + 2], fmaf(ks.z, g[u], acc[q4 * 4 + 2]));
-          acc[q4 * 4 + 3] = fmaf(-kr.w, xb[u] - xa[q4 * 4 + 3], fmaf(ks.w, g[u], acc[q4 * 4 + 3]));
+          const f32x2 ks_lo = f32x2{ks.x, ks.y}, ks_hi = f32x2{ks.z, ks.w}, kr_lo = f32x2{kr.x, kr.y}, kr_hi = f32x2{kr.z, kr.w};
+          acc2[2 * q4] = __builtin_elementwise_fma(-kr_lo, xb2 - xa2[2 * q4], __builtin_elementwise_fma(ks_lo, g2, acc2[2 * q4]));
+          acc2[2 * q4 + 1] = __builtin_elementwise_fma(-kr_hi, xb2 - xa2[2 * q4 + 1], __builtin_elementwise_fma(ks_hi, g2, acc2[2 * q4 + 1]));
         }
+      }
+    }
+#pragma unroll
+    for (int q2 = 0; q2 < TA / 2; ++q2) {
+      acc[2 * q2] = acc2[q2].x;
+      acc[2 * q2 + 1] = acc2[q2].y;
     }
     for (; b < b_hi; ++b) {
       const float g = pack[(size_t)b * pack_stride + grad_off + i];
