@@ -377,9 +377,16 @@ __host__ __device__ inline size_t bge_big_wave_bytes(int d, int G) {
   const size_t lb = G == 64 ? (size_t)d * (d | 1) : (size_t)(64 / G) * G * (G + 4);
   return (((lb + 3) & ~(size_t)3) * 4 + (size_t)(G == 64 ? 1 : 64 / G) * ilen * 4 + 15) & ~(size_t)15;
 }
+// waves of a block that work in the one-problem-per-wave tier (each needs a d x d factor in LDS): as many as fit next to R
+__host__ __device__ inline int bge_generic_waves(int d, bool r_in_lds) {
+  const size_t r = r_in_lds ? ((((size_t)d * d * 4) + 15) & ~(size_t)15) : 0;
+  const size_t room = (size_t)160 * 1024 - 1024 - r, per = bge_big_wave_bytes(d, 64);
+  const int nw = (int)(room / per);
+  return nw > 4 ? 4 : (nw < 1 ? 1 : nw);
+}
 __host__ __device__ inline size_t bge_big_lds_bytes(int d, int G, bool r_in_lds) {
   const size_t r = r_in_lds ? ((((size_t)d * d * 4) + 15) & ~(size_t)15) : 0;
-  return r + 4 * bge_big_wave_bytes(d, G);
+  return r + (G == 64 ? bge_generic_waves(d, r_in_lds) : 4) * bge_big_wave_bytes(d, G);
 }
 
 template <int G, bool R_LDS>
@@ -387,7 +394,7 @@ __device__ __forceinline__ void bge_big_body(unsigned char* smem_raw, const uint
                                              const BgeParams& bp, const uint32_t* __restrict__ list, unsigned int cnt, int d, int S, int W,
                                              unsigned long long* __restrict__ counters, int vblock, int vgrid) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if ((unsigned int)(vblock * 4 * (G < 64 ? 64 / G : 1)) >= cnt) return;  // nothing queued for this block (block-uniform)
+  if ((unsigned int)(vblock * (G < 64 ? 4 * (64 / G) : 1)) >= cnt) return;  // nothing queued for this block (block-uniform)
   float* Rs = reinterpret_cast<float*>(smem_raw);
   const size_t r_bytes = R_LDS ? ((((size_t)d * d * 4) + 15) & ~(size_t)15) : 0;
   if (R_LDS) {
@@ -470,10 +477,12 @@ __device__ __forceinline__ void bge_big_body(unsigned char* smem_raw, const uint
       }
     }
   } else {
+    const int nw = bge_generic_waves(d, R_LDS);
+    if (wave >= nw) return;  // (no block-wide barrier below this point)
     float* Lb = reinterpret_cast<float*>(wbase);
     int* myidx = reinterpret_cast<int*>(Lb + (((size_t)d * (d | 1) + 3) & ~(size_t)3));
     const int ldl = d | 1;
-    for (unsigned int q = vblock * 4 + wave; q < cnt; q += vgrid * 4) {
+    for (unsigned int q = vblock * nw + wave; q < cnt; q += vgrid * nw) {
       const uint32_t code = list[q];
       const int s = code % S, mj = code / S, j = mj % d;
       const float* R = R_LDS ? Rs : bp.R + (bp.n_mats > 1 ? (size_t)j * d * d : 0);

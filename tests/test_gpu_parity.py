@@ -60,18 +60,22 @@ def test_init_particles_matches_oracle(c_oracle64):
         eng.close()
 
 
-@pytest.mark.parametrize("d,M,S,Sa,prior,steps", [
-    (5, 4, 128, 32, "er", (0, 1, 5)),
-    (5, 3, 17, 5, "sf", (0, 2)),          # odd S / Sa: unpaired Threefry path
-    (20, 8, 128, 32, "er", (0, 3)),
-    (20, 4, 64, 16, "uniform", (1,)),
-    (50, 4, 128, 32, "er", (0, 2)),
-    (70, 2, 32, 8, "er", (1,)),           # > 64 variables: two mask words, 80x80 MFMA tiles
+@pytest.mark.parametrize("d,M,S,Sa,prior,steps,layout", [
+    (5, 4, 128, 32, "er", (0, 1, 5), "legacy"),
+    (5, 3, 17, 5, "sf", (0, 2), "legacy"),          # odd S / Sa: unpaired Threefry path
+    (20, 8, 128, 32, "er", (0, 3), "legacy"),
+    (20, 4, 64, 16, "uniform", (1,), "legacy"),
+    (50, 4, 128, 32, "er", (0, 2), "legacy"),
+    (70, 2, 32, 8, "er", (1,), "legacy"),           # > 64 variables: two mask words, 80x80 MFMA tiles
+    (112, 2, 16, 4, "er", (1,), "legacy"),          # engine maximum: 112x112 tiles, every BGe tier up to the one-problem-per-wave one
+    (3, 1, 4, 2, "uniform", (0, 1), "legacy"),      # smallest sensible problem, a single particle
+    (20, 5, 32, 8, "er", (2,), "partitionable"),   # jax_threefry_partitionable=True streams (no call pairing)
+    (5, 3, 16, 4, "sf", (0, 1), "partitionable"),
 ])
-def test_marginal_bge_step_stages(c_oracle64, d, M, S, Sa, prior, steps):
+def test_marginal_bge_step_stages(c_oracle64, d, M, S, Sa, prior, steps, layout):
     data, _, _ = make_data(d, seed=0)
     cfg = make_config(n_vars=d, n_particles=M, n_observations=100, edges_per_node=1 if d <= 5 else 2, graph_prior=prior,
-                      n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa)
+                      n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa, rng_layout=layout)
     st = c_oracle64.new_state(cfg, prng.PRNGKey(1))
     eng = _engine(cfg, data.x)
     for t in steps:
