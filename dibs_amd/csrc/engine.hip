@@ -12,6 +12,7 @@
 #include "kernels_marginal.h"
 #include "kernels_joint.h"
 #include "kernels_nn.h"
+#include "kernels_bge_soft.h"
 
 #define LDS_LIMIT ((size_t)160 * 1024)
 static thread_local std::string g_err;
@@ -42,7 +43,8 @@ struct dibs_engine {
   float* R;
   double *gam, *Nj;
   int n_mats;
-  double alpha_lambd;
+  double alpha_lambd, bge_alpha_mu, bge_log_t;
+  float* soft_ds;  // [Mloc, S, d, d]  BGe reparam estimator: per-sample score-space gradients
   bool has_data;
   // work
   float *scores, *probs, *w_tot, *w_lik, *acyc_part, *w_acyc, *logprobs_z, *logprobs_th, *pack, *kz, *kt, *phi_z, *phi_th;
@@ -110,8 +112,11 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
     return fail("MarginalDiBS needs a marginal likelihood (BGe)");
   if (c.joint && c.likelihood == DIBS_LIK_BGE)
     return fail("JointDiBS + BGe is not constructible (BGe has no parameters; linearGaussian.py:53-54)");
-  if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z != DIBS_EST_SCORE)
-    return fail("BGe + reparam estimator not supported yet");
+  if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_REPARAM) {
+    // soft-graph BGe (kernels_bge_soft.h): one matrix row per lane, d x d factor and solution block per wave in LDS
+    if (c.n_vars > 64 || bge_soft_waves(c.n_vars, false) < 1)
+      return fail("BGe + reparam estimator: n_vars must be <= 64 on the device");
+  }
   if (c.likelihood == DIBS_LIK_DENSENN) {
     if (c.nn_n_hidden != 1) return fail("DenseNonlinearGaussian: exactly one hidden layer is supported on the device");
     if (c.nn_hidden[0] < 1 || c.nn_hidden[0] > 64) return fail("DenseNonlinearGaussian: hidden width must be in [1, 64]");
@@ -223,6 +228,7 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
     HIP_OK(dalloc(&e->bq.list32, Ml * e->S * e->d));
     HIP_OK(dalloc(&e->bq.listg, Ml * e->S * e->d));
     HIP_OK(dalloc(&e->bq.counts, (size_t)4));
+    if (c.grad_estimator_z == DIBS_EST_REPARAM) HIP_OK(dalloc(&e->soft_ds, Ml * e->S * dd));
   }
   if (c.joint) {
     if (joint_alloc(&e->jw, e->Mloc, e->d, e->N, e->S) != 0) return fail("joint work buffers: hipMalloc failed");
@@ -238,7 +244,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->w_tot, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
-                  e->node_scores, e->x, e->mask, e->R, e->gam, e->Nj, e->bq.list12, e->bq.list16, e->bq.list32, e->bq.listg, e->bq.counts};
+                  e->node_scores, e->x, e->mask, e->R, e->gam, e->Nj, e->bq.list12, e->bq.list16, e->bq.list32, e->bq.listg, e->bq.counts, e->soft_ds};
   for (void* p : ptrs)
     if (p) hipFree(p);
   joint_free(&e->jw);
@@ -261,6 +267,8 @@ static int bge_prepare(dibs_engine* e, const float* x, const int32_t* mask, cons
   e->alpha_lambd = e->cfg.bge_alpha_lambd > 0 ? e->cfg.bge_alpha_lambd : d + 2.0;
   if (!(e->alpha_lambd > d + 1)) return fail("BGe: alpha_lambd must be > n_vars + 1");  // linearGaussian.py:47
   const double small_t = amu * (e->alpha_lambd - d - 1) / (amu + 1);
+  e->bge_alpha_mu = amu;
+  e->bge_log_t = log(small_t);
   bool any = false;
   if (mask)
     for (int64_t i = 0; i < (int64_t)N * d; ++i) any |= mask[i] != 0;
@@ -501,7 +509,28 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     hipLaunchKernelGGL(k_edge_scores, dim3(e->Mloc), dim3(256), lds, e->stream, e->z, e->scores, e->thr, e->probs, alpha, e->d, e->k,
                        e->dpad, e->ldk);
   }
-  if (c.likelihood == DIBS_LIK_BGE) {
+  if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_REPARAM) {
+    const BgeSoftParams sp{e->R, e->Nj, e->alpha_lambd, e->bge_alpha_mu, e->bge_log_t, e->n_mats};
+    {
+      KTimer tm(e, DIBS_K_BGE_NODES);
+      const bool rl = e->n_mats == 1 && bge_soft_waves(e->d, true) >= 1;
+      const size_t lds = bge_soft_lds_bytes(e->d, rl);
+      if (rl) {
+        allow_lds(k_bge_soft<true>, lds);
+        hipLaunchKernelGGL(k_bge_soft<true>, dim3(e->S, e->Mloc), dim3(256), lds, e->stream, e->scores, sp, carry_lik, e->m0, e->M, e->d,
+                           e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny, e->soft_ds, e->logprobs_z);
+      } else {
+        allow_lds(k_bge_soft<false>, lds);
+        hipLaunchKernelGGL(k_bge_soft<false>, dim3(e->S, e->Mloc), dim3(256), lds, e->stream, e->scores, sp, carry_lik, e->m0, e->M, e->d,
+                           e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny, e->soft_ds, e->logprobs_z);
+      }
+    }
+    {
+      KTimer tm(e, DIBS_K_LIK_WEIGHTS);
+      hipLaunchKernelGGL(k_soft_combine, dim3(e->Mloc), dim3(256), (size_t)e->S * 4 + 16, e->stream, e->soft_ds, e->logprobs_z, e->w_lik,
+                         e->d, e->S);
+    }
+  } else if (c.likelihood == DIBS_LIK_BGE) {
     BgeParams bp{e->R, e->gam, e->Nj, e->alpha_lambd, e->n_mats};
     unsigned long long* cnt = e->profiling ? e->counters : (unsigned long long*)nullptr;
     {  // (queue counters: zero at creation, reset by k_lik_weights_score at the end of every step)
