@@ -506,7 +506,8 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     KTimer tm(e, DIBS_K_EDGE);
     const size_t lds = (size_t)2 * e->dpad * e->ldk * 4;
     allow_lds(k_edge_scores, lds);
-    hipLaunchKernelGGL(k_edge_scores, dim3(e->Mloc), dim3(256), lds, e->stream, e->z, e->scores, e->thr, e->probs, alpha, e->d, e->k,
+    const int ntile = (e->dpad / 16) * (e->dpad / 16);
+    hipLaunchKernelGGL(k_edge_scores, dim3(e->Mloc, ntile >= 16 ? 4 : (ntile >= 8 ? 2 : 1)), dim3(256), lds, e->stream, e->z, e->scores, e->thr, e->probs, alpha, e->d, e->k,
                        e->dpad, e->ldk);
   }
   if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_REPARAM) {
@@ -633,14 +634,15 @@ static int step_update(dibs_engine* e, int t, const float* pack) {
   const dibs_config& c = e->cfg;
   {
     KTimer tm(e, DIBS_K_KMAT);
+    const int ksym = e->Mloc == e->M;  // single rank: the slab is the whole (symmetric) matrix
     auto kmat_lds = [](size_t len) { return (size_t)(((len < KMAT_CH ? len : (size_t)KMAT_CH) + 3) & ~(size_t)3) * 4; };
     allow_lds(k_kmat, kmat_lds(e->D > e->P ? e->D : e->P));
     const dim3 kg(e->Mloc, (e->M + KMAT_BT - 1) / KMAT_BT);
     hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->D), e->stream, pack, (size_t)e->E, (size_t)0,
-                       (int)e->D, e->kz, e->m0, e->M, (float)c.scale_latent, (float)c.h_latent);
+                       (int)e->D, e->kz, e->m0, e->M, (float)c.scale_latent, (float)c.h_latent, ksym);
     if (c.joint)
       hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->P), e->stream, pack, (size_t)e->E,
-                         (size_t)(2 * e->D), (int)e->P, e->kt, e->m0, e->M, (float)c.scale_theta, (float)c.h_theta);
+                         (size_t)(2 * e->D), (int)e->P, e->kt, e->m0, e->M, (float)c.scale_theta, (float)c.h_theta, ksym);
   }
   {
     KTimer tm(e, DIBS_K_PHI_UPDATE);

@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256) void k_edge_scores(const float* __restrict__ z
   __syncthreads();
   const int nt = dpad >> 4;
   const int kp = (k + 3) & ~3;
-  for (int t = wave; t < nt * nt; t += 4) {
+  // tiles are dealt out over the waves of the gridDim.y blocks of this particle (the epilogue's double-precision sigmoid
+  // is most of the work: more blocks, shorter critical path)
+  for (int t = blockIdx.y * 4 + wave; t < nt * nt; t += 4 * gridDim.y) {
     const int ti = t / nt, tj = t - ti * nt;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const float* ua = Us + (size_t)(ti * 16 + (lane & 15)) * ldk + (lane >> 4);
@@ -1059,10 +1061,13 @@ __global__ __launch_bounds__(256) void k_zgrad(const float* __restrict__ z, cons
 #define KMAT_BT 16
 #define KMAT_CH 32768  // floats of z_a staged in LDS at a time (128 KiB); longer vectors (DenseNN theta at d = 100) go in chunks
 __global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, size_t pack_stride, size_t seg_off, int len,
-                                              float* __restrict__ kout, int m0, int M, float scale, float h) {
+                                              float* __restrict__ kout, int m0, int M, float scale, float h, int symmetric) {
   // block (a, bt): particle a (local) against b = bt * KMAT_BT .. +KMAT_BT-1; wave w takes b = b0 + w, b0 + w + 4, ...
+  // symmetric (one rank holds all particles): tiles below the diagonal are skipped and k[a][b] is mirrored into k[b][a]
+  // -- the sum of squared differences is the same number either way, so the slab is bit-identical to the full computation.
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int a = blockIdx.x, b0 = blockIdx.y * KMAT_BT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (symmetric && b0 + KMAT_BT - 1 < a) return;
   const float* za = pack + (size_t)(m0 + a) * pack_stride + seg_off;
   double acc[KMAT_BT / 4];
 #pragma unroll
@@ -1074,42 +1079,68 @@ __global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, si
     for (int e = tid; e < len4; e += 256) reinterpret_cast<float4*>(smem)[e] = reinterpret_cast<const float4*>(za + c0)[e];
     for (int e = (len4 << 2) + tid; e < clen; e += 256) smem[e] = za[c0 + e];
     __syncthreads();
+    // the wave's four b rows advance together: 8 independent 16-byte loads in flight per lane and pass (the kernel is
+    // bound by the latency of the far cache levels, not by their bandwidth)
+    const float4* zb4[KMAT_BT / 4];
+    const float* zbs[KMAT_BT / 4];
 #pragma unroll
     for (int q = 0; q < KMAT_BT / 4; ++q) {
       const int b = b0 + wave + 4 * q;
-      if (b >= M) continue;
-      const float* zb = pack + (size_t)b * pack_stride + seg_off + c0;
-      const float4* zb4 = reinterpret_cast<const float4*>(zb);
-      const float4* za4 = reinterpret_cast<const float4*>(smem);
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      int e = lane;
-      for (; e + 192 < len4; e += 256) {
-        const float4 q0 = zb4[e], q1 = zb4[e + 64], q2 = zb4[e + 128], q3 = zb4[e + 192];
-        const float4 p0 = za4[e], p1 = za4[e + 64], p2 = za4[e + 128], p3 = za4[e + 192];
-        float t;
-        t = p0.x - q0.x; s0 = fmaf(t, t, s0); t = p0.y - q0.y; s0 = fmaf(t, t, s0); t = p0.z - q0.z; s0 = fmaf(t, t, s0); t = p0.w - q0.w; s0 = fmaf(t, t, s0);
-        t = p1.x - q1.x; s1 = fmaf(t, t, s1); t = p1.y - q1.y; s1 = fmaf(t, t, s1); t = p1.z - q1.z; s1 = fmaf(t, t, s1); t = p1.w - q1.w; s1 = fmaf(t, t, s1);
-        t = p2.x - q2.x; s2 = fmaf(t, t, s2); t = p2.y - q2.y; s2 = fmaf(t, t, s2); t = p2.z - q2.z; s2 = fmaf(t, t, s2); t = p2.w - q2.w; s2 = fmaf(t, t, s2);
-        t = p3.x - q3.x; s3 = fmaf(t, t, s3); t = p3.y - q3.y; s3 = fmaf(t, t, s3); t = p3.z - q3.z; s3 = fmaf(t, t, s3); t = p3.w - q3.w; s3 = fmaf(t, t, s3);
-      }
-      for (; e < len4; e += 64) {
-        const float4 q0 = zb4[e], p0 = za4[e];
-        float t;
-        t = p0.x - q0.x; s0 = fmaf(t, t, s0); t = p0.y - q0.y; s0 = fmaf(t, t, s0); t = p0.z - q0.z; s0 = fmaf(t, t, s0); t = p0.w - q0.w; s0 = fmaf(t, t, s0);
-      }
-      for (int e1 = (len4 << 2) + lane; e1 < clen; e1 += 64) {
-        const float t = smem[e1] - zb[e1];
-        s1 = fmaf(t, t, s1);
-      }
-      acc[q] += (double)s0 + (double)s1 + (double)s2 + (double)s3;
+      zbs[q] = pack + (size_t)(b < M ? b : M - 1) * pack_stride + seg_off + c0;  // rows past the end repeat the last one
+      zb4[q] = reinterpret_cast<const float4*>(zbs[q]);
     }
+    const float4* za4 = reinterpret_cast<const float4*>(smem);
+    float s0[KMAT_BT / 4], s1[KMAT_BT / 4];
+#pragma unroll
+    for (int q = 0; q < KMAT_BT / 4; ++q) s0[q] = s1[q] = 0.f;
+    int e = lane;
+    for (; e + 64 < len4; e += 128) {
+      float4 qa[KMAT_BT / 4], qb[KMAT_BT / 4];
+#pragma unroll
+      for (int q = 0; q < KMAT_BT / 4; ++q) {
+        qa[q] = zb4[q][e];
+        qb[q] = zb4[q][e + 64];
+      }
+      const float4 pa = za4[e], pb = za4[e + 64];
+#pragma unroll
+      for (int q = 0; q < KMAT_BT / 4; ++q) {
+        float t;
+        t = pa.x - qa[q].x; s0[q] = fmaf(t, t, s0[q]); t = pa.y - qa[q].y; s0[q] = fmaf(t, t, s0[q]);
+        t = pa.z - qa[q].z; s0[q] = fmaf(t, t, s0[q]); t = pa.w - qa[q].w; s0[q] = fmaf(t, t, s0[q]);
+        t = pb.x - qb[q].x; s1[q] = fmaf(t, t, s1[q]); t = pb.y - qb[q].y; s1[q] = fmaf(t, t, s1[q]);
+        t = pb.z - qb[q].z; s1[q] = fmaf(t, t, s1[q]); t = pb.w - qb[q].w; s1[q] = fmaf(t, t, s1[q]);
+      }
+    }
+    for (; e < len4; e += 64) {
+      const float4 pa = za4[e];
+#pragma unroll
+      for (int q = 0; q < KMAT_BT / 4; ++q) {
+        const float4 qa = zb4[q][e];
+        float t;
+        t = pa.x - qa.x; s0[q] = fmaf(t, t, s0[q]); t = pa.y - qa.y; s0[q] = fmaf(t, t, s0[q]);
+        t = pa.z - qa.z; s0[q] = fmaf(t, t, s0[q]); t = pa.w - qa.w; s0[q] = fmaf(t, t, s0[q]);
+      }
+    }
+    for (int e1 = (len4 << 2) + lane; e1 < clen; e1 += 64) {
+#pragma unroll
+      for (int q = 0; q < KMAT_BT / 4; ++q) {
+        const float t = smem[e1] - zbs[q][e1];
+        s1[q] = fmaf(t, t, s1[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < KMAT_BT / 4; ++q) acc[q] += (double)s0[q] + (double)s1[q];
   }
 #pragma unroll
   for (int q = 0; q < KMAT_BT / 4; ++q) {
     const int b = b0 + wave + 4 * q;
     if (b >= M) continue;
     const double tot = wave_sum_d(acc[q]);
-    if (lane == 0) kout[(size_t)a * M + b] = (float)((double)scale * exp(-tot / (double)h));
+    if (lane == 0) {
+      const float kv = (float)((double)scale * exp(-tot / (double)h));
+      kout[(size_t)a * M + b] = kv;
+      if (symmetric && b > a) kout[(size_t)b * M + a] = kv;
+    }
   }
 }
 

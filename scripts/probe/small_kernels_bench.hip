@@ -33,7 +33,7 @@ int main() {
   {
     hipFuncSetAttribute((const void*)k_kmat, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const size_t lds = (size_t)((D + 3) & ~3) * 4;
-    const float t = time_us([&] { hipLaunchKernelGGL(k_kmat, dim3(M, M / KMAT_BT), dim3(256), lds, 0, pack, (size_t)E, (size_t)0, D, kz, 0, M, 1.0f, 5.0f); });
+    const float t = time_us([&] { hipLaunchKernelGGL(k_kmat, dim3(M, M / KMAT_BT), dim3(256), lds, 0, pack, (size_t)E, (size_t)0, D, kz, 0, M, 1.0f, 5.0f, 1); });
     printf("k_kmat            %7.2f us\n", t);
   }
   {
