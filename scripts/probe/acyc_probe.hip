@@ -8,15 +8,15 @@ static void mm(const std::vector<double>& a, const std::vector<double>& b, std::
 }
 template <int NT> void run(int d, int grid_y) {
   constexpr int DP = 16 * NT, LD = DP + 4;
-  const int Sa = 4, cpb = 4;
+  const int Sa = 4, cpb = 2;   // paired kernel: a work unit is the chain pair (sa, sa + Sa/2); 2 units cover Sa = 4
   std::vector<float> scores((size_t)grid_y * d * d, 0.f), part((size_t)grid_y * d * d);
   float *ds, *dp; hipMalloc(&ds, scores.size()*4); hipMalloc(&dp, part.size()*4);
   hipMemcpy(ds, scores.data(), scores.size()*4, hipMemcpyHostToDevice);
   hipMemset(dp, 0, part.size()*4);
   size_t lds = (3 * DP + 1) * LD * 4;
-  hipFuncSetAttribute((const void*)k_acyc<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void*)k_acyc<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   Key2 carry{123u, 456u};
-  hipLaunchKernelGGL(k_acyc<NT>, dim3(1, grid_y), dim3(256), lds, 0, ds, dp, carry, 0, grid_y, d, Sa, cpb, 1.0f, 1.0f, 0, 0);
+  hipLaunchKernelGGL((k_acyc<NT, true>), dim3(1, grid_y), dim3(256), lds, 0, ds, dp, carry, 0, grid_y, d, Sa, cpb, 1.0f, 1.0f, 0, 0);
   hipError_t e2 = hipDeviceSynchronize();
   hipMemcpy(part.data(), dp, part.size()*4, hipMemcpyDeviceToHost);
   // CPU reference for particle 0
