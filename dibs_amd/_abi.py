@@ -15,8 +15,8 @@ ACT = {"relu": 0, "tanh": 1, "sigmoid": 2, "leakyrelu": 3}
 BUF = dict(Z=0, V_Z=1, THETA=2, V_THETA=3, SCORES=4, LOGPROBS_Z=5, W_LIK=6, W_ACYC=7, GRAD_Z=8,
            GRAD_THETA=9, KXX=10, PHI_Z=11, BASELINE=12, NODE_SCORES=13, PARENT_MASKS=14,
            LOGPROBS_THETA=15, PHI_THETA=16, GATHER=17)
-KERNELS = ["edge", "bge_nodes", "lik_weights", "acyc", "zgrad", "kmat", "phi_update", "lin_theta",
-           "lin_z", "nn_theta", "nn_z", "pack", "bge_big", "wtotal", "k14", "k15"]
+KERNELS = ["edge", "bge_nodes", "lik_weights", "acyc", "zgrad", "kmat", "phi_update", "lin_logprobs",
+           "lin_grad", "nn_theta", "nn_z", "pack", "bge_big", "wtotal", "k14", "k15"]
 K_COUNT = 16
 
 

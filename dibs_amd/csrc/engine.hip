@@ -570,12 +570,12 @@ static int step_local(dibs_engine* e, int t, float* pack) {
                    e->N, e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny, c.grad_estimator_z, c.score_function_baseline,
                    (float)c.lin_obs_noise, (float)c.lin_mean_edge, (float)c.lin_sig_edge};
     {
-      KTimer tm(e, DIBS_K_LIN_THETA);
-      joint_lin_theta(&e->jw, jl, carry_theta);
+      KTimer tm(e, DIBS_K_LIN_THETA);  // ("lin_logprobs": both log-prob launches)
+      joint_lin_all_logprobs(&e->jw, jl, carry_theta, carry_lik);
     }
     {
-      KTimer tm(e, DIBS_K_LIN_Z);
-      joint_lin_z(&e->jw, jl, carry_lik);
+      KTimer tm(e, DIBS_K_LIN_Z);      // ("lin_grad": the theta and the Z estimator in one launch)
+      joint_lin_all_grads(&e->jw, jl, carry_theta, carry_lik);
       std::swap(e->baseline, e->baseline2);
     }
   } else if (c.likelihood == DIBS_LIK_DENSENN) {

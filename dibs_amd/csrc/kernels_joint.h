@@ -370,15 +370,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 4 ? 3
 //   mode Z_SCORE   : W = scale * alpha (sum_s w_s G_s - P), off-diagonal                                 -> w_lik
 // grid = Mloc, block = 256
 // ------------------------------------------------------------------------------------------------
+// one estimator's inputs / outputs; the theta and the Z estimator of a step run as blockIdx.y = 0 / 1 of ONE launch (each has
+// only Mloc blocks -- half the CUs -- and they are independent once both sets of log-probs exist)
+struct LinGradJob {
+  const float* logprobs;
+  float* out;
+  size_t out_stride;
+  float* theta_copy;
+  float* baseline_out;
+  Key2 carry;
+  int mode;
+};
 template <int NT>
 __global__ __launch_bounds__(256) void k_lin_grad(const float* __restrict__ x, const int32_t* __restrict__ mask,
                                                   const float* __restrict__ theta, const float* __restrict__ scores,
-                                                  const uint32_t* __restrict__ thr, const float* __restrict__ logprobs,
-                                                  float* __restrict__ out, size_t out_stride, float* __restrict__ theta_copy,
-                                                  const float* __restrict__ baseline, float* __restrict__ baseline_out,
-                                                  Key2 carry, int mode, int m0, int M_global, int d, int N, int S, float alpha,
-                                                  float tau, int layout, int tiny, float obs_noise, float mu, float sig,
+                                                  const uint32_t* __restrict__ thr, LinGradJob job0, LinGradJob job1,
+                                                  const float* __restrict__ baseline, int m0, int M_global, int d, int N, int S,
+                                                  float alpha, float tau, int layout, int tiny, float obs_noise, float mu, float sig,
                                                   double sf_baseline, int any_mask) {
+  const LinGradJob job = blockIdx.y ? job1 : job0;
+  const float* __restrict__ logprobs = job.logprobs;
+  float* __restrict__ out = job.out;
+  const size_t out_stride = job.out_stride;
+  float* __restrict__ theta_copy = job.theta_copy;
+  float* __restrict__ baseline_out = job.baseline_out;
+  const Key2 carry = job.carry;
+  const int mode = job.mode;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const LinGeom g = lin_geom(d, N, NT);
   float* X = smem;
@@ -547,11 +564,10 @@ static inline int joint_set_data(JointWork* w, const float* x, const int32_t* ma
 }
 
 template <int NT>
-static void joint_lin_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode) {
+static void joint_lin_logprobs(JointWork* w, const JointLaunch& jl, Key2 carry, int mode) {
   const int spb = 4;
-  const size_t lds1 = lin_lds_bytes(jl.d, jl.N, NT, false), lds2 = lin_lds_bytes(jl.d, jl.N, NT, true);
+  const size_t lds1 = lin_lds_bytes(jl.d, jl.N, NT, false);
   if (lds1 > 48 * 1024) hipFuncSetAttribute((const void*)k_lin_logprobs<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-  if (lds2 > 48 * 1024) hipFuncSetAttribute((const void*)k_lin_grad<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
   float* lp = mode == LIN_MODE_THETA ? jl.logprobs_th : jl.logprobs_z;
   const bool paired = jl.layout == 0 && (jl.S & 1) == 0 && (uint64_t)jl.S * jl.d * jl.d < 0xFFFFFFFFull && jl.N <= 128;
   if (paired) {
@@ -576,27 +592,42 @@ static void joint_lin_launch(JointWork* w, const JointLaunch& jl, Key2 carry, in
                        jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, spb, jl.alpha, jl.tau, jl.layout, jl.tiny,
                        jl.obs_noise, jl.mean_edge, jl.sig_edge, w->any_mask);
   }
-  float* out = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off : jl.w_lik;
-  const size_t ostride = mode == LIN_MODE_THETA ? jl.pack_stride : (size_t)jl.d * jl.d;
-  float* tcopy = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr;
-  hipLaunchKernelGGL(k_lin_grad<NT>, dim3(jl.Mloc), dim3(256), lds2, jl.stream, w->x, w->mask, jl.theta, jl.scores, jl.thr, lp, out,
-                     ostride, tcopy, jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode, jl.m0,
-                     jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise, jl.mean_edge, jl.sig_edge,
-                     jl.sf_baseline, w->any_mask);
 }
 
-static inline void joint_lin_dispatch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode) {
-  switch ((jl.d + 15) / 16) {
-    case 1: joint_lin_launch<1>(w, jl, carry, mode); break;
-    case 2: joint_lin_launch<2>(w, jl, carry, mode); break;
-    case 3: joint_lin_launch<3>(w, jl, carry, mode); break;
-    case 4: joint_lin_launch<4>(w, jl, carry, mode); break;
-    case 5: joint_lin_launch<5>(w, jl, carry, mode); break;
-    case 6: joint_lin_launch<6>(w, jl, carry, mode); break;
-    default: joint_lin_launch<7>(w, jl, carry, mode); break;
+template <int NT>
+static void joint_lin_grads(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z) {
+  const size_t lds2 = lin_lds_bytes(jl.d, jl.N, NT, true);
+  if (lds2 > 48 * 1024) hipFuncSetAttribute((const void*)k_lin_grad<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+  const LinGradJob jt{jl.logprobs_th, jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off, jl.pack_stride,
+                      jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off, nullptr, carry_theta, LIN_MODE_THETA};
+  const LinGradJob jz{jl.logprobs_z, jl.w_lik, (size_t)jl.d * jl.d, nullptr, jl.baseline_out, carry_z,
+                      jl.est_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM};
+  hipLaunchKernelGGL(k_lin_grad<NT>, dim3(jl.Mloc, 2), dim3(256), lds2, jl.stream, w->x, w->mask, jl.theta, jl.scores, jl.thr, jt, jz,
+                     jl.baseline, jl.m0, jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise, jl.mean_edge,
+                     jl.sig_edge, jl.sf_baseline, w->any_mask);
+}
+
+#define LIN_NT_SWITCH(CALL_)                 \
+  switch ((jl.d + 15) / 16) {                \
+    case 1: CALL_(1); break;                 \
+    case 2: CALL_(2); break;                 \
+    case 3: CALL_(3); break;                 \
+    case 4: CALL_(4); break;                 \
+    case 5: CALL_(5); break;                 \
+    case 6: CALL_(6); break;                 \
+    default: CALL_(7); break;                \
   }
+// log p(theta, D | G_s) for the samples of the theta estimator and of the Z estimator (two launches)
+static inline void joint_lin_all_logprobs(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z) {
+  const int mz = jl.est_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM;
+#define LIN_CALL(NT_) { joint_lin_logprobs<NT_>(w, jl, carry_theta, LIN_MODE_THETA); joint_lin_logprobs<NT_>(w, jl, carry_z, mz); }
+  LIN_NT_SWITCH(LIN_CALL)
+#undef LIN_CALL
 }
-static inline void joint_lin_theta(JointWork* w, const JointLaunch& jl, Key2 carry) { joint_lin_dispatch(w, jl, carry, LIN_MODE_THETA); }
-static inline void joint_lin_z(JointWork* w, const JointLaunch& jl, Key2 carry) {
-  joint_lin_dispatch(w, jl, carry, jl.est_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM);
+// both softmax-weighted gradients in one launch
+static inline void joint_lin_all_grads(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z) {
+#define LIN_CALL(NT_) joint_lin_grads<NT_>(w, jl, carry_theta, carry_z)
+  LIN_NT_SWITCH(LIN_CALL)
+#undef LIN_CALL
 }
+#undef LIN_NT_SWITCH
