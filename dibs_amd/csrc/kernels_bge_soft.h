@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scor
           acc = dlt + p_r * pv[kk] * (R[r * d + kk] - dlt);
           const float* lr = L + (size_t)r * ldl;
           const float* lk = L + (size_t)kk * ldl;
-          for (int q = 0; q < kk; ++q) acc = fmaf(-lr[q], lk[q], acc);
+#pragma unroll 8
+          for (int q = 0; q < kk; ++q) acc = fmaf(-lr[q], lk[q], acc);  // (unrolled: the LDS reads of several terms in flight)
         }
         const float piv = __shfl(acc, kk, 64);
         const float inv = rsqrtf(piv);
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scor
           const float dlt = (k == r && r != j) ? 1.f : 0.f;
           float v = pv[k] * (R[r * d + k] - dlt);
           const float* lk = L + (size_t)k * ldl;
+#pragma unroll 8
           for (int q = 0; q < k; ++q) v = fmaf(-lk[q], U[q * 64 + lane], v);
           U[k * 64 + lane] = v * dinv[k];
         }
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scor
         const int stop = r == j ? 0 : r;
         for (int k = d - 1; k >= stop; --k) {
           float v = U[k * 64 + lane];
+#pragma unroll 8
           for (int q = k + 1; q < d; ++q) v = fmaf(-L[(size_t)q * ldl + k], U[q * 64 + lane], v);
           U[k * 64 + lane] = v * dinv[k];
         }
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scor
       wave_lds_fence();
       float t_r = 0.f;
       if (act) {
+#pragma unroll 8
         for (int b = 0; b < d; ++b) t_r = fmaf(R[r * d + b] - (b == r ? 1.f : 0.f), pv[b] * yv[b], t_r);
         t_r -= R[j * d + r];
       }
