@@ -82,9 +82,9 @@ __device__ __forceinline__ float lin_sample_g(int mode, Key2 key, uint64_t nbits
 }
 
 __device__ __forceinline__ Key2 lin_mode_key(int mode, Key2 carry, int M_global, int m_global, int layout) {
-  const Key2 kp = rng_split_row(carry, (uint32_t)M_global + 1u, (uint32_t)m_global + 1u, layout);
+  const Key2 kp = rng_split_row_uniform(carry, (uint32_t)M_global + 1u, (uint32_t)m_global + 1u, layout);
   if (mode == LIN_MODE_THETA) return kp;            // dibs.py:510: particle key itself
-  return rng_split_row(kp, 2u, 1u, layout);         // dibs.py:350-351 / 430-431: subk_ of split(particle key)
+  return rng_split_row_uniform(kp, 2u, 1u, layout); // dibs.py:350-351 / 430-431: subk_ of split(particle key)
 }
 
 template <int NT>

@@ -202,8 +202,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
 
   // ---- 1. sample column j of the S graphs -------------------------------------------------------
   // particle key = row (1 + m_global) of split(carry, M+1); subk_ = row 1 of split(particle key)   dibs.py:350-351
-  const Key2 kp = rng_split_row(carry, (uint32_t)M_global + 1u, (uint32_t)(m0 + m) + 1u, layout);
-  const Key2 kg = rng_split_row(kp, 2u, 1u, layout);
+  const Key2 kp = rng_split_row_uniform(carry, (uint32_t)M_global + 1u, (uint32_t)(m0 + m) + 1u, layout);
+  const Key2 kg = rng_split_row_uniform(kp, 2u, 1u, layout);
   const uint64_t dd = (uint64_t)d * d, nbits = (uint64_t)S * dd;
   if (!SAMPLE) {
   } else if ((S & 1) == 0) {
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
   constexpr int DP = 16 * NT, LD = DP + 4, BUF = DP * LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int blk = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const Key2 km = rng_split_row(carry, (uint32_t)M_global + 1u, (uint32_t)(m0 + m) + 1u, layout);  // dibs.py:595: key used directly
+  const Key2 km = rng_split_row_uniform(carry, (uint32_t)M_global + 1u, (uint32_t)(m0 + m) + 1u, layout);  // dibs.py:595: key used directly
   const uint64_t dd = (uint64_t)d * d, nbits = (uint64_t)Sa * dd;
   const int kp = (d + 3) & ~3;
   const bool kodd = (kp >> 2) & 1;

@@ -33,6 +33,10 @@ DIBS_HD void threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, ui
   o1 = x1;
 }
 
+// split row for wave-uniform arguments (key, row from kernel arguments / blockIdx): marking them uniform lets the compiler run
+// the whole derivation on the scalar unit instead of spending ~70 VALU issue slots per Threefry call in every wave
+__device__ __forceinline__ Key2 rng_split_row_uniform(Key2 key, uint32_t num, uint32_t r, int layout);
+
 // Threefry for wave-uniform keys, as one fixed instruction sequence (67 VALU ops): the key schedule lives in SGPRs,
 // each injection is folded into the following round's add (v_add3_u32), and the optimiser cannot re-derive the first rounds
 // as extra induction variables (it did, at +50 % instructions, when this ran inside a counter loop).  The sampling kernels are
@@ -208,4 +212,52 @@ __device__ __forceinline__ float rng_normal(uint32_t bits) {
 #pragma unroll
   for (int i = 1; i < 9; ++i) p = DIBS_FADD(lt ? A[i] : B[i], DIBS_FMUL(p, w));
   return DIBS_FMUL(1.41421354f, DIBS_FMUL(p, x));
+}
+
+// Threefry on the scalar unit (SALU has no rotate: shift, shift, or).  hipcc selects v_alignbit_b32 for a rotate even when
+// the operands are uniform, so the rounds are spelled out.
+#define TFS_R(r, rr) "s_add_u32 %0, %0, %1\n\ts_lshl_b32 %2, %1, " #r "\n\ts_lshr_b32 %1, %1, " #rr "\n\ts_or_b32 %1, %1, %2\n\ts_xor_b32 %1, %1, %0\n\t"
+__device__ __forceinline__ void threefry2x32_scalar(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t& o0, uint32_t& o1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
+  uint32_t x0 = c0 + k0, x1 = c1 + k1, t;
+  asm volatile(TFS_R(13, 19) TFS_R(15, 17) TFS_R(26, 6) TFS_R(6, 26) : "+s"(x0), "+s"(x1), "=&s"(t) : : "scc");
+  x0 += k1; x1 += k2 + 1u;
+  asm volatile(TFS_R(17, 15) TFS_R(29, 3) TFS_R(16, 16) TFS_R(24, 8) : "+s"(x0), "+s"(x1), "=&s"(t) : : "scc");
+  x0 += k2; x1 += k0 + 2u;
+  asm volatile(TFS_R(13, 19) TFS_R(15, 17) TFS_R(26, 6) TFS_R(6, 26) : "+s"(x0), "+s"(x1), "=&s"(t) : : "scc");
+  x0 += k0; x1 += k1 + 3u;
+  asm volatile(TFS_R(17, 15) TFS_R(29, 3) TFS_R(16, 16) TFS_R(24, 8) : "+s"(x0), "+s"(x1), "=&s"(t) : : "scc");
+  x0 += k1; x1 += k2 + 4u;
+  asm volatile(TFS_R(13, 19) TFS_R(15, 17) TFS_R(26, 6) TFS_R(6, 26) : "+s"(x0), "+s"(x1), "=&s"(t) : : "scc");
+  o0 = x0 + k2;
+  o1 = x1 + k0 + 5u;
+#else
+  threefry2x32(k0, k1, c0, c1, o0, o1);
+#endif
+}
+#undef TFS_R
+
+__device__ __forceinline__ Key2 rng_split_row_uniform(Key2 key, uint32_t num, uint32_t r, int layout) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t k0 = __builtin_amdgcn_readfirstlane(key.a), k1 = __builtin_amdgcn_readfirstlane(key.b);
+  num = __builtin_amdgcn_readfirstlane(num);
+  r = __builtin_amdgcn_readfirstlane(r);
+  Key2 o;
+  if (layout == 1) {
+    threefry2x32_scalar(k0, k1, 0u, r, o.a, o.b);
+    return o;
+  }
+  // legacy: element i of the 2 num draws comes from the call with counters (c, num + c), c = i mod num; first / second output
+  uint32_t y0, y1;
+  const uint32_t i0 = 2u * r, i1 = 2u * r + 1u;
+  const uint32_t ca = i0 < num ? i0 : i0 - num, cb = i1 < num ? i1 : i1 - num;
+  threefry2x32_scalar(k0, k1, ca, num + ca, y0, y1);
+  o.a = i0 < num ? y0 : y1;
+  threefry2x32_scalar(k0, k1, cb, num + cb, y0, y1);
+  o.b = i1 < num ? y0 : y1;
+  return o;
+#else
+  return rng_split_row(key, num, r, layout);
+#endif
 }
