@@ -1,6 +1,6 @@
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dibs_amd._abi import make_config
 from dibs_amd.engine import Engine
 from oracle.c_oracle import COracle

@@ -2,7 +2,7 @@
 BASELINE.json configs[1]: MarginalDiBS + BGe, d=20, 32 particles, 1000 steps (plus a JointDiBS + LinearGaussian run)."""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dibs_amd import random
 from dibs_amd._abi import make_config
 from dibs_amd.inference import MarginalDiBS, JointDiBS

@@ -1,7 +1,7 @@
 """GPU bring-up check: one SVGD step of the HIP engine vs the C oracle (f64), stage by stage."""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dibs_amd._abi import make_config
 from dibs_amd.engine import Engine
 from oracle.c_oracle import COracle

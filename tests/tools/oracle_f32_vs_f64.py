@@ -1,10 +1,10 @@
 """How far do the oracle's own float32 and float64 builds drift apart on a free-running trajectory?  (CPU only.)
-Same config / seeds as scripts/gpu_eshd_compare.py: the GPU-vs-oracle(f64) gap after 1000 steps is of the same size as the
+Same config / seeds as tests/tools/gpu_eshd_compare.py: the GPU-vs-oracle(f64) gap after 1000 steps is of the same size as the
 f32-vs-f64 gap of the oracle itself, i.e. it is the chaotic amplification of fp32 rounding (softmax over samples is close to
 an argmax; near-ties flip), not a property of the HIP kernels."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dibs_amd import random
 from dibs_amd.inference import MarginalDiBS
 from dibs_amd.metrics import expected_shd, expected_edges
