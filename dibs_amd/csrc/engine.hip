@@ -835,10 +835,10 @@ template <int NT>
 static void launch_nn_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N,
                             const NNParams& np_, size_t P, hipStream_t stream) {
   const size_t lds = nn_lds_bytes(d, N, NT, false);
-  allow_lds(k_nn_logprobs<NT>, lds);
-  hipLaunchKernelGGL(k_nn_logprobs<NT>, dim3(1, n), dim3(256), lds, stream, jw.x, jw.mask, theta, P, (const float*)nullptr,
+  allow_lds(k_nn_logprobs<NT, 4>, lds);
+  hipLaunchKernelGGL((k_nn_logprobs<NT, 4>), dim3(1, n), dim3(256), lds, stream, jw.x, jw.mask, theta, P, (const float*)nullptr,
                      reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, N, 1, 1, 0.f, 1.f, 0, 0, np_,
-                     jw.any_mask);
+                     jw.any_mask, (const float*)nullptr);
 }
 
 extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* theta, int32_t n, const float* x_ho,

@@ -17,6 +17,7 @@ struct JointWork {
   float* x;        // [N, d] device copy
   int32_t* mask;   // [N, d]
   float* wsm;      // [Mloc, S] softmax weights scratch
+  float* ln_tab;   // [Mloc, d, d] DenseNN: per-particle first-layer prior table (kernels_nn.h), else null
   int any_mask;
 };
 
@@ -530,18 +531,21 @@ __global__ __launch_bounds__(256) void k_lin_grad(const float* __restrict__ x, c
 
 // ---- host side -----------------------------------------------------------------------------------
 static inline int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) {
-  (void)d;
   (void)N;
   w->x = nullptr;
   w->mask = nullptr;
+  w->ln_tab = nullptr;
   w->any_mask = 0;
   if (hipMalloc((void**)&w->wsm, (size_t)Mloc * S * 4) != hipSuccess) return 1;
+  if (hipMalloc((void**)&w->ln_tab, (size_t)Mloc * d * d * 4) != hipSuccess) return 1;
   return 0;
 }
 static inline void joint_free(JointWork* w) {
   if (w->x) hipFree(w->x);
   if (w->mask) hipFree(w->mask);
   if (w->wsm) hipFree(w->wsm);
+  if (w->ln_tab) hipFree(w->ln_tab);
+  w->ln_tab = nullptr;
   w->x = nullptr;
   w->mask = nullptr;
   w->wsm = nullptr;

@@ -58,12 +58,12 @@ __host__ __device__ inline size_t nn_lds_bytes(int d, int N, int NT, bool grad) 
 }
 
 // pre = X * TW for the row tiles of this wave, results left in registers: acc[u][tj] (row tile ti = wave + 4 u)
-template <int NT, int NU>
+template <int NT, int NU, int NW = 4>
 __device__ __forceinline__ void nn_gemm_x_tw(const float* X, const float* TW, const LinGeom g, int lane, int wave, f32x4 (&acc)[NU][NT]) {
   const int nrt = g.np >> 4;
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const int ti = wave + 4 * u;
+    const int ti = wave + NW * u;
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj) acc[u][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (ti >= nrt) continue;
@@ -85,28 +85,47 @@ __device__ __forceinline__ void nn_gemm_x_tw(const float* X, const float* TW, co
   }
 }
 
-// sample graph s into GS (row-major [a][j]) ; returns nothing
-__device__ __forceinline__ void nn_build_graph(float* GS, int mode, Key2 key, uint64_t nbits, int s, const uint32_t* thr_m,
-                                               const float* sc_m, float alpha, float tau, int layout, int tiny, int d, int tid) {
-  const uint64_t dd = (uint64_t)d * d;
-  for (int e = tid; e < d * d; e += 256) {
-    const int a = e / d, j = e - a * d;
-    GS[e] = lin_sample_g(mode, key, nbits, dd, s, a, j, d, thr_m, sc_m, alpha, tau, layout, tiny);
-  }
+// LN[a][j] = sum_h logN(W1[j][a][h]; 0, sig_p): the graph-dependent part of the parameter prior is sum_aj g[a][j] LN[a][j]
+// (nonlinearGaussian.py:264-269).  It does not depend on the sample: one table per particle and step instead of H logN
+// evaluations per element of every sampled graph.   grid = (ceil(d*d / 256), Mloc)
+__global__ void k_nn_prior_table(const float* __restrict__ theta, size_t P, float* __restrict__ ln_tab, int d, int H, float sigp) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+  if (e >= d * d) return;
+  const int a = e / d, j = e - a * d;
+  const float* w = theta + (size_t)m * P + ((size_t)j * d + a) * H;
+  float t = 0.f;
+  for (int h = 0; h < H; ++h) t += lin_logn(w[h], 0.f, sigp);
+  ln_tab[(size_t)m * d * d + e] = t;
 }
 
-// TW[a][j] = GS[a][j] * W1[j][a][h]  (zero padded); returns this thread's share of sum g logN(W1[., ., h])
-__device__ __forceinline__ float nn_build_tw(float* TW, const float* GS, const float* __restrict__ th_m, int h, int H, float sigp,
-                                             const LinGeom g, int tid) {
+// sample graph s into GS (row-major [a][j]); with a prior table returns this thread's share of sum g LN
+__device__ __forceinline__ float nn_build_graph(float* GS, int mode, Key2 key, uint64_t nbits, int s, const uint32_t* thr_m,
+                                                const float* sc_m, float alpha, float tau, int layout, int tiny, int d, int tid,
+                                                const float* __restrict__ ln_m = nullptr, int nthr = 256) {
+  const uint64_t dd = (uint64_t)d * d;
   float prior = 0.f;
-  for (int e = tid; e < g.kp * g.ldw; e += 256) {
+  for (int e = tid; e < d * d; e += nthr) {
+    const int a = e / d, j = e - a * d;
+    const float gv = lin_sample_g(mode, key, nbits, dd, s, a, j, d, thr_m, sc_m, alpha, tau, layout, tiny);
+    GS[e] = gv;
+    if (ln_m) prior = fmaf(gv, ln_m[e], prior);
+  }
+  return prior;
+}
+
+// TW[a][j] = GS[a][j] * W1[j][a][h]  (zero padded); PRIOR: also returns this thread's share of sum g logN(W1[., ., h])
+template <bool PRIOR>
+__device__ __forceinline__ float nn_build_tw(float* TW, const float* GS, const float* __restrict__ th_m, int h, int H, float sigp,
+                                             const LinGeom g, int tid, int nthr = 256) {
+  float prior = 0.f;
+  for (int e = tid; e < g.kp * g.ldw; e += nthr) {
     const int a = e / g.ldw, j = e - a * g.ldw;
     float v = 0.f;
     if (a < g.d && j < g.d) {
       const float gv = GS[a * g.d + j];
       const float w = th_m[((size_t)j * g.d + a) * H + h];
       v = gv * w;
-      prior += gv * lin_logn(w, 0.f, sigp);
+      if (PRIOR) prior += gv * lin_logn(w, 0.f, sigp);
     }
     TW[e] = v;
   }
@@ -116,15 +135,18 @@ __device__ __forceinline__ float nn_build_tw(float* TW, const float* GS, const f
 // ------------------------------------------------------------------------------------------------
 // log p(theta, D | G_s) for all samples.  grid = (ceil(S / spb), Mloc), block = 256
 // ------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256) void k_nn_logprobs(const float* __restrict__ x, const int32_t* __restrict__ mask,
+// NW waves per block (8 when the operands leave room for one block per CU only: two waves per SIMD hide the barriers and
+// LDS / L2 waits of the build -> MFMA -> epilogue cycle of every hidden unit)
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_nn_logprobs(const float* __restrict__ x, const int32_t* __restrict__ mask,
                                                      const float* __restrict__ theta, size_t P, const float* __restrict__ scores,
                                                      const uint32_t* __restrict__ thr, float* __restrict__ logprobs, Key2 carry,
                                                      int mode, int m0, int M_global, int d, int N, int S, int spb, float alpha,
-                                                     float tau, int layout, int tiny, NNParams np_, int any_mask) {
+                                                     float tau, int layout, int tiny, NNParams np_, int any_mask,
+                                                     const float* __restrict__ ln_tab) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const LinGeom g = lin_geom(d, N, NT);
-  constexpr int NU = 2;  // row tiles per wave (np / 16 <= 8, i.e. N <= 128)
+  constexpr int NU = 8 / NW, NTHR = 64 * NW;  // row tiles per wave (np / 16 <= 8, i.e. N <= 128)
   float* X = smem;
   float* GS = X + (size_t)g.np * g.ldx;
   float* TW = GS + (size_t)d * d;
@@ -134,13 +156,13 @@ __global__ __launch_bounds__(256) void k_nn_logprobs(const float* __restrict__ x
   const int H = np_.H;
   const NNOff off = nn_offsets(d, H, np_.bias);
   const float* th_m = theta + (size_t)m * P;
-  for (int e = tid; e < g.np * g.ldx; e += 256) {
+  for (int e = tid; e < g.np * g.ldx; e += NTHR) {
     const int n = e / g.ldx, c = e - n * g.ldx;
     X[e] = (n < N && c < d) ? x[(size_t)n * d + c] : 0.f;
   }
   // graph-independent part of the prior: all leaves except the first-layer weights
   float prior_rest = 0.f;
-  for (size_t e = off.b1 + tid; e < off.P; e += 256) prior_rest += lin_logn(th_m[e], 0.f, np_.sig_param);
+  for (size_t e = off.b1 + tid; e < off.P; e += NTHR) prior_rest += lin_logn(th_m[e], 0.f, np_.sig_param);
   const Key2 key = (mode == LIN_MODE_GIVEN) ? Key2{0, 0} : lin_mode_key(mode, carry, M_global, m0 + m, layout);
   const uint64_t nbits = (uint64_t)S * dd;
   const float inv2 = 0.5f / np_.obs_noise;
@@ -150,9 +172,9 @@ __global__ __launch_bounds__(256) void k_nn_logprobs(const float* __restrict__ x
     const int s = blockIdx.x * spb + c;
     if (s >= S) break;
     __syncthreads();
-    nn_build_graph(GS, mode, key, nbits, s, thr + (size_t)m * dd, scores ? scores + (size_t)m * dd : nullptr, alpha, tau, layout, tiny,
-                   d, tid);
-    float part = prior_rest;
+    const float pg = nn_build_graph(GS, mode, key, nbits, s, thr + (size_t)m * dd, scores ? scores + (size_t)m * dd : nullptr, alpha,
+                                    tau, layout, tiny, d, tid, ln_tab ? ln_tab + (size_t)m * dd : nullptr, NTHR);
+    float part = prior_rest + pg;
     f32x4 macc[NU][NT];
 #pragma unroll
     for (int u = 0; u < NU; ++u)
@@ -160,16 +182,17 @@ __global__ __launch_bounds__(256) void k_nn_logprobs(const float* __restrict__ x
       for (int tj = 0; tj < NT; ++tj) macc[u][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int h = 0; h < H; ++h) {
       __syncthreads();
-      part += nn_build_tw(TW, GS, th_m, h, H, np_.sig_param, g, tid);
+      if (ln_tab) nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid, NTHR);
+      else part += nn_build_tw<true>(TW, GS, th_m, h, H, np_.sig_param, g, tid, NTHR);
       __syncthreads();
       f32x4 acc[NU][NT];
-      nn_gemm_x_tw<NT, NU>(X, TW, g, lane, wave, acc);
+      nn_gemm_x_tw<NT, NU, NW>(X, TW, g, lane, wave, acc);
 #pragma unroll
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj) {
           const int j = tj * 16 + (lane & 15);
-          if (j < d && wave + 4 * u < nrt) {
+          if (j < d && wave + NW * u < nrt) {
             const float b1 = np_.bias ? th_m[off.b1 + (size_t)j * H + h] : 0.f;
             const float w2 = th_m[off.w2 + (size_t)j * H + h];
 #pragma unroll
@@ -183,8 +206,8 @@ __global__ __launch_bounds__(256) void k_nn_logprobs(const float* __restrict__ x
       for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int n = (wave + 4 * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
-          if (n < N && j < d && wave + 4 * u < nrt && !(any_mask && mask[(size_t)n * d + j])) {
+          const int n = (wave + NW * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
+          if (n < N && j < d && wave + NW * u < nrt && !(any_mask && mask[(size_t)n * d + j])) {
             const float mean = macc[u][tj][r] + (np_.bias ? th_m[off.b2 + j] : 0.f);
             const float e = X[n * g.ldx + j] - mean;
             part += lognorm_x - inv2 * e * e;
@@ -194,7 +217,11 @@ __global__ __launch_bounds__(256) void k_nn_logprobs(const float* __restrict__ x
     __syncthreads();
     if (lane == 0) red[wave] = tot;
     __syncthreads();
-    if (tid == 0) logprobs[(size_t)m * S + s] = (float)(red[0] + red[1] + red[2] + red[3]);
+    if (tid == 0) {
+      double t = 0.0;
+      for (int w = 0; w < NW; ++w) t += red[w];
+      logprobs[(size_t)m * S + s] = (float)t;
+    }
   }
 }
 
@@ -285,7 +312,7 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
       for (int tj = 0; tj < NT; ++tj) macc[u][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int h = 0; h < H; ++h) {
       __syncthreads();
-      nn_build_tw(TW, GS, th_m, h, H, np_.sig_param, g, tid);
+      nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid);
       __syncthreads();
       f32x4 acc[NU][NT];
       nn_gemm_x_tw<NT, NU>(X, TW, g, lane, wave, acc);
@@ -328,7 +355,7 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
     // ---- backward, one hidden unit at a time ----
     for (int h = 0; h < H; ++h) {
       __syncthreads();
-      nn_build_tw(TW, GS, th_m, h, H, np_.sig_param, g, tid);
+      nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid);
       __syncthreads();
       f32x4 acc[NU][NT];
       nn_gemm_x_tw<NT, NU>(X, TW, g, lane, wave, acc);
@@ -454,12 +481,22 @@ template <int NT>
 static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P) {
   const int spb = 2;
   const size_t lds1 = nn_lds_bytes(jl.d, jl.N, NT, false), lds2 = nn_lds_bytes(jl.d, jl.N, NT, true);
-  if (lds1 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_logprobs<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
   if (lds2 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_grad<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
   float* lp = mode == LIN_MODE_THETA ? jl.logprobs_th : jl.logprobs_z;
-  hipLaunchKernelGGL(k_nn_logprobs<NT>, dim3((jl.S + spb - 1) / spb, jl.Mloc), dim3(256), lds1, jl.stream, w->x, w->mask, jl.theta, P,
-                     jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, spb, jl.alpha, jl.tau, jl.layout, jl.tiny, np_,
-                     w->any_mask);
+  if (mode == LIN_MODE_THETA && w->ln_tab)  // theta is the same for both estimators of a step: the table is built once (theta runs first)
+    hipLaunchKernelGGL(k_nn_prior_table, dim3((jl.d * jl.d + 255) / 256, jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->ln_tab, jl.d,
+                       np_.H, np_.sig_param);
+  if (lds1 > 80 * 1024) {  // one block per CU: run it with 8 waves
+    if (lds1 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_logprobs<NT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    hipLaunchKernelGGL((k_nn_logprobs<NT, 8>), dim3((jl.S + spb - 1) / spb, jl.Mloc), dim3(512), lds1, jl.stream, w->x, w->mask, jl.theta, P,
+                       jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, spb, jl.alpha, jl.tau, jl.layout, jl.tiny, np_,
+                       w->any_mask, w->ln_tab);
+  } else {
+    if (lds1 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_logprobs<NT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    hipLaunchKernelGGL((k_nn_logprobs<NT, 4>), dim3((jl.S + spb - 1) / spb, jl.Mloc), dim3(256), lds1, jl.stream, w->x, w->mask, jl.theta, P,
+                       jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, spb, jl.alpha, jl.tau, jl.layout, jl.tiny, np_,
+                       w->any_mask, w->ln_tab);
+  }
   float* out = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off : jl.w_lik;
   const size_t ostride = mode == LIN_MODE_THETA ? jl.pack_stride : (size_t)jl.d * jl.d;
   float* tcopy = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr;
