@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64 * NW) void k_nn_logprobs(const float* __restrict
                                                      const float* __restrict__ ln_tab) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const LinGeom g = lin_geom(d, N, NT);
-  constexpr int NU = 8 / NW, NTHR = 64 * NW;  // row tiles per wave (np / 16 <= 8, i.e. N <= 128)
+  constexpr int NU = NW >= 8 ? 1 : 8 / NW, NTHR = 64 * NW;  // row tiles per wave (np / 16 <= 8, i.e. N <= 128)
   float* X = smem;
   float* GS = X + (size_t)g.np * g.ldx;
   float* TW = GS + (size_t)d * d;
@@ -487,8 +487,8 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
     hipLaunchKernelGGL(k_nn_prior_table, dim3((jl.d * jl.d + 255) / 256, jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->ln_tab, jl.d,
                        np_.H, np_.sig_param);
   if (lds1 > 80 * 1024) {  // one block per CU: run it with 8 waves
-    if (lds1 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_logprobs<NT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    hipLaunchKernelGGL((k_nn_logprobs<NT, 8>), dim3((jl.S + spb - 1) / spb, jl.Mloc), dim3(512), lds1, jl.stream, w->x, w->mask, jl.theta, P,
+    if (lds1 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_logprobs<NT, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    hipLaunchKernelGGL((k_nn_logprobs<NT, 16>), dim3((jl.S + spb - 1) / spb, jl.Mloc), dim3(1024), lds1, jl.stream, w->x, w->mask, jl.theta, P,
                        jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, spb, jl.alpha, jl.tau, jl.layout, jl.tiny, np_,
                        w->any_mask, w->ln_tab);
   } else {
