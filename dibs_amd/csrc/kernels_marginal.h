@@ -125,8 +125,8 @@ __host__ __device__ inline int bge_lbuf_floats(int d) {
 }
 __host__ __device__ inline int bge_idx_len(int d) { return d + 4 > 36 ? d + 4 : 36; }  // >= 32: the 32-lane tier zero-fills 32 slots
 __host__ __device__ inline size_t bge_wave_bytes(int d, int S, int W) {
-  // masks[S*W] u64 | thr[d] | lim[d]
-  size_t b = (size_t)S * W * 8 + (size_t)2 * d * 4;
+  // masks[S*W] u64 | thr[d] | lim[d] | loc[S]
+  size_t b = (size_t)S * W * 8 + (size_t)2 * d * 4 + (size_t)S * 4;
   return (b + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t bge_lds_bytes(int d, int S, int W, int waves) {
@@ -180,6 +180,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
   }
   // lim = 512 * thr:  y < lim  <=>  (y >> 9) < thr.  thr == 2^23 (p == 1.0f) has no 32-bit lim; those rows are forced on.
   uint32_t* lims = thrs + d;
+  uint32_t* loc = lims + d;  // per sample: queue tier << 28 | index inside this block's reservation, or ~0
+  __shared__ unsigned int blk_cnt[4], blk_base[4];
+  if (tid < 4) blk_cnt[tid] = 0u;
   uint64_t force0 = 0, force1 = 0;
   if (active && SAMPLE) {
     for (int i0 = 0; i0 < d; i0 += 64) {
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
     }
   }
   __syncthreads();
-  if (!active) return;
+  if (active) {
   if (!SAMPLE) {  // scoring of given graphs (dibs_score_graphs): the parent sets come from the caller
     const uint64_t* mg = masks + ((size_t)m * d + j) * S * W;
     for (int e = lane; e < S * W; e += 64) mk[e] = mg[e];
@@ -337,32 +340,45 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __rest
       ns_out[s] = bge_assemble(bp, j, l, d, Nn, log(prod), schur);
       flops += (double)n * n * n / 3.0;
     }
-    // queue the rest by tier (wave-aggregated atomics; the order inside a queue does not affect any result)
+    // queue the rest by tier.  Slots are reserved per BLOCK (LDS counters here, one global atomicAdd per tier and block below):
+    // one atomic per wave pass made the four global counters the bottleneck while most problems are still queued.
     const bool big = valid && !small && l > 0;
-    const bool t12 = big && l <= 11, t16 = big && l >= 12 && l <= 15, t32 = big && l >= 16 && l <= 31, tg = big && l > 31;
+    const int tier = !big ? -1 : (l <= 11 ? 0 : (l <= 15 ? 1 : (l <= 31 ? 2 : 3)));
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const uint32_t code = (uint32_t)(((size_t)m * d + j) * S + s);
-#define BGE_ENQUEUE(FLAG_, IDX_, LIST_)                                                                         \
-    {                                                                                                           \
-      const unsigned long long bal = __ballot(FLAG_);                                                           \
-      if (bal) {                                                                                                \
-        const int leader = __ffsll((long long)bal) - 1;                                                         \
-        unsigned int base = 0;                                                                                  \
-        if (lane == leader) base = atomicAdd(&qs.counts[IDX_], (unsigned int)__popcll(bal));                    \
-        base = __shfl(base, leader, 64);                                                                        \
-        if (FLAG_) LIST_[base + __popcll(bal & lt)] = code;                                                     \
-      }                                                                                                         \
+    uint32_t myloc = 0xFFFFFFFFu;
+#pragma unroll
+    for (int tq = 0; tq < 4; ++tq) {
+      const unsigned long long bal = __ballot(tier == tq);
+      if (bal) {
+        const int leader = __ffsll((long long)bal) - 1;
+        unsigned int base = 0;
+        if (lane == leader) base = atomicAdd(&blk_cnt[tq], (unsigned int)__popcll(bal));
+        base = __shfl(base, leader, 64);
+        if (tier == tq) myloc = ((uint32_t)tq << 28) | (base + (unsigned int)__popcll(bal & lt));
+      }
     }
-    BGE_ENQUEUE(t12, 0, qs.list12)
-    BGE_ENQUEUE(t16, 1, qs.list16)
-    BGE_ENQUEUE(t32, 2, qs.list32)
-    BGE_ENQUEUE(tg, 3, qs.listg)
-#undef BGE_ENQUEUE
+    if (valid) loc[s] = myloc;
   }
   if (counters) {
     const double tot = wave_sum_d(flops);
     if (lane == 0 && tot > 0.0) atomicAdd(counters, (unsigned long long)tot);  // (same-address atomics serialise: skip the zeros)
   }
+  }  // active
+  __syncthreads();
+  if (tid < 4) {
+    const unsigned int c = blk_cnt[tid];
+    blk_base[tid] = c ? atomicAdd(&qs.counts[tid], c) : 0u;
+  }
+  __syncthreads();
+  if (active)
+    for (int s = lane; s < S; s += 64) {
+      const uint32_t v = loc[s];
+      if (v != 0xFFFFFFFFu) {
+        const uint32_t tq = v >> 28;
+        uint32_t* lst = tq == 0 ? qs.list12 : (tq == 1 ? qs.list16 : (tq == 2 ? qs.list32 : qs.listg));
+        lst[blk_base[tq] + (v & 0x0FFFFFFFu)] = (uint32_t)(((size_t)m * d + j) * S + s);
+      }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
