@@ -842,8 +842,11 @@ __device__ __forceinline__ void lds_matmul(float* __restrict__ lds, int c_off, i
       ACYC_MFMA(a1, b1)
     }
     if constexpr (ODD) { ACYC_MFMA(a0, b0) }  // (its fragments were loaded by the last pass, or by the prologue when ksteps == 1)
+    // last MFMA -> accumulator read: one wait for the whole group (volatile asm statements keep their order, so every
+    // accumulator's first read sits behind the s_nop)
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[NT - 1]));
 #pragma unroll
-    for (int tj = 0; tj < NT; ++tj) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[tj]));  // last MFMA -> accumulator read
+    for (int tj = 0; tj < NT - 1; ++tj) asm volatile("" : "+v"(acc[tj]));
 #undef ACYC_LOAD
 #undef ACYC_MFMA
 #pragma unroll

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $TAG -- python bench.py --no-cpu-baseline "$@" > $OUT/bench.log 2>&1 || { tail -20 $OUT/bench.log; exit 1; }
-tail -1 $OUT/bench.log > gpurun_out/${TAG}_bench.json
+grep "\"metric\"" $OUT/bench.log | tail -1 > gpurun_out/${TAG}_bench.json
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
 cp "$f" gpurun_out/${TAG}_kernel_stats.csv
 head -20 gpurun_out/${TAG}_kernel_stats.csv
