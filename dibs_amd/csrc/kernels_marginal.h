@@ -798,14 +798,17 @@ __device__ __forceinline__ int acyc_pc(int c) { return (c & 15) * NT + (c >> 4);
 // ODD: the number of k-steps (kp / 4) is odd.  A template parameter, not a runtime `if` around the last MFMA: the accumulators
 // must not meet a control-flow join between an MFMA and the s_nop that covers its latency -- hipcc places register copies
 // for the join right behind the (opaque) asm MFMA and reads the accumulator too early.
-template <int NT, bool ODD>
+// ZC (needs >= 2 k-steps): the first MFMA of every tile takes C = 0 as an inline constant instead of a zeroed accumulator.
+template <int NT, bool ODD, bool ZC>
 __device__ __forceinline__ void lds_matmul(float* __restrict__ lds, int c_off, int a_off, int b_off, int kp, int lane,
                                            int wave) {
   constexpr int DP = 16 * NT, LD = DP + 4;
   for (int ti = wave; ti < NT; ti += 4) {
     f32x4 acc[NT];
+    if constexpr (!ZC) {
 #pragma unroll
-    for (int tj = 0; tj < NT; ++tj) acc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int tj = 0; tj < NT; ++tj) acc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // A[row][k]: k = k0 + kk -> physical ((k0 & 15) + kk) * NT + (k0 >> 4)
     const int ap = a_off + (ti * 16 + (lane & 15)) * LD + (lane >> 4) * NT;
     // B[k][tj * 16 + col], tj = 0..NT-1 -> physical col * NT + tj (contiguous)
@@ -832,10 +835,22 @@ __device__ __forceinline__ void lds_matmul(float* __restrict__ lds, int c_off, i
     // read (s_nop after the loop); back-to-back MFMAs on the same accumulator need none.
 #define ACYC_MFMA(A_, B_) \
     _Pragma("unroll") for (int tj = 0; tj < NT; ++tj) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[tj]) : "v"(A_), "v"(B_[tj]));
+#define ACYC_MFMA_Z(A_, B_) \
+    _Pragma("unroll") for (int tj = 0; tj < NT; ++tj) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc[tj]) : "v"(A_), "v"(B_[tj]));
     ACYC_LOAD(a0, b0, 0)
-    asm volatile("s_nop 4" ::: "memory");
+    int st0 = 0;
+    if constexpr (ZC) {
+      ACYC_LOAD(a1, b1, 1)
+      ACYC_MFMA_Z(a0, b0)
+      ACYC_LOAD(a0, b0, 2)
+      ACYC_MFMA(a1, b1)
+      st0 = 2;
+    } else {
+      asm volatile("s_nop 4" ::: "memory");
+    }
+#undef ACYC_MFMA_Z
 #pragma unroll 1
-    for (int st = 0; st < nsteps; st += 2) {
+    for (int st = st0; st < nsteps; st += 2) {
       ACYC_LOAD(a1, b1, st + 1)
       ACYC_MFMA(a0, b0)
       ACYC_LOAD(a0, b0, st + 2)
@@ -960,14 +975,16 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
         const int hb = 31 - __builtin_clz((unsigned)ex);
         for (int b = hb - 1; b >= 0; --b) {
           int dst = (cur == BUF) ? 2 * BUF : BUF;
-          if (kodd) lds_matmul<NT, true>(smem, dst, cur, cur, kp, lane, wave);
-          else lds_matmul<NT, false>(smem, dst, cur, cur, kp, lane, wave);
+          if (kp < 8) lds_matmul<NT, true, false>(smem, dst, cur, cur, kp, lane, wave);
+          else if (kodd) lds_matmul<NT, true, true>(smem, dst, cur, cur, kp, lane, wave);
+          else lds_matmul<NT, false, true>(smem, dst, cur, cur, kp, lane, wave);
           __syncthreads();
           cur = dst;
           if ((ex >> b) & 1) {
             dst = (cur == BUF) ? 2 * BUF : BUF;
-            if (kodd) lds_matmul<NT, true>(smem, dst, cur, 0, kp, lane, wave);
-            else lds_matmul<NT, false>(smem, dst, cur, 0, kp, lane, wave);
+            if (kp < 8) lds_matmul<NT, true, false>(smem, dst, cur, 0, kp, lane, wave);
+            else if (kodd) lds_matmul<NT, true, true>(smem, dst, cur, 0, kp, lane, wave);
+            else lds_matmul<NT, false, true>(smem, dst, cur, 0, kp, lane, wave);
             __syncthreads();
             cur = dst;
           }
