@@ -525,7 +525,8 @@ __device__ __forceinline__ void bge_big_body(unsigned char* smem_raw, const uint
             acc = R[myidx[r] * d + ik];
             const float* lr = Lb + (size_t)r * ldl;
             const float* lk = Lb + (size_t)kk * ldl;
-            for (int p = 0; p < kk; ++p) acc = fmaf(-lr[p], lk[p], acc);
+#pragma unroll 8
+            for (int p = 0; p < kk; ++p) acc = fmaf(-lr[p], lk[p], acc);  // (unrolled: several LDS reads in flight)
           }
           accs[h] = acc;
           if (r == kk) mypiv[h] = acc;
