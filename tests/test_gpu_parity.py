@@ -494,3 +494,26 @@ def test_marginal_bge_reparam_estimator(d, M, S, Sa, interv):
         assert rel_err(g["z"], st2.z.numpy()) < 1e-4
         st = st2
     eng.close()
+
+
+def test_config2_free_running_200_steps(c_oracle64):
+    """north_star's criterion on BASELINE.json configs[1] (MarginalDiBS + BGe, d=20, 32 particles): Z within 1e-4 relative of
+    the (float64) oracle after N free-running steps on identical PRNG-seeded inputs, and the same posterior graphs / E-SHD.
+    N = 200: beyond ~300 steps fp32 trajectories decorrelate -- the oracle's own f32 and f64 builds do too
+    (tests/tools/oracle_f32_vs_f64.py)."""
+    from dibs_amd.inference import MarginalDiBS
+    from dibs_amd.metrics import expected_shd
+    d, M, steps = 20, 32, 200
+    data, gm, lm = make_data(d, seed=0)
+    dibs = MarginalDiBS(x=data.x, graph_model=gm, likelihood_model=lm)
+    g_gpu = dibs.sample(key=prng.PRNGKey(1), n_particles=M, steps=steps)
+    z_gpu = dibs.last_state["z"]
+    cfg = dibs._make_config(M, d)
+    st = c_oracle64.new_state(cfg, prng.PRNGKey(1))
+    c_oracle64.run(cfg, data.x, None, st, 0, steps, n_threads=min(os.cpu_count() or 1, 16))
+    assert rel_err(z_gpu, st["z"]) < 1e-4
+    g_or = dibs.particle_to_g_lim(st["z"])
+    assert np.array_equal(g_gpu, g_or)
+    e_gpu = expected_shd(dist=dibs.get_empirical(g_gpu), g=data.g)
+    e_or = expected_shd(dist=dibs.get_empirical(g_or), g=data.g)
+    assert abs(e_gpu - e_or) < 1e-3
