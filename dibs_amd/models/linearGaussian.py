@@ -82,6 +82,20 @@ class LinearGaussian:
             x[:, j] = (x[:, pa] @ np.asarray(theta)[pa, j] if pa.size else 0.0) + noise[:, j]
         return x
 
+    # host-side (numpy, float64) evaluation helpers with the reference's names (linearGaussian.py:278-316); the SVGD path and
+    # `interventional_log_joint_prob` run on the device
+    def log_prob_parameters(self, *, theta, g):
+        th, g = np.asarray(theta, np.float64), np.asarray(g, np.float64)
+        z = (th - self.mean_edge) / self.sig_edge
+        return float(np.sum(g * (-0.5 * z * z - np.log(self.sig_edge) - 0.5 * np.log(2.0 * np.pi))))
+
+    def log_likelihood(self, *, x, theta, g, interv_targets):
+        x, it = np.asarray(x, np.float64), np.asarray(interv_targets)
+        assert x.shape == it.shape
+        mean = x @ (np.asarray(g, np.float64) * np.asarray(theta, np.float64))
+        ll = -0.5 * (x - mean) ** 2 / self.obs_noise - 0.5 * np.log(2.0 * np.pi * self.obs_noise)
+        return float(np.sum(np.where(it != 0, 0.0, ll)))
+
     def interventional_log_joint_prob(self, g, theta, x, interv_targets, rng=None):
         from ..inference.scoring import score_graphs
         return float(score_graphs(self, np.asarray(g)[None], np.asarray(theta)[None], x, interv_targets)[0])

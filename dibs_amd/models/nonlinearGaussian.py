@@ -128,6 +128,28 @@ class DenseNonlinearGaussian:
                 x[:, j] = noise[:, j]
         return x
 
+    # host-side (numpy, float64) evaluation helpers with the reference's names (nonlinearGaussian.py:248-318)
+    def log_prob_parameters(self, *, theta, g):
+        g = np.asarray(g, np.float64)
+        sp = self.sig_param
+        logn = lambda a: -0.5 * (np.asarray(a, np.float64) / sp) ** 2 - np.log(sp) - 0.5 * np.log(2.0 * np.pi)
+        layers = [t for t in theta if len(t)]
+        lp = 0.0
+        for li, lay in enumerate(layers):
+            for leaf_i, leaf in enumerate(lay):
+                lw = logn(leaf)
+                if li == 0 and leaf_i == 0:  # first-layer weights [d, d, H]: masked by g^T (nonlinearGaussian.py:264-269)
+                    lw = lw * g.T[:, :, None]
+                lp += float(lw.sum())
+        return lp
+
+    def log_likelihood(self, *, x, theta, g, interv_targets):
+        x, it, g = np.asarray(x, np.float64), np.asarray(interv_targets), np.asarray(g, np.float64)
+        assert x.shape == it.shape
+        means = np.stack([self._forward_node(theta, j, x * g[:, j][None]) for j in range(g.shape[0])], axis=1)
+        ll = -0.5 * (x - means) ** 2 / self.obs_noise - 0.5 * np.log(2.0 * np.pi * self.obs_noise)
+        return float(np.sum(np.where(it != 0, 0.0, ll)))
+
     def interventional_log_joint_prob(self, g, theta, x, interv_targets, rng=None):
         from ..inference.scoring import score_graphs
         flat = self.tree_to_flat(theta)

@@ -126,3 +126,30 @@ def test_lingauss_sample_parameters_stream():
     flat = nn.tree_to_flat(tree)
     back = nn.flat_to_tree(flat, 4)
     assert flat.shape == (2, 4 * 4 * 3 + 4 * 3 + 4 * 3 + 4) and np.array_equal(back[2][1], tree[2][1])
+
+
+def test_model_log_prob_helpers_match_oracle():
+    """LinearGaussian / DenseNonlinearGaussian.log_prob_parameters + log_likelihood (host-side helpers with the reference's
+    names) add up to the oracle's log joint (linearGaussian.py:278-338, nonlinearGaussian.py:248-326)."""
+    import torch
+    from oracle import dibs_oracle as O
+    from dibs_amd import random
+    from dibs_amd.models import LinearGaussian, DenseNonlinearGaussian
+    rng = np.random.default_rng(0)
+    d, N = 6, 20
+    x = rng.normal(size=(N, d))
+    it = (rng.random((N, d)) < 0.2).astype(np.int32)
+    g = (rng.random((d, d)) < 0.4).astype(np.int32)
+    np.fill_diagonal(g, 0)
+    t64 = lambda a: torch.as_tensor(np.asarray(a, np.float64))
+    lin = LinearGaussian(n_vars=d)
+    th = rng.normal(size=(d, d))
+    ref = float(O.lingauss_log_joint(t64(g), t64(th), t64(x), t64(it), O.LinGaussParams()))
+    got = lin.log_prob_parameters(theta=th, g=g) + lin.log_likelihood(x=x, theta=th, g=g, interv_targets=it)
+    assert abs(got - ref) < 1e-8 * abs(ref)
+    nn = DenseNonlinearGaussian(n_vars=d, hidden_layers=(4,), activation="tanh")
+    theta = nn.sample_parameters(key=random.PRNGKey(3), n_vars=d)
+    tht = [t64(leaf) for lay in theta for leaf in lay]   # the oracle's container: flat list of leaves
+    ref = float(O.densenn_log_joint(t64(g), tht, t64(x), t64(it), O.DenseNNParams(hidden_layers=(4,), activation="tanh")))
+    got = nn.log_prob_parameters(theta=theta, g=g) + nn.log_likelihood(x=x, theta=theta, g=g, interv_targets=it)
+    assert abs(got - ref) < 1e-6 * abs(ref)
