@@ -44,6 +44,7 @@ struct dibs_engine {
   double *gam, *Nj;
   int n_mats;
   double alpha_lambd, bge_alpha_mu, bge_log_t;
+  bool kmat_fused;  // this step's latent kernel matrix was computed inside the k_bge_nodes launch
   float* soft_ds;  // [Mloc, S, d, d]  BGe reparam estimator: per-sample score-space gradients
   bool has_data;
   // work
@@ -537,14 +538,24 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     {  // (queue counters: zero at creation, reset by k_lik_weights_score at the end of every step)
       KTimer tm(e, DIBS_K_BGE_NODES);
       const size_t lds4 = bge_lds_bytes(e->d, e->S, e->W, 4), lds1 = bge_lds_bytes(e->d, e->S, e->W, 1);
+      KmatFuse kf{nullptr, nullptr, 0, 0, 0, 0.f, 0.f};
+      e->kmat_fused = false;
       if (e->n_mats == 1 && lds4 <= 80 * 1024) {
-        allow_lds(k_bge_nodes<4, true>, lds4);
-        hipLaunchKernelGGL((k_bge_nodes<4, true>), dim3((e->d + 3) / 4, e->Mloc), dim3(256), lds4, e->stream, e->thr, e->masks,
-                           e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L, cnt, e->bq);
+        const int nbx = (e->d + 3) / 4;
+        size_t lds = lds4;
+        // single rank, vector fits one LDS chunk: the latent kernel matrix rides along (see KmatFuse)
+        if (e->Mloc == e->M && e->D <= KMAT_CH && (size_t)e->D * 4 + 64 <= 80 * 1024 && !getenv("DIBS_NO_KMAT_FUSE")) {
+          kf = KmatFuse{e->z, e->kz, (int)e->D, e->M, nbx, (float)c.scale_latent, (float)c.h_latent};
+          lds = lds4 > (size_t)e->D * 4 + 64 ? lds4 : (size_t)e->D * 4 + 64;
+          e->kmat_fused = true;
+        }
+        allow_lds(k_bge_nodes<4, true>, lds);
+        hipLaunchKernelGGL((k_bge_nodes<4, true>), dim3(nbx + (kf.z ? (e->M + KMAT_BT - 1) / KMAT_BT : 0), e->Mloc), dim3(256), lds,
+                           e->stream, e->thr, e->masks, e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L, cnt, e->bq, kf);
       } else {
         allow_lds(k_bge_nodes<1, true>, lds1);
         hipLaunchKernelGGL((k_bge_nodes<1, true>), dim3(e->d, e->Mloc), dim3(64), lds1, e->stream, e->thr, e->masks,
-                           e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L, cnt, e->bq);
+                           e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L, cnt, e->bq, kf);
       }
     }
     {
@@ -638,8 +649,9 @@ static int step_update(dibs_engine* e, int t, const float* pack) {
     auto kmat_lds = [](size_t len) { return (size_t)(((len < KMAT_CH ? len : (size_t)KMAT_CH) + 3) & ~(size_t)3) * 4; };
     allow_lds(k_kmat, kmat_lds(e->D > e->P ? e->D : e->P));
     const dim3 kg(e->Mloc, (e->M + KMAT_BT - 1) / KMAT_BT);
-    hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->D), e->stream, pack, (size_t)e->E, (size_t)0,
-                       (int)e->D, e->kz, e->m0, e->M, (float)c.scale_latent, (float)c.h_latent, ksym);
+    if (!e->kmat_fused)
+      hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->D), e->stream, pack, (size_t)e->E, (size_t)0,
+                         (int)e->D, e->kz, e->m0, e->M, (float)c.scale_latent, (float)c.h_latent, ksym);
     if (c.joint)
       hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->P), e->stream, pack, (size_t)e->E,
                          (size_t)(2 * e->D), (int)e->P, e->kt, e->m0, e->M, (float)c.scale_theta, (float)c.h_theta, ksym);
@@ -890,11 +902,11 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
       if (st.n_mats == 1 && lds4 <= 96 * 1024) {
         allow_lds(k_bge_nodes<4, false>, lds4);
         hipLaunchKernelGGL((k_bge_nodes<4, false>), dim3((d + 3) / 4, 1), dim3(256), lds4, e->stream, (const uint32_t*)nullptr,
-                           d_masks, d_ns, bp, Key2{0, 0}, 0, 1, d, S, W, 0, (unsigned long long*)nullptr, sq);
+                           d_masks, d_ns, bp, Key2{0, 0}, 0, 1, d, S, W, 0, (unsigned long long*)nullptr, sq, KmatFuse{nullptr, nullptr, 0, 0, 0, 0.f, 0.f});
       } else {
         allow_lds(k_bge_nodes<1, false>, lds1);
         hipLaunchKernelGGL((k_bge_nodes<1, false>), dim3(d, 1), dim3(64), lds1, e->stream, (const uint32_t*)nullptr, d_masks,
-                           d_ns, bp, Key2{0, 0}, 0, 1, d, S, W, 0, (unsigned long long*)nullptr, sq);
+                           d_ns, bp, Key2{0, 0}, 0, 1, d, S, W, 0, (unsigned long long*)nullptr, sq, KmatFuse{nullptr, nullptr, 0, 0, 0, 0.f, 0.f});
       }
       launch_bge_big(e, bp, d_masks, d_ns, sq, S, (unsigned long long*)nullptr);
       hipLaunchKernelGGL(k_sum_nodes, dim3((S + 127) / 128), dim3(128), 0, e->stream, d_ns, d_out + q0, d, S);

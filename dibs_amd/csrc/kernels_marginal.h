@@ -158,12 +158,32 @@ struct BgeQueues {
   unsigned int* counts;  // [4]: zero at creation, reset by k_lik_weights_score / the scoring path after every use
 };
 
+// The latent kernel matrix only needs z, which is final when a step starts.  On a single rank its blocks ride along in the
+// k_bge_nodes launch (extra blockIdx.x range): that kernel is bound by VALU issue, k_kmat by the latency of the far cache
+// levels, so the two overlap almost for free.  (Several ranks: the rows of the other ranks arrive with the all-gather, the
+// kernel matrix stays in phase B.)
+#define KMAT_BT 16
+struct KmatFuse {
+  const float* z;   // [M, len] (null: nothing fused)
+  float* kout;      // [M, M]
+  int len, M, nbx;  // nbx: first blockIdx.x of the kernel-matrix range
+  float scale, h;
+};
+__device__ __forceinline__ void kmat_block(float* __restrict__ smem, const float* __restrict__ pack, size_t pack_stride,
+                                           size_t seg_off, int len, float* __restrict__ kout, int m0, int M, float scale, float h,
+                                           int symmetric, int a, int bt);
+
 template <int WAVES, bool SAMPLE>
 __global__ __launch_bounds__(64 * WAVES) void k_bge_nodes(const uint32_t* __restrict__ thr, uint64_t* __restrict__ masks,
                                                           double* __restrict__ node_scores, BgeParams bp, Key2 carry,
                                                           int m0, int M_global, int d, int S, int W, int layout,
-                                                          unsigned long long* __restrict__ counters, BgeQueues qs) {
+                                                          unsigned long long* __restrict__ counters, BgeQueues qs, KmatFuse kf) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (WAVES == 4 && kf.z && (int)blockIdx.x >= kf.nbx) {  // kernel-matrix role (block-uniform)
+    kmat_block(reinterpret_cast<float*>(smem_raw), kf.z, (size_t)kf.len, (size_t)0, kf.len, kf.kout, 0, kf.M, kf.scale, kf.h, 1,
+               (int)blockIdx.y, (int)blockIdx.x - kf.nbx);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = blockIdx.y;
   const int j = blockIdx.x * WAVES + wave;
@@ -1095,15 +1115,14 @@ __global__ __launch_bounds__(256) void k_zgrad(const float* __restrict__ z, cons
 //     reference: kernel.py:20-30 / 52-71, svgd.py:165-176 / 537-551
 // grid = Mloc, block = 256; dynamic LDS = len * 4
 // ------------------------------------------------------------------------------------------------
-#define KMAT_BT 16
 #define KMAT_CH 32768  // floats of z_a staged in LDS at a time (128 KiB); longer vectors (DenseNN theta at d = 100) go in chunks
-__global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, size_t pack_stride, size_t seg_off, int len,
-                                              float* __restrict__ kout, int m0, int M, float scale, float h, int symmetric) {
+__device__ __forceinline__ void kmat_block(float* __restrict__ smem, const float* __restrict__ pack, size_t pack_stride,
+                                           size_t seg_off, int len, float* __restrict__ kout, int m0, int M, float scale, float h,
+                                           int symmetric, int a, int bt) {
   // block (a, bt): particle a (local) against b = bt * KMAT_BT .. +KMAT_BT-1; wave w takes b = b0 + w, b0 + w + 4, ...
   // symmetric (one rank holds all particles): tiles below the diagonal are skipped and k[a][b] is mirrored into k[b][a]
   // -- the sum of squared differences is the same number either way, so the slab is bit-identical to the full computation.
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int a = blockIdx.x, b0 = blockIdx.y * KMAT_BT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = bt * KMAT_BT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (symmetric && b0 + KMAT_BT - 1 < a) return;
   const float* za = pack + (size_t)(m0 + a) * pack_stride + seg_off;
   double acc[KMAT_BT / 4];
@@ -1179,6 +1198,12 @@ __global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, si
       if (symmetric && b > a) kout[(size_t)b * M + a] = kv;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, size_t pack_stride, size_t seg_off, int len,
+                                              float* __restrict__ kout, int m0, int M, float scale, float h, int symmetric) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  kmat_block(smem, pack, pack_stride, seg_off, len, kout, m0, M, scale, h, symmetric, blockIdx.x, blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
