@@ -643,7 +643,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
 static int step_update(dibs_engine* e, int t, const float* pack) {
   (void)t;
   const dibs_config& c = e->cfg;
-  {
+  if (!e->kmat_fused || c.joint) {
     KTimer tm(e, DIBS_K_KMAT);
     const int ksym = e->Mloc == e->M;  // single rank: the slab is the whole (symmetric) matrix
     auto kmat_lds = [](size_t len) { return (size_t)(((len < KMAT_CH ? len : (size_t)KMAT_CH) + 3) & ~(size_t)3) * 4; };
