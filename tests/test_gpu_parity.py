@@ -536,3 +536,20 @@ def test_joint_free_running_100_steps(c_oracle64, model, tol):
     c_oracle64.run(cfg, data.x, None, st, 0, steps, n_threads=min(os.cpu_count() or 1, 16))
     assert rel_err(dibs.last_state["z"], st["z"]) < tol
     assert np.array_equal(g, dibs.particle_to_g_lim(st["z"]))
+
+
+def test_kernel_matrix_fusion_is_transparent(monkeypatch):
+    """Single rank: the latent kernel matrix computed inside the k_bge_nodes launch (default) equals the stand-alone k_kmat
+    launch (DIBS_NO_KMAT_FUSE=1) bit for bit, and so does the trajectory."""
+    data, _, _ = make_data(20, seed=0)
+    cfg = make_config(n_vars=20, n_particles=12, n_observations=100)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("DIBS_NO_KMAT_FUSE", "1")
+        eng = _engine(cfg, data.x)
+        eng.init_particles(prng.PRNGKey(5))
+        eng.run(0, 7)
+        outs.append((eng.read("KXX").copy(), eng.get_state()["z"].copy()))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
