@@ -564,7 +564,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     }
     {
       KTimer tm(e, DIBS_K_LIK_WEIGHTS);
-      const int ny = e->d < 4 ? e->d : 4;
+      const int ny = e->d < 8 ? e->d : 8;  // blocks per particle (2 / 4 / 8 / 16 measured: 26 / 19 / 17 / 19 us)
       const size_t base = (((size_t)e->S * 36 + 15) & ~(size_t)15);
       const size_t mbytes = (size_t)e->S * ((e->d + ny - 1) / ny) * e->W * 8;
       const int in_lds = base + mbytes <= 64 * 1024;
