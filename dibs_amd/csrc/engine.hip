@@ -631,7 +631,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     KTimer tm(e, DIBS_K_ZGRAD);
     const size_t lds = ((size_t)e->d * e->d + (size_t)2 * e->d * e->k) * 4;
     allow_lds(k_zgrad, lds);
-    const int zs = e->d < 4 ? e->d : 4;
+    const int zs = e->d < 8 ? e->d : 8;
     hipLaunchKernelGGL(k_zgrad, dim3(e->Mloc, zs), dim3(256), lds, e->stream, e->z, e->w_tot, pack, (size_t)e->E, e->m0, e->d,
                        e->k, 1.0f / (e->sigz * e->sigz));
   }
@@ -659,10 +659,11 @@ static int step_update(dibs_engine* e, int t, const float* pack) {
   {
     KTimer tm(e, DIBS_K_PHI_UPDATE);
     auto phi = [&](size_t val_off, size_t grad_off, size_t len, int is_theta, float* x, float* v, float* phi_out, float h) {
-      // particles per block: as many as keep >= 512 blocks in flight and the [M][TA] tables within 48 KiB of LDS
+      // particles per block: as many as keep >= 1024 blocks in flight and the [M][TA] tables within 48 KiB of LDS
+      // (headline size: TA = 16 / 8 / 4 measured 20.5 / 18.9 / 26.0 us)
       const long cols = (long)((len + 63) / 64);
       int ta = 16;
-      while (ta > 4 && (cols * ((e->Mloc + ta - 1) / ta) < 512 || (size_t)2 * ta * e->M * 4 > 48 * 1024)) ta >>= 1;
+      while (ta > 4 && (cols * ((e->Mloc + ta - 1) / ta) < 1024 || (size_t)2 * ta * e->M * 4 > 48 * 1024)) ta >>= 1;
       const size_t lds = ((size_t)2 * ta * e->M + (size_t)4 * ta * 64) * 4;
       const dim3 g((unsigned)cols, (e->Mloc + ta - 1) / ta);
 #define PHI_LAUNCH(TA_)                                                                                                        \
