@@ -470,20 +470,22 @@ static void launch_bge_big(dibs_engine* e, const BgeParams& bp, const uint64_t* 
 }
 
 template <int NT>
-static void launch_acyc(dibs_engine* e, Key2 carry, float alpha) {
+static void launch_acyc(dibs_engine* e, Key2 carry, float alpha, const LikArgs& lik, int lik_blocks, size_t lik_lds) {
   constexpr int DP = 16 * NT, LD = DP + 4;
-  const size_t lds = (size_t)(3 * DP + 1) * LD * 4;  // + one slack row (the k pipeline may load one step past the end)
+  size_t lds = (size_t)(3 * DP + 1) * LD * 4;  // + one slack row (the k pipeline may load one step past the end)
+  if (lik_blocks && lik_lds > lds) lds = lik_lds;
   const bool paired = e->acyc_units != e->Sa;
+  const dim3 grid(e->acyc_nblk + lik_blocks, e->Mloc);  // blockIdx.x >= acyc_nblk: score-estimator blocks riding along
   if (paired) {
     allow_lds(k_acyc<NT, true>, lds);
-    hipLaunchKernelGGL((k_acyc<NT, true>), dim3(e->acyc_nblk, e->Mloc), dim3(256), lds, e->stream, e->scores, e->acyc_part, carry,
+    hipLaunchKernelGGL((k_acyc<NT, true>), grid, dim3(256), lds, e->stream, e->scores, e->acyc_part, carry,
                        e->m0, e->M, e->d, e->Sa, e->acyc_cpb, alpha, (float)e->cfg.tau, e->cfg.rng_layout,
-                       e->cfg.logistic_minval_tiny);
+                       e->cfg.logistic_minval_tiny, e->acyc_nblk, lik);
   } else {
     allow_lds(k_acyc<NT, false>, lds);
-    hipLaunchKernelGGL((k_acyc<NT, false>), dim3(e->acyc_nblk, e->Mloc), dim3(256), lds, e->stream, e->scores, e->acyc_part, carry,
+    hipLaunchKernelGGL((k_acyc<NT, false>), grid, dim3(256), lds, e->stream, e->scores, e->acyc_part, carry,
                        e->m0, e->M, e->d, e->Sa, e->acyc_cpb, alpha, (float)e->cfg.tau, e->cfg.rng_layout,
-                       e->cfg.logistic_minval_tiny);
+                       e->cfg.logistic_minval_tiny, e->acyc_nblk, lik);
   }
 }
 
@@ -511,6 +513,9 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     hipLaunchKernelGGL(k_edge_scores, dim3(e->Mloc, ntile >= 16 ? 4 : (ntile >= 8 ? 2 : 1)), dim3(256), lds, e->stream, e->z, e->scores, e->thr, e->probs, alpha, e->d, e->k,
                        e->dpad, e->ldk);
   }
+  LikArgs lik{};
+  int lik_blocks = 0;
+  size_t lik_lds = 0;
   if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_REPARAM) {
     const BgeSoftParams sp{e->R, e->Nj, e->alpha_lambd, e->bge_alpha_mu, e->bge_log_t, e->n_mats};
     {
@@ -563,16 +568,23 @@ static int step_local(dibs_engine* e, int t, float* pack) {
       launch_bge_big(e, bp, e->masks, e->node_scores, e->bq, e->S, cnt);
     }
     {
-      KTimer tm(e, DIBS_K_LIK_WEIGHTS);
       const int ny = e->d < 8 ? e->d : 8;  // blocks per particle (2 / 4 / 8 / 16 measured: 26 / 19 / 17 / 19 us)
       const size_t base = (((size_t)e->S * 36 + 15) & ~(size_t)15);
       const size_t mbytes = (size_t)e->S * ((e->d + ny - 1) / ny) * e->W * 8;
       const int in_lds = base + mbytes <= 64 * 1024;
-      const size_t lds = base + (in_lds ? mbytes : 0);
-      allow_lds(k_lik_weights_score, lds);
-      hipLaunchKernelGGL(k_lik_weights_score, dim3(e->Mloc, ny), dim3(256), lds, e->stream, e->node_scores, e->masks,
-                         e->probs, e->logprobs_z, e->w_lik, e->baseline, e->baseline2, alpha, c.score_function_baseline,
-                         e->d, e->S, e->W, in_lds, e->bq.counts);
+      lik_lds = base + (in_lds ? mbytes : 0);
+      lik = LikArgs{e->node_scores, e->masks, e->probs, e->logprobs_z, e->w_lik, e->baseline, e->baseline2, alpha,
+                    c.score_function_baseline, e->d, e->S, e->W, in_lds, ny, e->bq.counts};
+      // A rank with few particles leaves most block slots of the k_acyc launch empty (<= 2 of the 3 per CU): the score
+      // estimator's latency-bound blocks ride along there.  With all slots taken (one rank, 128 particles) riding along
+      // made k_acyc 21 us longer for 19 us saved, so it stays a launch of its own.
+      if ((long)e->acyc_nblk * e->Mloc <= 512 && !getenv("DIBS_NO_LIK_FUSE")) {
+        lik_blocks = ny;
+      } else {
+        KTimer tm(e, DIBS_K_LIK_WEIGHTS);
+        allow_lds(k_lik_weights_score, lik_lds);
+        hipLaunchKernelGGL(k_lik_weights_score, dim3(e->Mloc, ny), dim3(256), lik_lds, e->stream, lik);
+      }
       std::swap(e->baseline, e->baseline2);
     }
   } else if (c.likelihood == DIBS_LIK_LINGAUSS) {
@@ -608,13 +620,13 @@ static int step_local(dibs_engine* e, int t, float* pack) {
   {
     KTimer tm(e, DIBS_K_ACYC);
     switch (e->acyc_nt) {
-      case 1: launch_acyc<1>(e, carry_prior, alpha); break;
-      case 2: launch_acyc<2>(e, carry_prior, alpha); break;
-      case 3: launch_acyc<3>(e, carry_prior, alpha); break;
-      case 4: launch_acyc<4>(e, carry_prior, alpha); break;
-      case 5: launch_acyc<5>(e, carry_prior, alpha); break;
-      case 6: launch_acyc<6>(e, carry_prior, alpha); break;
-      default: launch_acyc<7>(e, carry_prior, alpha); break;
+      case 1: launch_acyc<1>(e, carry_prior, alpha, lik, lik_blocks, lik_lds); break;
+      case 2: launch_acyc<2>(e, carry_prior, alpha, lik, lik_blocks, lik_lds); break;
+      case 3: launch_acyc<3>(e, carry_prior, alpha, lik, lik_blocks, lik_lds); break;
+      case 4: launch_acyc<4>(e, carry_prior, alpha, lik, lik_blocks, lik_lds); break;
+      case 5: launch_acyc<5>(e, carry_prior, alpha, lik, lik_blocks, lik_lds); break;
+      case 6: launch_acyc<6>(e, carry_prior, alpha, lik, lik_blocks, lik_lds); break;
+      default: launch_acyc<7>(e, carry_prior, alpha, lik, lik_blocks, lik_lds); break;
     }
   }
   {

@@ -671,17 +671,36 @@ __global__ void k_sum_nodes(const double* __restrict__ node_scores, float* __res
 //     reference: dibs.py:359-389 (closed form of the signed-logsumexp ratio)
 // grid = Mloc, block = 256; dynamic LDS = S*d*W*8 + S*8 + S*4
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restrict__ node_scores,
-                                                           const uint64_t* __restrict__ masks,
-                                                           const float* __restrict__ probs, float* __restrict__ logprobs,
-                                                           float* __restrict__ w_lik, const float* __restrict__ baseline,
-                                                           float* __restrict__ baseline_out, float alpha,
-                                                           double sf_baseline, int d, int S, int W, int masks_in_lds,
-                                                           unsigned int* __restrict__ queue_counts) {
+struct LikArgs {
+  const double* node_scores;
+  const uint64_t* masks;
+  const float* probs;
+  float* logprobs;
+  float* w_lik;
+  const float* baseline;
+  float* baseline_out;
+  float alpha;
+  double sf_baseline;
+  int d, S, W, masks_in_lds, ny;
+  unsigned int* queue_counts;
+};
+// body of one block (m, y of ny).  Also called from the k_acyc launch when that launch leaves block slots free (a rank with
+// few particles): these latency-bound blocks then hide behind the acyclicity blocks -- the k_bge_big launch they depend
+// on precedes both in stream order.
+__device__ __forceinline__ void lik_weights_block(unsigned char* smem_raw, const LikArgs& A, int m, int y) {
+  const double* __restrict__ node_scores = A.node_scores;
+  const uint64_t* __restrict__ masks = A.masks;
+  const float* __restrict__ probs = A.probs;
+  float* __restrict__ logprobs = A.logprobs;
+  float* __restrict__ w_lik = A.w_lik;
+  const float* __restrict__ baseline = A.baseline;
+  float* __restrict__ baseline_out = A.baseline_out;
+  const float alpha = A.alpha;
+  const double sf_baseline = A.sf_baseline;
+  const int d = A.d, S = A.S, W = A.W, masks_in_lds = A.masks_in_lds, ny = A.ny;
   // the BGe queues of this step have been consumed (stream order): reset their counters for the next step
-  if (queue_counts && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) queue_counts[threadIdx.x] = 0u;
-  // block (m, y) handles the columns j = y, y + gridDim.y, ... of particle m; every block recomputes l_s / softmax
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (A.queue_counts && m == 0 && y == 0 && threadIdx.x < 4) A.queue_counts[threadIdx.x] = 0u;
+  // block (m, y) handles the columns j = y, y + ny, ... of particle m; every block recomputes l_s / softmax
   double* lp = reinterpret_cast<double*>(smem_raw);
   double* lp2 = lp + S;  // [2][S] partial sums
   float* wt = reinterpret_cast<float*>(lp2 + 2 * S);
@@ -690,7 +709,7 @@ __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restr
   uint64_t* mkl = reinterpret_cast<uint64_t*>(smem_raw + (((size_t)S * 36 + 15) & ~(size_t)15));
   __shared__ double red[8];
   __shared__ int nnz_s;
-  const int m = blockIdx.x, y = blockIdx.y, ny = gridDim.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ncol = (d - y + ny - 1) / ny;  // columns of this block
   const uint64_t* mg = masks + (size_t)m * d * S * W;  // [j][s][w]
   if (masks_in_lds)
@@ -798,6 +817,11 @@ __global__ __launch_bounds__(256) void k_lik_weights_score(const double* __restr
     w_lik[(size_t)m * d * d + i * d + j] = out;
   }
   if (tid == 0 && y == 0) baseline_out[m] = (float)(sf_baseline * (sm / S) + (1.0 - sf_baseline) * (double)bold);
+}
+
+__global__ __launch_bounds__(256) void k_lik_weights_score(LikArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  lik_weights_block(smem_raw, A, blockIdx.x, blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -909,9 +933,13 @@ __device__ __forceinline__ void lds_matmul(float* __restrict__ lds, int c_off, i
 template <int NT, bool PAIRED>
 __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, float* __restrict__ part, Key2 carry, int m0,
                                               int M_global, int d, int Sa, int cpb, float alpha, float tau, int layout,
-                                              int tiny) {
+                                              int tiny, int n_acyc_blk, LikArgs lik) {
   constexpr int DP = 16 * NT, LD = DP + 4, BUF = DP * LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x >= n_acyc_blk) {  // score-estimator role (block-uniform): see lik_weights_block
+    lik_weights_block(reinterpret_cast<unsigned char*>(smem), lik, (int)blockIdx.y, (int)blockIdx.x - n_acyc_blk);
+    return;
+  }
   const int blk = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Key2 km = rng_split_row_uniform(carry, (uint32_t)M_global + 1u, (uint32_t)(m0 + m) + 1u, layout);  // dibs.py:595: key used directly
   const uint64_t dd = (uint64_t)d * d, nbits = (uint64_t)Sa * dd;
@@ -1023,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
     }
   }
   if (pact) {
-    float* po = part + ((size_t)m * gridDim.x + blk) * dd;
+    float* po = part + ((size_t)m * n_acyc_blk + blk) * dd;
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
       const int i = pi0 + q * R;

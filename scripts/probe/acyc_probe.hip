@@ -16,7 +16,7 @@ template <int NT> void run(int d, int grid_y) {
   size_t lds = (3 * DP + 1) * LD * 4;
   hipFuncSetAttribute((const void*)k_acyc<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   Key2 carry{123u, 456u};
-  hipLaunchKernelGGL((k_acyc<NT, true>), dim3(1, grid_y), dim3(256), lds, 0, ds, dp, carry, 0, grid_y, d, Sa, cpb, 1.0f, 1.0f, 0, 0);
+  hipLaunchKernelGGL((k_acyc<NT, true>), dim3(1, grid_y), dim3(256), lds, 0, ds, dp, carry, 0, grid_y, d, Sa, cpb, 1.0f, 1.0f, 0, 0, 1, LikArgs{});
   hipError_t e2 = hipDeviceSynchronize();
   hipMemcpy(part.data(), dp, part.size()*4, hipMemcpyDeviceToHost);
   // CPU reference for particle 0
