@@ -27,7 +27,7 @@ class DibsHipError(RuntimeError):
 
 def build(verbose=False):
     """Compile libdibs_hip.so for gfx950 (hipcc --offload-arch=gfx950)."""
-    r = subprocess.run(["make", "-C", _CSRC], capture_output=True, text=True)
+    r = subprocess.run(["make", "-j8", "-C", _CSRC], capture_output=True, text=True)
     if verbose or r.returncode:
         print(r.stdout + r.stderr)
     if r.returncode:
@@ -43,6 +43,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise DibsHipError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)")
+    # One HIP runtime per process: torch ships its own libamdhip64 / libhsa-runtime64 (same SONAME as /opt/rocm's).  Loaded
+    # first, it is the copy libdibs_hip.so binds to as well; the other order leaves two runtimes in the process and torch
+    # then finds "no ROCm-capable device".  (torch is the host layer's plumbing for streams and torch.distributed.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     lib.dibs_last_error.restype = C.c_char_p

@@ -8,7 +8,9 @@
 #include <vector>
 #include <utility>
 
+#define DIBS_TU_ENGINE
 #include "../../include/dibs_hip.h"
+#include "launch.h"
 #include "kernels_marginal.h"
 #include "kernels_joint.h"
 #include "kernels_nn.h"
@@ -26,6 +28,28 @@ static int fail(const std::string& m) {
     if (_e != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(_e));              \
   } while (0)
 
+// BGe statistics that do not depend on the graph (linearGaussian.py:78-94): R_j, N_j, the (j, l) table of log_gamma_term,
+// and for the complement form of kernels_bge.h R_j^-1 and logdet R_j.  Computed once per data set on the host in double,
+// uploaded as f32 / f64.  Owns its device buffers.
+struct BgeStats {
+  float *R = nullptr, *Rp = nullptr, *Qp = nullptr;
+  double *gam = nullptr, *Nj = nullptr, *ldR = nullptr;
+  int n_mats = 1;
+  double alpha_lambd = 0, alpha_mu = 0, log_t = 0;
+  void release() {
+    void* ptrs[] = {R, Rp, Qp, gam, Nj, ldR};
+    for (void* p_ : ptrs)
+      if (p_) hipFree(p_);
+    R = Rp = Qp = nullptr;
+    gam = Nj = ldR = nullptr;
+  }
+  ~BgeStats() { release(); }
+  BgeStats() = default;
+  BgeStats(const BgeStats&) = delete;
+  BgeStats& operator=(const BgeStats&) = delete;
+  BgeParams params() const { return BgeParams{Rp, Qp, gam, Nj, ldR, alpha_lambd, n_mats}; }
+};
+
 struct dibs_engine {
   dibs_config cfg;
   int d, k, M, Mloc, m0, N, S, Sa, W;
@@ -40,11 +64,8 @@ struct dibs_engine {
   // data
   float* x;
   int32_t* mask;
-  float* R;
-  double *gam, *Nj;
-  int n_mats;
-  double alpha_lambd, bge_alpha_mu, bge_log_t;
-  bool kmat_fused;  // this step's latent kernel matrix was computed inside the k_bge_nodes launch
+  BgeStats bge;
+  bool kmat_fused;  // this step's latent kernel matrix was computed inside the k_bge_sample launch
   float* soft_ds;  // [Mloc, S, d, d]  BGe reparam estimator: per-sample score-space gradients
   bool has_data;
   // work
@@ -94,61 +115,9 @@ static hipError_t dalloc(T** p, size_t n) {
   return e;
 }
 
-extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_engine** out) {
-  if (!cfg || !out) return fail("null argument");
-  *out = nullptr;
-  const dibs_config& c = *cfg;
-  if (c.abi_version != DIBS_ABI_VERSION) return fail("dibs_config.abi_version mismatch");
-  if (c.n_vars < 2 || c.n_vars > 112) return fail("n_vars must be in [2, 112]");
-  if (c.n_dim < 1) return fail("n_dim must be >= 1");
-  if (c.n_particles < 1 || c.n_grad_mc_samples < 1 || c.n_acyclicity_mc_samples < 1) return fail("sizes must be >= 1");
-  if (c.n_ranks < 1 || c.rank < 0 || c.rank >= c.n_ranks) return fail("bad rank / n_ranks");
-  if (c.n_particles % c.n_ranks) return fail("n_particles must be divisible by n_ranks");
-  if (c.grad_estimator_z != DIBS_EST_SCORE && c.grad_estimator_z != DIBS_EST_REPARAM)
-    return fail("Unknown gradient estimator");  // dibs.py:318 (ValueError)
-  if (c.optimizer != DIBS_OPT_GD && c.optimizer != DIBS_OPT_RMSPROP) return fail("unknown optimizer");  // svgd.py:122
-  if (c.likelihood < 0 || c.likelihood > 2) return fail("unknown likelihood model");
-  if (c.graph_prior < 0 || c.graph_prior > 2) return fail("unknown graph prior");
-  if (!c.joint && c.likelihood != DIBS_LIK_BGE)
-    return fail("MarginalDiBS needs a marginal likelihood (BGe)");
-  if (c.joint && c.likelihood == DIBS_LIK_BGE)
-    return fail("JointDiBS + BGe is not constructible (BGe has no parameters; linearGaussian.py:53-54)");
-  if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_REPARAM) {
-    // soft-graph BGe (kernels_bge_soft.h): one matrix row per lane, d x d factor and solution block per wave in LDS
-    if (c.n_vars > 64 || bge_soft_waves(c.n_vars, false) < 1)
-      return fail("BGe + reparam estimator: n_vars must be <= 64 on the device");
-  }
-  if (c.likelihood == DIBS_LIK_DENSENN) {
-    if (c.nn_n_hidden != 1) return fail("DenseNonlinearGaussian: exactly one hidden layer is supported on the device");
-    if (c.nn_hidden[0] < 1 || c.nn_hidden[0] > 64) return fail("DenseNonlinearGaussian: hidden width must be in [1, 64]");
-    if (c.n_observations > 128) return fail("DenseNonlinearGaussian: n_observations must be <= 128");
-    if (c.nn_activation < 0 || c.nn_activation > 3) return fail("Invalid activation function");  // nonlinearGaussian.py:61 (KeyError)
-  }
-  if (c.graph_prior == DIBS_PRIOR_ER) {
-    const double p = c.graph_prior_edges_per_node * c.n_vars / ((c.n_vars * (c.n_vars - 1)) / 2.0);
-    if (!(p > 0.0 && p < 1.0)) return fail("Erdos-Renyi prior: edge probability must be in (0, 1)");
-  }
-  {
-    if ((size_t)2 * 4 * c.n_particles * 4 + 4096 > LDS_LIMIT) return fail("n_particles too large (kernel rows must fit in LDS)");
-    if (((size_t)c.n_vars * c.n_vars + (size_t)2 * c.n_vars * c.n_dim) * 4 > LDS_LIMIT) return fail("n_vars * n_dim too large");
-  }
-  {  // LDS budgets of the likelihood kernels (x, theta / graph, per-sample operand and residuals are LDS-resident)
-    const int nt = (c.n_vars + 15) / 16;
-    if (c.likelihood == DIBS_LIK_LINGAUSS && lin_lds_bytes(c.n_vars, c.n_observations, nt, true) > LDS_LIMIT)
-      return fail("LinearGaussian: n_vars / n_observations too large for the LDS-resident kernels (n_vars <= 112 at 100 observations)");
-    if (c.likelihood == DIBS_LIK_DENSENN && nn_lds_bytes(c.n_vars, c.n_observations, nt, true) > LDS_LIMIT)
-      return fail("DenseNonlinearGaussian: n_vars / n_observations too large for the LDS-resident kernels (n_vars <= 112 at 100 observations)");
-  }
-  int ndev = 0;
-  HIP_OK(hipGetDeviceCount(&ndev));
-  if (ndev < 1) return fail("no HIP device");
-  HIP_OK(hipSetDevice(c.device_id));
-  hipDeviceProp_t prop;
-  HIP_OK(hipGetDeviceProperties(&prop, c.device_id));
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(std::string("libdibs_hip is built for gfx950 only; device is ") + prop.gcnArchName);
-
-  dibs_engine* e = new dibs_engine();  // value-initialised: every POD member starts at zero
+extern "C" int dibs_engine_destroy(dibs_engine* e);
+// sizes, stream, events and every device buffer of a new engine; on failure the caller destroys the half-built engine
+static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   e->cfg = c;
   e->d = c.n_vars;
   e->k = c.n_dim;
@@ -224,17 +193,80 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
   if (c.likelihood == DIBS_LIK_BGE) {
     HIP_OK(dalloc(&e->masks, Ml * e->S * e->d * e->W));
     HIP_OK(dalloc(&e->node_scores, Ml * e->S * e->d));
-    HIP_OK(dalloc(&e->bq.list12, Ml * e->S * e->d));
-    HIP_OK(dalloc(&e->bq.list16, Ml * e->S * e->d));
-    HIP_OK(dalloc(&e->bq.list32, Ml * e->S * e->d));
-    HIP_OK(dalloc(&e->bq.listg, Ml * e->S * e->d));
-    HIP_OK(dalloc(&e->bq.counts, (size_t)4));
+    e->bq.cap = (uint32_t)(Ml * e->S * e->d);
+    HIP_OK(dalloc(&e->bq.list, (size_t)BGE_NQ * e->bq.cap));
+    HIP_OK(dalloc(&e->bq.counts, (size_t)16));
     if (c.grad_estimator_z == DIBS_EST_REPARAM) HIP_OK(dalloc(&e->soft_ds, Ml * e->S * dd));
   }
   if (c.joint) {
     if (joint_alloc(&e->jw, e->Mloc, e->d, e->N, e->S) != 0) return fail("joint work buffers: hipMalloc failed");
   }
   hipDeviceSynchronize();  // the zero fills above ran on the null stream; the engine's own stream does not wait for it
+  return 0;
+}
+
+
+extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_engine** out) {
+  if (!cfg || !out) return fail("null argument");
+  *out = nullptr;
+  const dibs_config& c = *cfg;
+  if (c.abi_version != DIBS_ABI_VERSION) return fail("dibs_config.abi_version mismatch");
+  if (c.n_vars < 2 || c.n_vars > 112) return fail("n_vars must be in [2, 112]");
+  if (c.n_dim < 1) return fail("n_dim must be >= 1");
+  if (c.n_particles < 1 || c.n_grad_mc_samples < 1 || c.n_acyclicity_mc_samples < 1) return fail("sizes must be >= 1");
+  if (c.n_ranks < 1 || c.rank < 0 || c.rank >= c.n_ranks) return fail("bad rank / n_ranks");
+  if (c.n_particles % c.n_ranks) return fail("n_particles must be divisible by n_ranks");
+  if (c.grad_estimator_z != DIBS_EST_SCORE && c.grad_estimator_z != DIBS_EST_REPARAM)
+    return fail("Unknown gradient estimator");  // dibs.py:318 (ValueError)
+  if (c.optimizer != DIBS_OPT_GD && c.optimizer != DIBS_OPT_RMSPROP) return fail("unknown optimizer");  // svgd.py:122
+  if (c.likelihood < 0 || c.likelihood > 2) return fail("unknown likelihood model");
+  if (c.graph_prior < 0 || c.graph_prior > 2) return fail("unknown graph prior");
+  if (!c.joint && c.likelihood != DIBS_LIK_BGE)
+    return fail("MarginalDiBS needs a marginal likelihood (BGe)");
+  if (c.joint && c.likelihood == DIBS_LIK_BGE)
+    return fail("JointDiBS + BGe is not constructible (BGe has no parameters; linearGaussian.py:53-54)");
+  if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_REPARAM) {
+    // soft-graph BGe (kernels_bge_soft.h): one matrix row per lane, d x d factor and solution block per wave in LDS
+    if (c.n_vars > 64 || bge_soft_waves(c.n_vars, false) < 1)
+      return fail("BGe + reparam estimator: n_vars must be <= 64 on the device");
+  }
+  if (c.likelihood == DIBS_LIK_DENSENN) {
+    if (c.nn_n_hidden != 1) return fail("DenseNonlinearGaussian: exactly one hidden layer is supported on the device");
+    if (c.nn_hidden[0] < 1 || c.nn_hidden[0] > 64) return fail("DenseNonlinearGaussian: hidden width must be in [1, 64]");
+    if (c.n_observations > 128) return fail("DenseNonlinearGaussian: n_observations must be <= 128");
+    if (c.nn_activation < 0 || c.nn_activation > 3) return fail("Invalid activation function");  // nonlinearGaussian.py:61 (KeyError)
+  }
+  if (c.graph_prior == DIBS_PRIOR_ER) {
+    const double p = c.graph_prior_edges_per_node * c.n_vars / ((c.n_vars * (c.n_vars - 1)) / 2.0);
+    if (!(p > 0.0 && p < 1.0)) return fail("Erdos-Renyi prior: edge probability must be in (0, 1)");
+  }
+  {
+    if ((size_t)2 * 4 * c.n_particles * 4 + 4096 > LDS_LIMIT) return fail("n_particles too large (kernel rows must fit in LDS)");
+    if (((size_t)c.n_vars * c.n_vars + (size_t)2 * c.n_vars * c.n_dim) * 4 > LDS_LIMIT) return fail("n_vars * n_dim too large");
+  }
+  {  // LDS budgets of the likelihood kernels (x, theta / graph, per-sample operand and residuals are LDS-resident)
+    const int nt = (c.n_vars + 15) / 16;
+    if (c.likelihood == DIBS_LIK_LINGAUSS && lin_lds_bytes(c.n_vars, c.n_observations, nt, true) > LDS_LIMIT)
+      return fail("LinearGaussian: n_vars / n_observations too large for the LDS-resident kernels (n_vars <= 112 at 100 observations)");
+    if (c.likelihood == DIBS_LIK_DENSENN && nn_lds_bytes(c.n_vars, c.n_observations, nt, true) > LDS_LIMIT)
+      return fail("DenseNonlinearGaussian: n_vars / n_observations too large for the LDS-resident kernels (n_vars <= 112 at 100 observations)");
+  }
+  int ndev = 0;
+  HIP_OK(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return fail("no HIP device");
+  HIP_OK(hipSetDevice(c.device_id));
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, c.device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(std::string("libdibs_hip is built for gfx950 only; device is ") + prop.gcnArchName);
+
+  dibs_engine* e = new dibs_engine();  // value-initialised: every POD member starts at zero
+  if (engine_alloc(e, c, stream)) {
+    const std::string msg = g_err;
+    dibs_engine_destroy(e);  // frees whatever had been allocated (stream, events, buffers)
+    g_err = msg;
+    return 1;
+  }
   *out = e;
   return 0;
 }
@@ -242,41 +274,75 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
 extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (!e) return 0;
   hipSetDevice(e->cfg.device_id);
-  hipStreamSynchronize(e->stream);
+  if (e->stream) hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->w_tot, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
-                  e->node_scores, e->x, e->mask, e->R, e->gam, e->Nj, e->bq.list12, e->bq.list16, e->bq.list32, e->bq.listg, e->bq.counts, e->soft_ds};
+                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds};
   for (void* p : ptrs)
     if (p) hipFree(p);
   joint_free(&e->jw);
-  hipEventDestroy(e->ev0);
-  hipEventDestroy(e->ev1);
+  if (e->ev0) hipEventDestroy(e->ev0);
+  if (e->ev1) hipEventDestroy(e->ev1);
   for (auto& pe : e->pending) {
     hipEventDestroy(pe.second.first);
     hipEventDestroy(pe.second.second);
   }
-  if (e->own_stream) hipStreamDestroy(e->stream);
+  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
   delete e;
   return 0;
 }
 
-// BGe statistics that do not depend on the graph (linearGaussian.py:78-94): R_j, N_j and the (j, l) table of
-// log_gamma_term.  Computed once per data set on the host in double, uploaded as f32 / f64.
-static int bge_prepare(dibs_engine* e, const float* x, const int32_t* mask, const float* mean_obs) {
-  const int d = e->d, N = e->N;
-  const double amu = e->cfg.bge_alpha_mu;
-  e->alpha_lambd = e->cfg.bge_alpha_lambd > 0 ? e->cfg.bge_alpha_lambd : d + 2.0;
-  if (!(e->alpha_lambd > d + 1)) return fail("BGe: alpha_lambd must be > n_vars + 1");  // linearGaussian.py:47
-  const double small_t = amu * (e->alpha_lambd - d - 1) / (amu + 1);
-  e->bge_alpha_mu = amu;
-  e->bge_log_t = log(small_t);
+// in-place inverse and log-determinant of an SPD matrix (Cholesky, double)
+static bool spd_inverse_logdet(std::vector<double>& a, int n, double* logdet) {
+  std::vector<double> L((size_t)n * n, 0.0), Li((size_t)n * n, 0.0);
+  double ld = 0;
+  for (int j = 0; j < n; ++j) {
+    double s = a[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) s -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+    if (!(s > 0.0)) return false;
+    const double dj = sqrt(s);
+    ld += 2.0 * log(dj);
+    L[(size_t)j * n + j] = dj;
+    for (int i = j + 1; i < n; ++i) {
+      double t = a[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) t -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+      L[(size_t)i * n + j] = t / dj;
+    }
+  }
+  for (int c = 0; c < n; ++c) {  // Li = L^-1 (lower), column by column
+    Li[(size_t)c * n + c] = 1.0 / L[(size_t)c * n + c];
+    for (int i = c + 1; i < n; ++i) {
+      double t = 0;
+      for (int k = c; k < i; ++k) t -= L[(size_t)i * n + k] * Li[(size_t)k * n + c];
+      Li[(size_t)i * n + c] = t / L[(size_t)i * n + i];
+    }
+  }
+  for (int i = 0; i < n; ++i)  // A^-1 = Li^T Li
+    for (int j = 0; j <= i; ++j) {
+      double t = 0;
+      for (int k = i; k < n; ++k) t += Li[(size_t)k * n + i] * Li[(size_t)k * n + j];
+      a[(size_t)i * n + j] = a[(size_t)j * n + i] = t;
+    }
+  *logdet = ld;
+  return true;
+}
+
+static int bge_prepare(BgeStats* st, const dibs_config& cfg, int d, int N, const float* x, const int32_t* mask, const float* mean_obs) {
+  const double amu = cfg.bge_alpha_mu;
+  st->release();
+  st->alpha_lambd = cfg.bge_alpha_lambd > 0 ? cfg.bge_alpha_lambd : d + 2.0;
+  if (!(st->alpha_lambd > d + 1)) return fail("BGe: alpha_lambd must be > n_vars + 1");  // linearGaussian.py:47
+  const double small_t = amu * (st->alpha_lambd - d - 1) / (amu + 1);
+  st->alpha_mu = amu;
+  st->log_t = log(small_t);
   bool any = false;
   if (mask)
     for (int64_t i = 0; i < (int64_t)N * d; ++i) any |= mask[i] != 0;
-  e->n_mats = any ? d : 1;
-  std::vector<float> R((size_t)e->n_mats * d * d);
-  std::vector<double> Nj(d), gam((size_t)d * (d + 1)), xb(d);
-  for (int jm = 0; jm < e->n_mats; ++jm) {
+  st->n_mats = any ? d : 1;
+  const int n_mats = st->n_mats, dp = d + 1;
+  std::vector<float> R((size_t)n_mats * d * d), Rp((size_t)n_mats * dp * dp, 0.f), Qp((size_t)n_mats * dp * dp, 0.f);
+  std::vector<double> Nj(d), gam((size_t)d * (d + 1)), xb(d), ldR(n_mats), Rd((size_t)d * d);
+  for (int jm = 0; jm < n_mats; ++jm) {
     double Nn = 0;
     for (int n = 0; n < N; ++n) Nn += (any && mask[(int64_t)n * d + jm]) ? 0.0 : 1.0;
     for (int a = 0; a < d; ++a) {
@@ -292,29 +358,37 @@ static int bge_prepare(dibs_engine* e, const float* x, const int32_t* mask, cons
           if (!(any && mask[(int64_t)n * d + jm]))
             s += ((double)x[(int64_t)n * d + a] - xb[a]) * ((double)x[(int64_t)n * d + b] - xb[b]);
         const double ma = mean_obs ? (double)mean_obs[a] : 0.0, mb = mean_obs ? (double)mean_obs[b] : 0.0;
-        R[(size_t)jm * d * d + a * d + b] =
-            (float)((a == b ? small_t : 0.0) + s + (Nn * amu / (Nn + amu)) * (xb[a] - ma) * (xb[b] - mb));
+        const double v = (a == b ? small_t : 0.0) + s + (Nn * amu / (Nn + amu)) * (xb[a] - ma) * (xb[b] - mb);
+        Rd[(size_t)a * d + b] = v;
+        R[(size_t)jm * d * d + a * d + b] = (float)v;
+        Rp[(size_t)jm * dp * dp + (size_t)a * dp + b] = (float)v;
       }
+    if (!spd_inverse_logdet(Rd, d, &ldR[jm])) return fail("BGe: R is not positive definite");
+    for (int a = 0; a < d; ++a)
+      for (int b = 0; b < d; ++b) Qp[(size_t)jm * dp * dp + (size_t)a * dp + b] = (float)Rd[(size_t)a * d + b];
     if (any) Nj[jm] = Nn;
     else
       for (int j = 0; j < d; ++j) Nj[j] = Nn;
   }
   for (int j = 0; j < d; ++j)
     for (int l = 0; l <= d; ++l) {
-      const double Nn = Nj[j], al = e->alpha_lambd;
+      const double Nn = Nj[j], al = st->alpha_lambd;
       gam[(size_t)j * (d + 1) + l] = 0.5 * (log(amu) - log(Nn + amu)) + lgamma(0.5 * (Nn + al - d + l + 1)) -
                                      lgamma(0.5 * (al - d + l + 1)) - 0.5 * Nn * log(M_PI) +
                                      0.5 * (al - d + 2 * l + 1) * log(small_t);
     }
-  if (e->R) hipFree(e->R);
-  if (e->gam) hipFree(e->gam);
-  if (e->Nj) hipFree(e->Nj);
-  HIP_OK(dalloc(&e->R, R.size()));
-  HIP_OK(dalloc(&e->gam, gam.size()));
-  HIP_OK(dalloc(&e->Nj, Nj.size()));
-  HIP_OK(hipMemcpy(e->R, R.data(), R.size() * 4, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(e->gam, gam.data(), gam.size() * 8, hipMemcpyHostToDevice));
-  HIP_OK(hipMemcpy(e->Nj, Nj.data(), Nj.size() * 8, hipMemcpyHostToDevice));
+  HIP_OK(dalloc(&st->R, R.size()));
+  HIP_OK(dalloc(&st->Rp, Rp.size()));
+  HIP_OK(dalloc(&st->Qp, Qp.size()));
+  HIP_OK(dalloc(&st->gam, gam.size()));
+  HIP_OK(dalloc(&st->Nj, Nj.size()));
+  HIP_OK(dalloc(&st->ldR, ldR.size()));
+  HIP_OK(hipMemcpy(st->R, R.data(), R.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(st->Rp, Rp.data(), Rp.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(st->Qp, Qp.data(), Qp.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(st->gam, gam.data(), gam.size() * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(st->Nj, Nj.data(), Nj.size() * 8, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(st->ldR, ldR.data(), ldR.size() * 8, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -332,7 +406,7 @@ extern "C" int dibs_engine_set_data(dibs_engine* e, const float* x, const int32_
   if (e->cfg.likelihood == DIBS_LIK_BGE) {
     e->has_mean_obs = bge_mean_obs != nullptr;
     if (bge_mean_obs) e->mean_obs.assign(bge_mean_obs, bge_mean_obs + e->d);
-    if (bge_prepare(e, x, interv_mask, bge_mean_obs)) return 1;
+    if (bge_prepare(&e->bge, e->cfg, e->d, e->N, x, interv_mask, bge_mean_obs)) return 1;
   } else {
     if (joint_set_data(&e->jw, x, interv_mask, e->N, e->d)) return fail("joint_set_data failed");
   }
@@ -360,9 +434,8 @@ extern "C" int dibs_engine_init_particles(dibs_engine* e, const uint32_t key[2])
                          (uint64_t)e->m0 * e->P, tl, (float)e->cfg.lin_mean_edge, (float)e->cfg.lin_sig_edge,
                          (float)e->cfg.lin_min_edge, L);
     } else if (e->cfg.likelihood == DIBS_LIK_DENSENN) {
-      const int nt = e->Mloc * e->d;
-      hipLaunchKernelGGL(k_init_theta_nn, dim3((nt + 63) / 64), dim3(64), 0, e->stream, e->theta, (size_t)e->P, tsub, e->m0, e->Mloc,
-                         e->M, e->d, e->cfg.nn_hidden[0], e->cfg.nn_bias, (float)e->cfg.nn_sig_param, L);
+      const NNParams np_{e->cfg.nn_hidden[0], e->cfg.nn_activation, e->cfg.nn_bias, (float)e->cfg.nn_obs_noise, (float)e->cfg.nn_sig_param};
+      joint_nn_init_theta(e->theta, (size_t)e->P, tsub, e->m0, e->Mloc, e->M, e->d, np_, L, e->stream);
     } else {
       return fail("sample_parameters not implemented for this likelihood");
     }
@@ -452,43 +525,6 @@ static void drain_timers(dibs_engine* e) {
 // the host walks the chain (row 0), kernels derive row 1 + m.
 static Key2 next_carry(const dibs_engine* e, Key2 k) { return rng_split_row(k, (uint32_t)e->M + 1u, 0u, e->cfg.rng_layout); }
 
-// queued BGe problems (k_bge_big): one grid-stride launch over the four tiers, R in LDS when there is one matrix
-static void launch_bge_big(dibs_engine* e, const BgeParams& bp, const uint64_t* masks, double* ns, const BgeQueues& q, int S,
-                           unsigned long long* cnt) {
-  const bool rl = bp.n_mats == 1;
-  const int d = e->d, W = e->W;
-  const int n12 = 1024, n16 = 512, n32 = 512, ng = 256;
-  size_t lds = rl ? ((((size_t)d * d * 4) + 15) & ~(size_t)15) : 16;   // the per-lane tiers only keep R
-  for (int G : {32, 64}) lds = bge_big_lds_bytes(d, G, rl) > lds ? bge_big_lds_bytes(d, G, rl) : lds;
-  if (rl) {
-    allow_lds(k_bge_big<true>, lds);
-    hipLaunchKernelGGL(k_bge_big<true>, dim3(n12 + n16 + n32 + ng), dim3(256), lds, e->stream, masks, ns, bp, q, n12, n16, n32, d, S, W, cnt);
-  } else {
-    allow_lds(k_bge_big<false>, lds);
-    hipLaunchKernelGGL(k_bge_big<false>, dim3(n12 + n16 + n32 + ng), dim3(256), lds, e->stream, masks, ns, bp, q, n12, n16, n32, d, S, W, cnt);
-  }
-}
-
-template <int NT>
-static void launch_acyc(dibs_engine* e, Key2 carry, float alpha, const LikArgs& lik, int lik_blocks, size_t lik_lds) {
-  constexpr int DP = 16 * NT, LD = DP + 4;
-  size_t lds = (size_t)(3 * DP + 1) * LD * 4;  // + one slack row (the k pipeline may load one step past the end)
-  if (lik_blocks && lik_lds > lds) lds = lik_lds;
-  const bool paired = e->acyc_units != e->Sa;
-  const dim3 grid(e->acyc_nblk + lik_blocks, e->Mloc);  // blockIdx.x >= acyc_nblk: score-estimator blocks riding along
-  if (paired) {
-    allow_lds(k_acyc<NT, true>, lds);
-    hipLaunchKernelGGL((k_acyc<NT, true>), grid, dim3(256), lds, e->stream, e->scores, e->acyc_part, carry,
-                       e->m0, e->M, e->d, e->Sa, e->acyc_cpb, alpha, (float)e->cfg.tau, e->cfg.rng_layout,
-                       e->cfg.logistic_minval_tiny, e->acyc_nblk, lik);
-  } else {
-    allow_lds(k_acyc<NT, false>, lds);
-    hipLaunchKernelGGL((k_acyc<NT, false>), grid, dim3(256), lds, e->stream, e->scores, e->acyc_part, carry,
-                       e->m0, e->M, e->d, e->Sa, e->acyc_cpb, alpha, (float)e->cfg.tau, e->cfg.rng_layout,
-                       e->cfg.logistic_minval_tiny, e->acyc_nblk, lik);
-  }
-}
-
 static int step_local(dibs_engine* e, int t, float* pack) {
   const dibs_config& c = e->cfg;
   const float alpha = (float)(c.alpha_linear * t), beta = (float)(c.beta_linear * t);
@@ -517,55 +553,27 @@ static int step_local(dibs_engine* e, int t, float* pack) {
   int lik_blocks = 0;
   size_t lik_lds = 0;
   if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_REPARAM) {
-    const BgeSoftParams sp{e->R, e->Nj, e->alpha_lambd, e->bge_alpha_mu, e->bge_log_t, e->n_mats};
-    {
-      KTimer tm(e, DIBS_K_BGE_NODES);
-      const bool rl = e->n_mats == 1 && bge_soft_waves(e->d, true) >= 1;
-      const size_t lds = bge_soft_lds_bytes(e->d, rl);
-      if (rl) {
-        allow_lds(k_bge_soft<true>, lds);
-        hipLaunchKernelGGL(k_bge_soft<true>, dim3(e->S, e->Mloc), dim3(256), lds, e->stream, e->scores, sp, carry_lik, e->m0, e->M, e->d,
-                           e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny, e->soft_ds, e->logprobs_z);
-      } else {
-        allow_lds(k_bge_soft<false>, lds);
-        hipLaunchKernelGGL(k_bge_soft<false>, dim3(e->S, e->Mloc), dim3(256), lds, e->stream, e->scores, sp, carry_lik, e->m0, e->M, e->d,
-                           e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny, e->soft_ds, e->logprobs_z);
-      }
-    }
-    {
-      KTimer tm(e, DIBS_K_LIK_WEIGHTS);
-      hipLaunchKernelGGL(k_soft_combine, dim3(e->Mloc), dim3(256), (size_t)e->S * 4 + 16, e->stream, e->soft_ds, e->logprobs_z, e->w_lik,
-                         e->d, e->S);
-    }
+    const BgeSoftParams sp{e->bge.R, e->bge.Nj, e->bge.alpha_lambd, e->bge.alpha_mu, e->bge.log_t, e->bge.n_mats};
+    KTimer tm(e, DIBS_K_BGE_NODES);
+    bge_soft_launch(sp, e->scores, carry_lik, e->m0, e->M, e->Mloc, e->d, e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny,
+                    e->soft_ds, e->logprobs_z, e->w_lik, e->stream);
   } else if (c.likelihood == DIBS_LIK_BGE) {
-    BgeParams bp{e->R, e->gam, e->Nj, e->alpha_lambd, e->n_mats};
-    unsigned long long* cnt = e->profiling ? e->counters : (unsigned long long*)nullptr;
+    const BgeParams bp = e->bge.params();
     {  // (queue counters: zero at creation, reset by k_lik_weights_score at the end of every step)
       KTimer tm(e, DIBS_K_BGE_NODES);
-      const size_t lds4 = bge_lds_bytes(e->d, e->S, e->W, 4), lds1 = bge_lds_bytes(e->d, e->S, e->W, 1);
       KmatFuse kf{nullptr, nullptr, 0, 0, 0, 0.f, 0.f};
       e->kmat_fused = false;
-      if (e->n_mats == 1 && lds4 <= 80 * 1024) {
-        const int nbx = (e->d + 3) / 4;
-        size_t lds = lds4;
-        // single rank, vector fits one LDS chunk: the latent kernel matrix rides along (see KmatFuse)
-        if (e->Mloc == e->M && e->D <= KMAT_CH && (size_t)e->D * 4 + 64 <= 80 * 1024 && !getenv("DIBS_NO_KMAT_FUSE")) {
-          kf = KmatFuse{e->z, e->kz, (int)e->D, e->M, nbx, (float)c.scale_latent, (float)c.h_latent};
-          lds = lds4 > (size_t)e->D * 4 + 64 ? lds4 : (size_t)e->D * 4 + 64;
-          e->kmat_fused = true;
-        }
-        allow_lds(k_bge_nodes<4, true>, lds);
-        hipLaunchKernelGGL((k_bge_nodes<4, true>), dim3(nbx + (kf.z ? (e->M + KMAT_BT - 1) / KMAT_BT : 0), e->Mloc), dim3(256), lds,
-                           e->stream, e->thr, e->masks, e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L, cnt, e->bq, kf);
-      } else {
-        allow_lds(k_bge_nodes<1, true>, lds1);
-        hipLaunchKernelGGL((k_bge_nodes<1, true>), dim3(e->d, e->Mloc), dim3(64), lds1, e->stream, e->thr, e->masks,
-                           e->node_scores, bp, carry_lik, e->m0, e->M, e->d, e->S, e->W, L, cnt, e->bq, kf);
+      // single rank, vector fits one LDS chunk: the latent kernel matrix rides along (see KmatFuse)
+      if (e->Mloc == e->M && e->D <= KMAT_CH && (size_t)e->D * 4 + 64 <= 80 * 1024 && !getenv("DIBS_NO_KMAT_FUSE")) {
+        kf = KmatFuse{e->z, e->kz, (int)e->D, e->M, (e->d + 3) / 4, (float)c.scale_latent, (float)c.h_latent};
+        e->kmat_fused = true;
       }
+      bge_launch_sample(true, e->stream, e->thr, e->masks, e->node_scores, bp, carry_lik, e->m0, e->M, e->Mloc, e->d, e->S, e->W, L,
+                        e->bq, kf);
     }
     {
       KTimer tm(e, DIBS_K_BGE_BIG);
-      launch_bge_big(e, bp, e->masks, e->node_scores, e->bq, e->S, cnt);
+      bge_launch_chol(e->stream, e->masks, e->node_scores, bp, e->bq, e->d, e->S);
     }
     {
       const int ny = e->d < 8 ? e->d : 8;  // blocks per particle (2 / 4 / 8 / 16 measured: 26 / 19 / 17 / 19 us)
@@ -619,15 +627,9 @@ static int step_local(dibs_engine* e, int t, float* pack) {
   }
   {
     KTimer tm(e, DIBS_K_ACYC);
-    switch (e->acyc_nt) {
-      case 1: launch_acyc<1>(e, carry_prior, alpha, lik, lik_blocks, lik_lds); break;
-      case 2: launch_acyc<2>(e, carry_prior, alpha, lik, lik_blocks, lik_lds); break;
-      case 3: launch_acyc<3>(e, carry_prior, alpha, lik, lik_blocks, lik_lds); break;
-      case 4: launch_acyc<4>(e, carry_prior, alpha, lik, lik_blocks, lik_lds); break;
-      case 5: launch_acyc<5>(e, carry_prior, alpha, lik, lik_blocks, lik_lds); break;
-      case 6: launch_acyc<6>(e, carry_prior, alpha, lik, lik_blocks, lik_lds); break;
-      default: launch_acyc<7>(e, carry_prior, alpha, lik, lik_blocks, lik_lds); break;
-    }
+    const AcycLaunch al{e->stream, e->scores, e->acyc_part, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
+                        e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny};
+    acyc_launch(al, lik, lik_blocks, lik_lds);
   }
   {
     KTimer tm(e, DIBS_K_WTOTAL);
@@ -832,39 +834,21 @@ extern "C" int dibs_engine_get_counters(dibs_engine* e, double* out, int32_t n) 
   return 0;
 }
 
-// BGe statistics of an arbitrary data set (host, double) -> device buffers
-struct BgeStats {
-  float* R = nullptr;
-  double* gam = nullptr;
-  double* Nj = nullptr;
-  int n_mats = 1;
-  double alpha_lambd = 0;
-  ~BgeStats() {
-    if (R) hipFree(R);
-    if (gam) hipFree(gam);
-    if (Nj) hipFree(Nj);
+
+// device buffer that frees itself (error paths of dibs_score_graphs)
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  ~DevBuf() {
+    if (p) hipFree(p);
   }
+  hipError_t alloc(size_t n) { return dalloc(&p, n); }
 };
-
-template <int NT>
-static void launch_lin_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N,
-                             const dibs_config& c, hipStream_t stream) {
-  const size_t lds = lin_lds_bytes(d, N, NT, false);
-  allow_lds(k_lin_logprobs<NT>, lds);
-  hipLaunchKernelGGL(k_lin_logprobs<NT>, dim3(1, n), dim3(256), lds, stream, jw.x, jw.mask, theta, (const float*)nullptr,
-                     reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, N, 1, 1, 0.f, 1.f, 0, 0,
-                     (float)c.lin_obs_noise, (float)c.lin_mean_edge, (float)c.lin_sig_edge, jw.any_mask);
-}
-
-template <int NT>
-static void launch_nn_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N,
-                            const NNParams& np_, size_t P, hipStream_t stream) {
-  const size_t lds = nn_lds_bytes(d, N, NT, false);
-  allow_lds(k_nn_logprobs<NT, 4>, lds);
-  hipLaunchKernelGGL((k_nn_logprobs<NT, 4>), dim3(1, n), dim3(256), lds, stream, jw.x, jw.mask, theta, P, (const float*)nullptr,
-                     reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, N, 1, 1, 0.f, 1.f, 0, 0, np_,
-                     jw.any_mask, (const float*)nullptr);
-}
+struct JointWorkGuard {
+  JointWork jw;
+  JointWorkGuard() { memset(&jw, 0, sizeof jw); }
+  ~JointWorkGuard() { joint_free(&jw); }
+};
 
 extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* theta, int32_t n, const float* x_ho,
                                  const int32_t* mask_ho, int32_t n_ho, float* out) {
@@ -875,32 +859,23 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
   const dibs_config& c = e->cfg;
   const int d = e->d;
   const size_t dd = (size_t)d * d;
-  float* d_out = nullptr;
-  HIP_OK(dalloc(&d_out, (size_t)n));
-  int rc = 0;
+  DevBuf<float> d_out;
+  HIP_OK(d_out.alloc((size_t)n));
   if (c.likelihood == DIBS_LIK_BGE) {
-    // statistics of (x_ho, mask_ho): temporarily swap them into the engine, reuse bge_prepare
-    float* R0 = e->R; double *g0 = e->gam, *N0 = e->Nj; const int nm0 = e->n_mats, Nsave = e->N; const double al0 = e->alpha_lambd;
-    e->R = nullptr; e->gam = nullptr; e->Nj = nullptr; e->N = n_ho;
-    std::vector<float> mo;
-    if (e->has_mean_obs) mo = e->mean_obs;
-    rc = bge_prepare(e, x_ho, mask_ho, e->has_mean_obs ? mo.data() : nullptr);
-    BgeStats st;
-    st.R = e->R; st.gam = e->gam; st.Nj = e->Nj; st.n_mats = e->n_mats; st.alpha_lambd = e->alpha_lambd;
-    e->R = R0; e->gam = g0; e->Nj = N0; e->n_mats = nm0; e->N = Nsave; e->alpha_lambd = al0;
-    if (rc) { hipFree(d_out); return 1; }
+    BgeStats st;  // statistics of (x_ho, mask_ho)
+    if (bge_prepare(&st, c, d, n_ho, x_ho, mask_ho, e->has_mean_obs ? e->mean_obs.data() : nullptr)) return 1;
     const int W = e->W, CH = 512;
-    uint64_t* d_masks = nullptr;
-    double* d_ns = nullptr;
-    HIP_OK(dalloc(&d_masks, (size_t)d * CH * W));
-    HIP_OK(dalloc(&d_ns, (size_t)d * CH));
+    DevBuf<uint64_t> d_masks;
+    DevBuf<double> d_ns;
+    DevBuf<uint32_t> q_list;
+    DevBuf<unsigned int> q_counts;
+    HIP_OK(d_masks.alloc((size_t)d * CH * W));
+    HIP_OK(d_ns.alloc((size_t)d * CH));
+    HIP_OK(q_list.alloc((size_t)BGE_NQ * d * CH));
+    HIP_OK(q_counts.alloc((size_t)BGE_NQ));
+    const BgeQueues sq{q_list.p, q_counts.p, (uint32_t)(d * CH)};  // scratch queues for this call
+    const BgeParams bp = st.params();
     std::vector<uint64_t> hm((size_t)d * CH * W);
-    BgeQueues sq;  // scratch queues for this call
-    HIP_OK(dalloc(&sq.list12, (size_t)d * CH));
-    HIP_OK(dalloc(&sq.list16, (size_t)d * CH));
-    HIP_OK(dalloc(&sq.list32, (size_t)d * CH));
-    HIP_OK(dalloc(&sq.listg, (size_t)d * CH));
-    HIP_OK(dalloc(&sq.counts, (size_t)4));
     for (int q0 = 0; q0 < n; q0 += CH) {
       const int S = n - q0 < CH ? n - q0 : CH;
       std::fill(hm.begin(), hm.end(), 0ull);
@@ -908,86 +883,39 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
         for (int i = 0; i < d; ++i)
           for (int j = 0; j < d; ++j)
             if (i != j && g[(size_t)(q0 + s) * dd + (size_t)i * d + j] != 0) hm[((size_t)j * S + s) * W + (i >> 6)] |= 1ull << (i & 63);
-      HIP_OK(hipMemcpy(d_masks, hm.data(), (size_t)d * S * W * 8, hipMemcpyHostToDevice));
-      BgeParams bp{st.R, st.gam, st.Nj, st.alpha_lambd, st.n_mats};
-      const size_t lds4 = bge_lds_bytes(d, S, W, 4), lds1 = bge_lds_bytes(d, S, W, 1);
-      hipMemsetAsync(sq.counts, 0, 4 * sizeof(unsigned int), e->stream);
-      if (st.n_mats == 1 && lds4 <= 96 * 1024) {
-        allow_lds(k_bge_nodes<4, false>, lds4);
-        hipLaunchKernelGGL((k_bge_nodes<4, false>), dim3((d + 3) / 4, 1), dim3(256), lds4, e->stream, (const uint32_t*)nullptr,
-                           d_masks, d_ns, bp, Key2{0, 0}, 0, 1, d, S, W, 0, (unsigned long long*)nullptr, sq, KmatFuse{nullptr, nullptr, 0, 0, 0, 0.f, 0.f});
-      } else {
-        allow_lds(k_bge_nodes<1, false>, lds1);
-        hipLaunchKernelGGL((k_bge_nodes<1, false>), dim3(d, 1), dim3(64), lds1, e->stream, (const uint32_t*)nullptr, d_masks,
-                           d_ns, bp, Key2{0, 0}, 0, 1, d, S, W, 0, (unsigned long long*)nullptr, sq, KmatFuse{nullptr, nullptr, 0, 0, 0, 0.f, 0.f});
-      }
-      launch_bge_big(e, bp, d_masks, d_ns, sq, S, (unsigned long long*)nullptr);
-      hipLaunchKernelGGL(k_sum_nodes, dim3((S + 127) / 128), dim3(128), 0, e->stream, d_ns, d_out + q0, d, S);
+      HIP_OK(hipMemcpy(d_masks.p, hm.data(), (size_t)d * S * W * 8, hipMemcpyHostToDevice));
+      HIP_OK(hipMemsetAsync(sq.counts, 0, BGE_NQ * sizeof(unsigned int), e->stream));
+      bge_launch_sample(false, e->stream, nullptr, d_masks.p, d_ns.p, bp, Key2{0, 0}, 0, 1, 1, d, S, W, 0, sq,
+                        KmatFuse{nullptr, nullptr, 0, 0, 0, 0.f, 0.f});
+      bge_launch_chol(e->stream, d_masks.p, d_ns.p, bp, sq, d, S);
+      bge_launch_sum_nodes(e->stream, d_ns.p, d_out.p + q0, d, S);
       HIP_OK(hipStreamSynchronize(e->stream));
     }
-    hipFree(d_masks);
-    hipFree(d_ns);
-    hipFree(sq.list12);
-    hipFree(sq.list16);
-    hipFree(sq.list32);
-    hipFree(sq.listg);
-    hipFree(sq.counts);
-  } else if (c.likelihood == DIBS_LIK_LINGAUSS) {
-    if (!theta) { hipFree(d_out); return fail("theta required"); }
-    JointWork jw;
-    memset(&jw, 0, sizeof jw);
-    if (joint_set_data(&jw, x_ho, mask_ho, n_ho, d)) { hipFree(d_out); return fail("joint_set_data failed"); }
-    float* d_th = nullptr;
-    int32_t* d_g = nullptr;
-    HIP_OK(dalloc(&d_th, (size_t)n * dd));
-    HIP_OK(dalloc(&d_g, (size_t)n * dd));
-    HIP_OK(hipMemcpy(d_th, theta, (size_t)n * dd * 4, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(d_g, g, (size_t)n * dd * 4, hipMemcpyHostToDevice));
-    switch ((d + 15) / 16) {
-      case 1: launch_lin_given<1>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
-      case 2: launch_lin_given<2>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
-      case 3: launch_lin_given<3>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
-      case 4: launch_lin_given<4>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
-      case 5: launch_lin_given<5>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
-      case 6: launch_lin_given<6>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
-      default: launch_lin_given<7>(jw, d_th, d_g, d_out, n, d, n_ho, c, e->stream); break;
+  } else if (c.likelihood == DIBS_LIK_LINGAUSS || c.likelihood == DIBS_LIK_DENSENN) {
+    if (!theta) return fail("theta required");
+    const bool nn = c.likelihood == DIBS_LIK_DENSENN;
+    if (nn && n_ho > 128) return fail("DenseNonlinearGaussian: at most 128 observations per scoring call");
+    JointWorkGuard jg;
+    if (joint_set_data(&jg.jw, x_ho, mask_ho, n_ho, d)) return fail("joint_set_data failed");
+    const size_t P = nn ? (size_t)e->P : dd;
+    DevBuf<float> d_th;
+    DevBuf<int32_t> d_g;
+    HIP_OK(d_th.alloc((size_t)n * P));
+    HIP_OK(d_g.alloc((size_t)n * dd));
+    HIP_OK(hipMemcpy(d_th.p, theta, (size_t)n * P * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_g.p, g, (size_t)n * dd * 4, hipMemcpyHostToDevice));
+    if (nn) {
+      const NNParams np_{c.nn_hidden[0], c.nn_activation, c.nn_bias, (float)c.nn_obs_noise, (float)c.nn_sig_param};
+      joint_nn_score_given(jg.jw, d_th.p, d_g.p, d_out.p, n, d, n_ho, np_, P, e->stream);
+    } else {
+      joint_lin_score_given(jg.jw, d_th.p, d_g.p, d_out.p, n, d, n_ho, (float)c.lin_obs_noise, (float)c.lin_mean_edge,
+                            (float)c.lin_sig_edge, e->stream);
     }
     HIP_OK(hipStreamSynchronize(e->stream));
-    hipFree(d_th);
-    hipFree(d_g);
-    joint_free(&jw);
-  } else if (c.likelihood == DIBS_LIK_DENSENN) {
-    if (!theta) { hipFree(d_out); return fail("theta required"); }
-    if (n_ho > 128) { hipFree(d_out); return fail("DenseNonlinearGaussian: at most 128 observations per scoring call"); }
-    JointWork jw;
-    memset(&jw, 0, sizeof jw);
-    if (joint_set_data(&jw, x_ho, mask_ho, n_ho, d)) { hipFree(d_out); return fail("joint_set_data failed"); }
-    float* d_th = nullptr;
-    int32_t* d_g = nullptr;
-    HIP_OK(dalloc(&d_th, (size_t)n * e->P));
-    HIP_OK(dalloc(&d_g, (size_t)n * dd));
-    HIP_OK(hipMemcpy(d_th, theta, (size_t)n * e->P * 4, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(d_g, g, (size_t)n * dd * 4, hipMemcpyHostToDevice));
-    const NNParams np_{c.nn_hidden[0], c.nn_activation, c.nn_bias, (float)c.nn_obs_noise, (float)c.nn_sig_param};
-    switch ((d + 15) / 16) {
-      case 1: launch_nn_given<1>(jw, d_th, d_g, d_out, n, d, n_ho, np_, (size_t)e->P, e->stream); break;
-      case 2: launch_nn_given<2>(jw, d_th, d_g, d_out, n, d, n_ho, np_, (size_t)e->P, e->stream); break;
-      case 3: launch_nn_given<3>(jw, d_th, d_g, d_out, n, d, n_ho, np_, (size_t)e->P, e->stream); break;
-      case 4: launch_nn_given<4>(jw, d_th, d_g, d_out, n, d, n_ho, np_, (size_t)e->P, e->stream); break;
-      case 5: launch_nn_given<5>(jw, d_th, d_g, d_out, n, d, n_ho, np_, (size_t)e->P, e->stream); break;
-      case 6: launch_nn_given<6>(jw, d_th, d_g, d_out, n, d, n_ho, np_, (size_t)e->P, e->stream); break;
-      default: launch_nn_given<7>(jw, d_th, d_g, d_out, n, d, n_ho, np_, (size_t)e->P, e->stream); break;
-    }
-    HIP_OK(hipStreamSynchronize(e->stream));
-    hipFree(d_th);
-    hipFree(d_g);
-    joint_free(&jw);
   } else {
-    hipFree(d_out);
     return fail("dibs_score_graphs: likelihood not supported yet");
   }
   HIP_OK(hipGetLastError());
-  HIP_OK(hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
-  hipFree(d_out);
+  HIP_OK(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
   return 0;
 }

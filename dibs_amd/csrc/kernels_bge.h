@@ -1,0 +1,591 @@
+// BGe marginal likelihood of sampled graphs (gfx950): Bernoulli sampling of the parent sets, then one small Cholesky
+// factorisation per (particle m, sample s, node j).
+//   reference: dibs/inference/dibs.py:102-119 (sample_g), dibs/models/linearGaussian.py:63-118 (BGe node score),
+//              dibs/utils/func.py:128-145 (masked slogdet)
+//
+// For node j with parent set pa (l = |pa|) the reference needs logdet R[pa,pa] and logdet R[pa+j,pa+j] (as slogdet of the
+// masked d x d matrix; SURVEY.md 8(a) E1 shows the identity).  With j ordered LAST in a Cholesky factorisation of
+// A = R[pa+j, pa+j] the leading l pivots give the first determinant and the last pivot is the Schur complement
+//   score = gam(j, l) - 1/2 logdet R[pa,pa] - 1/2 (N + alpha_lambd - d + l + 1) log(schur).
+// When the parent set is larger than its complement the SAME two determinants come from the complementary minors of
+// Q = R^-1 (Jacobi: det R[A,A] = det R * det Q[V\A, V\A]): factorise Q[C+j, C+j], C = V \ (pa+j), j last, leading pivots
+// -> logdet Q[C,C] =: ld, last pivot pi:
+//   score = gam(j, l) - 1/2 (logdet R + ld) + 1/2 (N + alpha_lambd - d + l) log(pi).
+// So every problem has n = min(l + 1, d - l) <= (d + 1) / 2 rows.
+//
+// Two launches per step:
+//   k_bge_sample  one wave per (m, j): Threefry -> parent-set bit masks of all S samples (bit-exact with the reference's
+//                 stream), problems appended to one queue per size tier (n <= 4, 8, ..., 32, larger)
+//   k_bge_chol    persistent blocks work the queues off, largest tier first:
+//                   n <= 16   one problem per LANE, the whole factor in registers;
+//                   n <= 32   one problem per QUAD (4 lanes): lane q owns rows q, q+4, ...; the pivot row is broadcast with
+//                             DPP quad_perm inside v_fmac_f32_dpp, so a column step is one instruction per (row block, p);
+//                   larger    one problem per wave, factor in LDS (only reached for d > 64).
+#pragma once
+#include "common.h"
+#include "kernels_kmat.h"
+
+#define BGE_NQ 9  // queue tiers: q = (n + 3) / 4 - 1 for n <= 32, 8 for larger problems
+
+struct BgeParams {
+  const float* Rp;      // [n_mats, d+1, d+1]  R with a zero row / column d (index d = "no variable": padding rows of a tier)
+  const float* Qp;      // [n_mats, d+1, d+1]  R^-1, same layout
+  const double* gam;    // [d, d+1]  log_gamma_term(j, l)
+  const double* Nj;     // [d]
+  const double* ldR;    // [n_mats]  logdet R
+  double alpha_lambd;
+  int n_mats;
+};
+
+struct BgeQueues {
+  uint32_t* list;        // [BGE_NQ][cap] problem codes (m * d + j) * S + s
+  unsigned int* counts;  // [BGE_NQ]: zero at creation, reset by the consumer of the node scores after every use
+  uint32_t cap;
+};
+
+__host__ __device__ inline int bge_rows(int l, int d) { return l + 1 <= d - l ? l + 1 : d - l; }
+__host__ __device__ inline int bge_tier(int n) { return n <= 32 ? (n + 3) / 4 - 1 : BGE_NQ - 1; }
+
+// log(x) of a positive float with ~1e-7 ABSOLUTE error: x = 2^e m, m in [sqrt(1/2), sqrt(2)), log m = 2 atanh((m-1)/(m+1)).
+// (The Schur complement enters the score with a factor ~ (N + l) / 2: the relative error of logf on a value like log(400)
+//  would be amplified to 1e-5 .. 1e-4; a double-precision log costs ~100 instructions per problem.)
+__device__ __forceinline__ double bge_log(float x) {
+  int e;
+  float m = frexpf(x, &e);  // m in [0.5, 1)
+  if (m < 0.70710678f) {
+    m *= 2.0f;
+    e -= 1;
+  }
+  const float r = (m - 1.0f) / (m + 1.0f), r2 = r * r;
+  const float p = fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, 2.0f / 11.0f, 2.0f / 9.0f), 2.0f / 7.0f), 2.0f / 5.0f), 2.0f / 3.0f), 2.0f);
+  return (double)e * 0.6931471805599453 + (double)(r * p);
+}
+
+// node score from the factorisation: ld2 = sum of log2 of the leading pivots, last = last pivot (see the file header)
+__device__ __forceinline__ double bge_score(const BgeParams& bp, int j, int l, int d, bool comp, float ld2, float last) {
+  const double Nn = bp.Nj[j];
+  if (!(Nn > 0.0)) return 0.0;  // linearGaussian.py:118
+  const double c = Nn + bp.alpha_lambd - d + l;
+  const double g = bp.gam[(size_t)j * (d + 1) + l], ld = 0.6931471805599453 * (double)ld2, ll = bge_log(last);
+  return comp ? g - 0.5 * (bp.ldR[bp.n_mats > 1 ? j : 0] + ld) + 0.5 * c * ll : g - 0.5 * ld - 0.5 * (c + 1.0) * ll;
+}
+
+// index set of a problem: the parents (or, complement form, the non-parents other than j) as a bit mask over the d variables
+__device__ __forceinline__ void bge_index_mask(uint64_t& w0, uint64_t& w1, int j, int d, bool comp) {
+  if (!comp) return;
+  const uint64_t v0 = d >= 64 ? ~0ull : (1ull << d) - 1ull, v1 = d > 64 ? (d >= 128 ? ~0ull : (1ull << (d - 64)) - 1ull) : 0ull;
+  w0 = ~w0 & v0;
+  w1 = ~w1 & v1;
+  if (j < 64) w0 &= ~(1ull << j);
+  else w1 &= ~(1ull << (j - 64));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2  sampling + queueing.  grid = (ceil(d / WAVES) [+ kernel-matrix blocks], Mloc), block = 64 * WAVES
+//     layouts: masks [Mloc][d][S][W] u64, node_scores [Mloc][d][S] f64
+//     SAMPLE = false: the parent sets are given (dibs_score_graphs), only the queueing runs
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t bge_sample_wave_bytes(int d, int S, int W) {
+  // masks[S*W] u64 | thr[d] | lim[d] | loc[S]
+  return ((size_t)S * W * 8 + (size_t)2 * d * 4 + (size_t)S * 4 + 15) & ~(size_t)15;
+}
+
+template <int WAVES, bool SAMPLE>
+__global__ __launch_bounds__(64 * WAVES) void k_bge_sample(const uint32_t* __restrict__ thr, uint64_t* __restrict__ masks,
+                                                           double* __restrict__ node_scores, BgeParams bp, Key2 carry, int m0,
+                                                           int M_global, int d, int S, int W, int layout, BgeQueues qs, KmatFuse kf) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (kf.z && (int)blockIdx.x >= kf.nbx) {  // kernel-matrix role (block-uniform; WAVES == 4): see KmatFuse
+    kmat_block(reinterpret_cast<float*>(smem_raw), kf.z, (size_t)kf.len, (size_t)0, kf.len, kf.kout, 0, kf.M, kf.scale, kf.h, 1,
+               (int)blockIdx.y, (int)blockIdx.x - kf.nbx);
+    return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = blockIdx.y;
+  const int j = blockIdx.x * WAVES + wave;
+  const bool active = j < d;
+  unsigned char* wbase = smem_raw + (size_t)wave * bge_sample_wave_bytes(d, S, W);
+  uint64_t* mk = reinterpret_cast<uint64_t*>(wbase);
+  uint32_t* thrs = reinterpret_cast<uint32_t*>(mk + (size_t)S * W);
+  // lim = 512 * thr:  y < lim  <=>  (y >> 9) < thr.  thr == 2^23 (p == 1.0f) has no 32-bit lim; those rows are forced on.
+  uint32_t* lims = thrs + d;
+  uint32_t* loc = lims + d;  // per sample: queue tier << 28 | index inside this block's reservation, or ~0
+  __shared__ unsigned int blk_cnt[BGE_NQ], blk_base[BGE_NQ];
+  if (tid < BGE_NQ) blk_cnt[tid] = 0u;
+  uint64_t force0 = 0, force1 = 0;
+  if (active && SAMPLE) {
+    for (int i0 = 0; i0 < d; i0 += 64) {
+      const int i = i0 + lane;
+      const uint32_t t = i < d ? thr[((size_t)m * d + i) * d + j] : 0u;
+      if (i < d) {
+        thrs[i] = t;
+        lims[i] = t >= 0x800000u ? 0xFFFFFFFFu : t << 9;
+      }
+      const uint64_t f = __ballot(t >= 0x800000u);
+      if (i0 == 0) force0 = f; else force1 = f;
+    }
+  }
+  __syncthreads();
+  if (active) {
+    if (!SAMPLE) {
+      const uint64_t* mg = masks + ((size_t)m * d + j) * S * W;
+      for (int e = lane; e < S * W; e += 64) mk[e] = mg[e];
+    }
+    // ---- 1. sample column j of the S graphs -----------------------------------------------------
+    // particle key = row (1 + m_global) of split(carry, M+1); subk_ = row 1 of split(particle key)   dibs.py:350-351
+    const Key2 kp = rng_split_row_uniform(carry, (uint32_t)M_global + 1u, (uint32_t)(m0 + m) + 1u, layout);
+    const Key2 kg = rng_split_row_uniform(kp, 2u, 1u, layout);
+    const uint64_t dd = (uint64_t)d * d, nbits = (uint64_t)S * dd;
+    if (!SAMPLE) {
+    } else if ((S & 1) == 0) {
+      const int hS = S >> 1;
+      for (int p = lane; p < hS; p += 64) {
+        uint64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+        const uint64_t cbase = (uint64_t)p * dd + j;
+        if (layout == 0 && nbits < 0xFFFFFFFFull) {
+          // legacy layout, 32-bit counters: element c pairs with c + n/2 in one Threefry call.  The kernel is bound by VALU
+          // issue and this loop is most of it: per output bit one compare and one add-with-carry (word = 2 * word + bit,
+          // i.e. rows arrive MSB first and the word is bit-reversed once at the end).
+          const TfKeys tk = tf_keys(kg);
+          uint32_t c0 = (uint32_t)cbase, c1 = (uint32_t)cbase + (uint32_t)(nbits >> 1);
+          uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int w32 = 0; w32 < 4; ++w32) {
+            const int i0 = w32 * 32;
+            if (i0 < d) {
+              const int i1 = d < i0 + 32 ? d : i0 + 32;
+              uint32_t A = 0u, B = 0u;
+              int i = i0;
+              for (; i + 1 < i1; i += 2, c0 += 2u * (uint32_t)d, c1 += 2u * (uint32_t)d) {
+                uint32_t y0, y1, y2, y3;
+                threefry2x32_uk2(tk, c0, c1, c0 + (uint32_t)d, c1 + (uint32_t)d, y0, y1, y2, y3);
+                const uint32_t L = lims[i], L2 = lims[i + 1];
+                asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(A) : "v"(y0), "v"(L) : "vcc");
+                asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(B) : "v"(y1), "v"(L) : "vcc");
+                asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(A) : "v"(y2), "v"(L2) : "vcc");
+                asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(B) : "v"(y3), "v"(L2) : "vcc");
+              }
+              if (i < i1) {
+                uint32_t y0, y1;
+                threefry2x32_uk(tk, c0, c1, y0, y1);
+                const uint32_t L = lims[i];
+                asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(A) : "v"(y0), "v"(L) : "vcc");
+                asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(B) : "v"(y1), "v"(L) : "vcc");
+                c0 += (uint32_t)d;
+                c1 += (uint32_t)d;
+              }
+              wa[w32] = __brev(A) >> (32 - (i1 - i0));
+              wb[w32] = __brev(B) >> (32 - (i1 - i0));
+            }
+          }
+          a0 = (((uint64_t)wa[1] << 32) | wa[0]) | force0;
+          b0 = (((uint64_t)wb[1] << 32) | wb[0]) | force0;
+          a1 = (((uint64_t)wa[3] << 32) | wa[2]) | force1;
+          b1 = (((uint64_t)wb[3] << 32) | wb[2]) | force1;
+        } else {
+          for (int i = 0; i < d; ++i) {
+            uint32_t y0, y1;
+            rng_bits_pair(kg, nbits, cbase + (uint64_t)i * d, layout, y0, y1);
+            const uint32_t t = thrs[i];
+            const uint64_t ba = (uint64_t)((y0 >> 9) < t) << (i & 63), bb = (uint64_t)((y1 >> 9) < t) << (i & 63);
+            if (i < 64) { a0 |= ba; b0 |= bb; } else { a1 |= ba; b1 |= bb; }
+          }
+        }
+        mk[p * W] = a0;
+        mk[(p + hS) * W] = b0;
+        if (W > 1) { mk[p * W + 1] = a1; mk[(p + hS) * W + 1] = b1; }
+      }
+    } else {
+      for (int s = lane; s < S; s += 64) {
+        uint64_t a0 = 0, a1 = 0;
+        for (int i = 0; i < d; ++i) {
+          const uint32_t y = rng_bits_at(kg, nbits, (uint64_t)s * dd + (uint64_t)i * d + j, layout);
+          const uint64_t ba = (uint64_t)((y >> 9) < thrs[i]) << (i & 63);
+          if (i < 64) a0 |= ba; else a1 |= ba;
+        }
+        mk[s * W] = a0;
+        if (W > 1) mk[s * W + 1] = a1;
+      }
+    }
+    wave_lds_fence();
+    if (SAMPLE) {
+      uint64_t* mg = masks + ((size_t)m * d + j) * S * W;
+      for (int e = lane; e < S * W; e += 64) mg[e] = mk[e];
+    }
+
+    // ---- 2. no parents: closed form (logdet of the empty minor is 0, Schur complement R_jj); the rest is queued by size.
+    // Slots are reserved per BLOCK (LDS counters here, one global atomicAdd per tier and block below): same-address global
+    // atomics from every wave were the bottleneck while most problems are still queued.
+    const float rjj = bp.Rp[(bp.n_mats > 1 ? (size_t)j * (d + 1) * (d + 1) : 0) + (size_t)j * (d + 1) + j];
+    const double score_l0 = bge_score(bp, j, 0, d, false, 0.f, rjj);
+    double* ns_out = node_scores + ((size_t)m * d + j) * S;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      const int s = s0 + lane;
+      const bool valid = s < S;
+      const uint64_t w0 = valid ? mk[s * W] : 0ull, w1 = (valid && W > 1) ? mk[s * W + 1] : 0ull;
+      const int l = __popcll(w0) + __popcll(w1);
+      if (valid && l == 0) ns_out[s] = score_l0;
+      const int tier = (valid && l > 0) ? bge_tier(bge_rows(l, d)) : -1;
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      uint32_t myloc = 0xFFFFFFFFu;
+      for (int tq = 0; tq < BGE_NQ; ++tq) {
+        const unsigned long long bal = __ballot(tier == tq);
+        if (bal) {
+          const int leader = __ffsll((long long)bal) - 1;
+          unsigned int base = 0;
+          if (lane == leader) base = atomicAdd(&blk_cnt[tq], (unsigned int)__popcll(bal));
+          base = __shfl(base, leader, 64);
+          if (tier == tq) myloc = ((uint32_t)tq << 28) | (base + (unsigned int)__popcll(bal & lt));
+        }
+      }
+      if (valid) loc[s] = myloc;
+    }
+  }  // active
+  __syncthreads();
+  if (tid < BGE_NQ) {
+    const unsigned int c = blk_cnt[tid];
+    blk_base[tid] = c ? atomicAdd(&qs.counts[tid], c) : 0u;
+  }
+  __syncthreads();
+  if (active)
+    for (int s = lane; s < S; s += 64) {
+      const uint32_t v = loc[s];
+      if (v != 0xFFFFFFFFu) {
+        const uint32_t tq = v >> 28;
+        qs.list[(size_t)tq * qs.cap + blk_base[tq] + (v & 0x0FFFFFFFu)] = (uint32_t)(((size_t)m * d + j) * S + s);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3  queued factorisations
+// ------------------------------------------------------------------------------------------------
+// One problem per LANE, n <= NMAX: indices and the lower triangle in registers, fully unrolled.  Rows n .. NMAX-1 are padding:
+// their index is d (the zero row / column of Rp) and their diagonal is set to 1, so the unrolled code is the same for every lane
+// and the padding pivots are exactly 1 (log2 = 0).  `mat` = offset (floats) of this problem's matrix (R or Q, of node j) from `R`.
+template <int NMAX, bool W2>
+__device__ __forceinline__ void bge_chol_lane(const float* __restrict__ R, int mat, int ldr, int d, uint64_t w0, uint64_t w1, int j,
+                                              int li /* index-set size = n - 1 */, float& ld2, float& last) {
+  int idx[NMAX];
+#pragma unroll
+  for (int t = 0; t < NMAX; ++t) {
+    int b = d;
+    if (w0) { b = __ffsll((long long)w0) - 1; w0 &= w0 - 1; }
+    else if (W2 && w1) { b = 64 + __ffsll((long long)w1) - 1; w1 &= w1 - 1; }
+    idx[t] = (t == li) ? j : b;
+  }
+  float A[NMAX][NMAX];
+#pragma unroll
+  for (int r = 0; r < NMAX; ++r) {
+    const int ro = mat + idx[r] * ldr;
+#pragma unroll
+    for (int c = 0; c <= r; ++c) A[r][c] = R[ro + idx[c]];
+    if (r > li) A[r][r] = 1.0f;
+  }
+  float lsum = 0.f, lst = 1.f;
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) {
+    float dk = A[k][k];
+#pragma unroll
+    for (int p = 0; p < k; ++p) dk = fmaf(-A[k][p], A[k][p], dk);
+    lsum += __log2f(dk);
+    lst = (k == li) ? dk : lst;
+    const float inv = __builtin_amdgcn_rsqf(dk);
+#pragma unroll
+    for (int r = k + 1; r < NMAX; ++r) {
+      float v = A[r][k];
+#pragma unroll
+      for (int p = 0; p < k; ++p) v = fmaf(-A[r][p], A[k][p], v);
+      A[r][k] = v * inv;
+    }
+  }
+  ld2 = lsum - __log2f(lst);  // leading pivots only (the padding pivots are 1)
+  last = lst;
+}
+
+// acc -= bcast_quad(b, lane C) * own   -- one VALU instruction (DPP quad_perm broadcast of the first source)
+__device__ __forceinline__ void fmac_quad(float& acc, const float& b, const float& own, int c) {
+  switch (c) {
+    case 0: asm volatile("v_fmac_f32_dpp %0, -%1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(own)); break;
+    case 1: asm volatile("v_fmac_f32_dpp %0, -%1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(own)); break;
+    case 2: asm volatile("v_fmac_f32_dpp %0, -%1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(own)); break;
+    default: asm volatile("v_fmac_f32_dpp %0, -%1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(own)); break;
+  }
+}
+// (s_nop 1: a DPP read needs two wait states after the VALU write of its source; the writer here is the last v_fmac above it)
+__device__ __forceinline__ float bcast_quad(const float& v, int c) {
+  float o;
+  switch (c) {
+    case 0: asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v)); break;
+    case 1: asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v)); break;
+    case 2: asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v)); break;
+    default: asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v)); break;
+  }
+  return o;
+}
+
+// column step K of the quad factorisation as a template recursion: every register index is a compile-time constant
+template <int NB, int K>
+struct BgeQuadCol {
+  static __device__ __forceinline__ void run(float (&L)[NB][4 * NB], int li, float& lsum, float& lst) {
+    constexpr int kb = K >> 2, kq = K & 3;
+#pragma unroll
+    for (int p = 0; p < K; ++p)
+#pragma unroll
+      for (int a = kb; a < NB; ++a) fmac_quad(L[a][K], L[kb][p], L[a][p], kq);
+    const float piv = bcast_quad(L[kb][K], kq);
+    lsum += __log2f(piv);
+    lst = (K == li) ? piv : lst;
+    float inv = __builtin_amdgcn_rsqf(piv);
+    // gfx950: a VALU instruction must not read the result of a transcendental op in the next issue slot; hipcc inserts that
+    // wait state for its own instructions but not in front of an asm statement
+    asm volatile("s_nop 1" : "+v"(inv));
+#pragma unroll
+    for (int a = kb; a < NB; ++a) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(L[a][K]) : "v"(inv));
+    BgeQuadCol<NB, K + 1>::run(L, li, lsum, lst);
+  }
+};
+template <int NB>
+struct BgeQuadCol<NB, 4 * NB> {
+  static __device__ __forceinline__ void run(float (&)[NB][4 * NB], int, float&, float&) {}
+};
+
+// One problem per QUAD, n <= 4 NB.  Lane q of the quad owns rows q, q + 4, ...: L[a][c] is row 4a + q, column c <= 4a + 3
+// (entries right of the diagonal are zero-filled scratch).  Column step k (row k lives in lane k % 4, block k / 4):
+//   L[a][k] -= L[a][p] * bcast(L[k/4][p], lane k%4)   for p < k, a >= k/4        (v_fmac_f32_dpp)
+//   pivot = bcast(L[k/4][k]);  L[a][k] *= rsqrt(pivot)
+// Rows above k inside block k/4 compute garbage that only ever feeds themselves.  `qidx`: this quad's index list in LDS
+// (QS ints, 16-byte aligned).
+#define BGE_QS 36
+template <int NB, bool W2>
+__device__ __forceinline__ void bge_chol_quad(const float* __restrict__ R, int mat, int ldr, int d, int* __restrict__ qidx,
+                                              uint64_t w0, uint64_t w1, int j, int li, float& ld2, float& last) {
+  constexpr int N = 4 * NB;
+  const int q = threadIdx.x & 3;
+  // ---- index list: padding = d, lane q extracts the set bits of its quarter of the mask, j goes last
+#pragma unroll
+  for (int t = 0; t < NB; ++t) qidx[4 * t + q] = d;
+  wave_lds_fence();
+  {
+    uint32_t chunk;
+    int base_bit, t;
+    if (W2) {
+      const uint64_t w = q < 2 ? w0 : w1;
+      chunk = (uint32_t)(w >> (32 * (q & 1)));
+      base_bit = 32 * q;
+      t = (q >= 2 ? __popcll(w0) : 0) + ((q & 1) ? __popc((uint32_t)w) : 0);
+    } else {
+      chunk = (uint32_t)(w0 >> (16 * q)) & 0xFFFFu;
+      base_bit = 16 * q;
+      t = __popcll(w0 & ((1ull << (16 * q)) - 1ull));
+    }
+    while (__any(chunk != 0u)) {
+      if (chunk) {
+        const int b = __ffs((int)chunk) - 1;
+        chunk &= chunk - 1u;
+        if (t < N) qidx[t] = base_bit + b;
+        ++t;
+      }
+    }
+  }
+  wave_lds_fence();
+  if (q == 0 && li < N) qidx[li] = j;
+  wave_lds_fence();
+  int cidx[N], ro[NB];
+#pragma unroll
+  for (int t = 0; t < NB; ++t) {
+    const int4 v = *reinterpret_cast<const int4*>(qidx + 4 * t);
+    cidx[4 * t] = v.x; cidx[4 * t + 1] = v.y; cidx[4 * t + 2] = v.z; cidx[4 * t + 3] = v.w;
+  }
+#pragma unroll
+  for (int a = 0; a < NB; ++a) ro[a] = mat + qidx[4 * a + q] * ldr;
+  // ---- gather
+  float L[NB][N];
+#pragma unroll
+  for (int a = 0; a < NB; ++a) {
+#pragma unroll
+    for (int c = 0; c < 4 * a + 4; ++c) {
+      float v = R[ro[a] + cidx[c]];
+      if (c > 4 * a) v = (c - 4 * a <= q) ? v : 0.f;                   // right of the diagonal of this lane's row
+      if (c >= 4 * a) v = (c - 4 * a == q && 4 * a + q > li) ? 1.f : v;  // padding row: unit diagonal
+      L[a][c] = v;
+    }
+  }
+  // every entry is pinned into its register HERE: hipcc would otherwise sink the selects above to their first use, i.e. directly in
+  // front of an asm statement that reads them through DPP (two wait states needed, and it cannot see inside the asm)
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int c = 0; c < 4 * a + 4; ++c) asm volatile("" : "+v"(L[a][c]));
+  asm volatile("s_nop 1" ::: "memory");
+  float lsum = 0.f, lst = 1.f;
+  BgeQuadCol<NB, 0>::run(L, li, lsum, lst);
+  ld2 = lsum - __log2f(lst);
+  last = lst;
+}
+
+// One problem per WAVE, any n <= 128: lane owns rows r and r + 64, the factor lives in LDS (Lb: [d][d|1] floats + index list).
+__host__ __device__ inline size_t bge_generic_wave_bytes(int d) {
+  return ((((size_t)d * (d | 1) + 3) & ~(size_t)3) * 4 + (size_t)(d + 4) * 4 + 15) & ~(size_t)15;
+}
+__device__ __forceinline__ void bge_chol_wave(const float* __restrict__ R, int mat, int ldr, int d, unsigned char* wbase, uint64_t w0,
+                                              uint64_t w1, int j, int li, float& ld2, float& last) {
+  const int lane = threadIdx.x & 63;
+  float* Lb = reinterpret_cast<float*>(wbase);
+  int* myidx = reinterpret_cast<int*>(Lb + (((size_t)d * (d | 1) + 3) & ~(size_t)3));
+  const int ldl = d | 1, n = li + 1;
+  if ((w0 >> lane) & 1ull) myidx[__popcll(w0 & ((1ull << lane) - 1ull))] = lane;
+  if ((w1 >> lane) & 1ull) myidx[__popcll(w0) + __popcll(w1 & ((1ull << lane) - 1ull))] = 64 + lane;
+  if (lane == 0) myidx[li] = j;
+  wave_lds_fence();
+  float mypiv[2] = {1.f, 1.f};
+  for (int kk = 0; kk < n; ++kk) {
+    const int ik = myidx[kk];
+    float accs[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = lane + h * 64;
+      float acc = 0.f;
+      if (r >= kk && r < n) {
+        acc = R[mat + myidx[r] * ldr + ik];
+        const float* lr = Lb + (size_t)r * ldl;
+        const float* lk = Lb + (size_t)kk * ldl;
+#pragma unroll 8
+        for (int p = 0; p < kk; ++p) acc = fmaf(-lr[p], lk[p], acc);  // (unrolled: several LDS reads in flight)
+      }
+      accs[h] = acc;
+      if (r == kk) mypiv[h] = acc;
+    }
+    const float piv = __shfl(kk < 64 ? accs[0] : accs[1], kk & 63, 64);
+    const float inv = __builtin_amdgcn_rsqf(piv);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = lane + h * 64;
+      if (r > kk && r < n) Lb[(size_t)r * ldl + kk] = accs[h] * inv;
+    }
+    wave_lds_fence();
+  }
+  float lg = 0.f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = lane + h * 64;
+    if (r < li) lg += __log2f(mypiv[h]);
+  }
+  ld2 = wave_sum(lg);
+  last = __shfl(li < 64 ? mypiv[0] : mypiv[1], li & 63, 64);
+  wave_lds_fence();
+}
+
+// waves of a block that can work in the one-problem-per-wave tier (each needs a d x d factor in LDS)
+__host__ __device__ inline int bge_generic_waves(int d, bool r_in_lds) {
+  const size_t r = r_in_lds ? (((size_t)2 * (d + 1) * (d + 1) * 4 + 15) & ~(size_t)15) : 0;
+  const size_t room = (size_t)160 * 1024 - 2048 - r, per = bge_generic_wave_bytes(d);
+  const int nw = (int)(room / per);
+  return nw > 4 ? 4 : (nw < 1 ? 1 : nw);
+}
+__host__ __device__ inline size_t bge_chol_wave_bytes(int d, bool generic) {
+  const size_t quad = (size_t)16 * BGE_QS * 4;
+  const size_t g = generic ? bge_generic_wave_bytes(d) : 0;
+  return quad > g ? quad : g;
+}
+// d <= 64: every problem has n <= 32 rows (complement form), the per-wave tier and its LDS are not needed
+__host__ __device__ inline size_t bge_chol_lds_bytes(int d, bool r_in_lds) {
+  const size_t r = r_in_lds ? (((size_t)2 * (d + 1) * (d + 1) * 4 + 15) & ~(size_t)15) : 0;
+  const bool generic = d > 64;
+  return r + (size_t)(generic ? bge_generic_waves(d, r_in_lds) : 4) * bge_chol_wave_bytes(d, generic);
+}
+
+// grid = any (persistent: work units are dealt round-robin, largest tier first), block = 256; dynamic LDS = bge_chol_lds_bytes()
+// R_LDS: one matrix pair (no interventions) resident in LDS; otherwise R_j / Q_j are read through the caches.
+template <bool R_LDS, bool W2>
+__global__ __launch_bounds__(256) void k_bge_chol(const uint64_t* __restrict__ masks, double* __restrict__ node_scores, BgeParams bp,
+                                                  BgeQueues qs, int d, int S) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ unsigned int cnt_s[BGE_NQ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < BGE_NQ) cnt_s[tid] = qs.counts[tid];
+  __syncthreads();
+  const int nwg = W2 ? bge_generic_waves(d, R_LDS) : 4;
+  unsigned int cnt[BGE_NQ], units[BGE_NQ], total = 0;
+#pragma unroll
+  for (int qi = 0; qi < BGE_NQ; ++qi) {
+    cnt[qi] = cnt_s[qi];
+    const unsigned int per = qi < 4 ? 256u : (qi < 8 ? 64u : (unsigned int)nwg);
+    units[qi] = (cnt[qi] + per - 1u) / per;
+    total += units[qi];
+  }
+  if (blockIdx.x >= total) return;  // (block-uniform)
+  const int ldr = d + 1, msz = ldr * ldr;
+  const float* Rg = bp.Rp;
+  float* Rs = reinterpret_cast<float*>(smem_raw);
+  const size_t r_bytes = R_LDS ? (((size_t)2 * msz * 4 + 15) & ~(size_t)15) : 0;
+  if (R_LDS) {
+    for (int e = tid; e < msz; e += 256) {
+      Rs[e] = bp.Rp[e];
+      Rs[msz + e] = bp.Qp[e];
+    }
+    __syncthreads();
+  }
+  unsigned char* wbase = smem_raw + r_bytes + (size_t)wave * bge_chol_wave_bytes(d, W2);
+  const int W = W2 ? 2 : 1;
+  // matrix offset of a problem relative to `Rm`: LDS holds [R | Q]; global memory holds Rp and Qp as separate arrays
+  const float* Rm = R_LDS ? Rs : Rg;
+  const long qoff = R_LDS ? (long)msz : (long)(bp.Qp - bp.Rp);
+
+  for (unsigned int u = blockIdx.x; u < total; u += gridDim.x) {
+    int qi = BGE_NQ - 1;
+    unsigned int base = 0;
+#pragma unroll
+    for (int t = BGE_NQ - 1; t > 0; --t)
+      if (qi == t && u >= base + units[t]) { base += units[t]; qi = t - 1; }
+    const unsigned int local = u - base;
+    const uint32_t* list = qs.list + (size_t)qi * qs.cap;
+    const unsigned int n_q = cnt[0] * (qi == 0) + cnt[1] * (qi == 1) + cnt[2] * (qi == 2) + cnt[3] * (qi == 3) + cnt[4] * (qi == 4) +
+                             cnt[5] * (qi == 5) + cnt[6] * (qi == 6) + cnt[7] * (qi == 7) + cnt[8] * (qi == 8);
+    // problem of this lane / quad / wave
+    unsigned int pi;
+    if (qi < 4) pi = local * 256u + tid;
+    else if (qi < 8) pi = local * 64u + (tid >> 2);
+    else pi = local * (unsigned int)nwg + wave;
+    const bool has = pi < n_q && (qi < 8 || wave < nwg);
+    const uint32_t code = has ? list[pi] : 0u;
+    const int s = code % S, mj = code / S, j = mj % d;
+    uint64_t w0 = 0, w1 = 0;
+    if (has) {
+      w0 = masks[(size_t)code * W];
+      if (W2) w1 = masks[(size_t)code * W + 1];
+    }
+    const int l = __popcll(w0) + __popcll(w1);
+    const bool comp = has && (l + 1 > d - l);
+    bge_index_mask(w0, w1, j, d, comp);
+    const int li = has ? (comp ? d - 1 - l : l) : 0;  // rows before j
+    const int mat = (int)((comp ? qoff : 0) + (bp.n_mats > 1 ? (long)j * msz : 0));
+    float ld2 = 0.f, last = 1.f;
+    switch (qi) {
+      case 0: bge_chol_lane<4, W2>(Rm, mat, ldr, d, w0, w1, has ? j : d, li, ld2, last); break;
+      case 1: bge_chol_lane<8, W2>(Rm, mat, ldr, d, w0, w1, has ? j : d, li, ld2, last); break;
+      case 2: bge_chol_lane<12, W2>(Rm, mat, ldr, d, w0, w1, has ? j : d, li, ld2, last); break;
+      case 3: bge_chol_lane<16, W2>(Rm, mat, ldr, d, w0, w1, has ? j : d, li, ld2, last); break;
+      case 4: bge_chol_quad<5, W2>(Rm, mat, ldr, d, reinterpret_cast<int*>(wbase) + (lane >> 2) * BGE_QS, w0, w1, has ? j : d, li, ld2, last); break;
+      case 5: bge_chol_quad<6, W2>(Rm, mat, ldr, d, reinterpret_cast<int*>(wbase) + (lane >> 2) * BGE_QS, w0, w1, has ? j : d, li, ld2, last); break;
+      case 6: bge_chol_quad<7, W2>(Rm, mat, ldr, d, reinterpret_cast<int*>(wbase) + (lane >> 2) * BGE_QS, w0, w1, has ? j : d, li, ld2, last); break;
+      case 7: bge_chol_quad<8, W2>(Rm, mat, ldr, d, reinterpret_cast<int*>(wbase) + (lane >> 2) * BGE_QS, w0, w1, has ? j : d, li, ld2, last); break;
+      default:
+        if (W2 && wave < nwg && has) bge_chol_wave(Rm, mat, ldr, d, wbase, w0, w1, j, li, ld2, last);
+        break;
+    }
+    const bool writer = has && (qi < 4 || (qi < 8 ? (tid & 3) == 0 : lane == 0));
+    if (writer) node_scores[(size_t)mj * S + s] = bge_score(bp, j, l, d, comp, ld2, last);
+  }
+}
+
+// out[s] = sum_j node_scores[j][s]   (scoring of given graphs)
+#ifdef DIBS_TU_BGE
+__global__ void k_sum_nodes(const double* __restrict__ node_scores, float* __restrict__ out, int d, int S) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  double t = 0.0;
+  for (int j = 0; j < d; ++j) t += node_scores[(size_t)j * S + s];
+  out[s] = (float)t;
+}
+#endif

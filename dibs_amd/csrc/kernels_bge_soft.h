@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scor
   if (tid == 0) logprobs[(size_t)m * S + s] = (float)(red[0] + red[1] + red[2] + red[3]);
 }
 
+#ifdef DIBS_TU_BGE_SOFT
 // softmax over the samples and W = sum_s w_s dS_s (samples with w_s == 0 in float are skipped, in sample order)
 // grid = Mloc, block = 256; dynamic LDS = S * 8
 __global__ __launch_bounds__(256) void k_soft_combine(const float* __restrict__ ds, const float* __restrict__ logprobs,
@@ -207,3 +208,24 @@ __global__ __launch_bounds__(256) void k_soft_combine(const float* __restrict__ 
     w_lik[(size_t)m * dd + e] = acc;
   }
 }
+
+// both launches of the estimator: per-sample soft-graph scores + gradients, then the softmax-weighted combination
+void bge_soft_launch(const BgeSoftParams& sp, const float* scores, Key2 carry, int m0, int M, int Mloc, int d, int S, float alpha,
+                     float tau, int layout, int tiny, float* soft_ds, float* logprobs, float* w_lik, hipStream_t stream) {
+  const bool rl = sp.n_mats == 1 && bge_soft_waves(d, true) >= 1;
+  const size_t lds = bge_soft_lds_bytes(d, rl);
+  if (rl) {
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_bge_soft<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_bge_soft<true>, dim3(S, Mloc), dim3(256), lds, stream, scores, sp, carry, m0, M, d, S, alpha, tau, layout, tiny,
+                       soft_ds, logprobs);
+  } else {
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_bge_soft<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_bge_soft<false>, dim3(S, Mloc), dim3(256), lds, stream, scores, sp, carry, m0, M, d, S, alpha, tau, layout, tiny,
+                       soft_ds, logprobs);
+  }
+  hipLaunchKernelGGL(k_soft_combine, dim3(Mloc), dim3(256), (size_t)S * 4 + 16, stream, soft_ds, logprobs, w_lik, d, S);
+}
+#else
+void bge_soft_launch(const BgeSoftParams& sp, const float* scores, Key2 carry, int m0, int M, int Mloc, int d, int S, float alpha,
+                     float tau, int layout, int tiny, float* soft_ds, float* logprobs, float* w_lik, hipStream_t stream);
+#endif  // DIBS_TU_BGE_SOFT

@@ -9,7 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "rng.h"
-#include "kernels_marginal.h"
+#include "common.h"
 
 enum { LIN_MODE_THETA = 0, LIN_MODE_Z_SCORE = 1, LIN_MODE_Z_REPARAM = 2, LIN_MODE_GIVEN = 3 };
 
@@ -529,8 +529,18 @@ __global__ __launch_bounds__(256) void k_lin_grad(const float* __restrict__ x, c
     baseline_out[m] = (mode == LIN_MODE_Z_SCORE) ? (float)(sf_baseline * (sm / S) + (1.0 - sf_baseline) * (double)bold) : bold;
 }
 
-// ---- host side -----------------------------------------------------------------------------------
-static inline int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) {
+// ---- host side (defined in tu_lin.hip) --------------------------------------------------------------
+int joint_alloc(JointWork* w, int Mloc, int d, int N, int S);
+void joint_free(JointWork* w);
+int joint_set_data(JointWork* w, const float* x, const int32_t* mask, int N, int d);
+void joint_lin_all_logprobs(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z);
+void joint_lin_all_grads(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z);
+// log p(theta_i, D | g_i) of n given (graph, parameter) pairs (held-out scoring; dibs_score_graphs)
+void joint_lin_score_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N, float obs_noise,
+                           float mean_edge, float sig_edge, hipStream_t stream);
+
+#ifdef DIBS_TU_LIN
+int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) {
   (void)N;
   w->x = nullptr;
   w->mask = nullptr;
@@ -540,7 +550,7 @@ static inline int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) {
   if (hipMalloc((void**)&w->ln_tab, (size_t)Mloc * d * d * 4) != hipSuccess) return 1;
   return 0;
 }
-static inline void joint_free(JointWork* w) {
+void joint_free(JointWork* w) {
   if (w->x) hipFree(w->x);
   if (w->mask) hipFree(w->mask);
   if (w->wsm) hipFree(w->wsm);
@@ -550,7 +560,7 @@ static inline void joint_free(JointWork* w) {
   w->mask = nullptr;
   w->wsm = nullptr;
 }
-static inline int joint_set_data(JointWork* w, const float* x, const int32_t* mask, int N, int d) {
+int joint_set_data(JointWork* w, const float* x, const int32_t* mask, int N, int d) {
   const size_t n = (size_t)N * d;
   if (w->x) hipFree(w->x);
   if (w->mask) hipFree(w->mask);
@@ -622,16 +632,39 @@ static void joint_lin_grads(JointWork* w, const JointLaunch& jl, Key2 carry_thet
     default: CALL_(7); break;                \
   }
 // log p(theta, D | G_s) for the samples of the theta estimator and of the Z estimator (two launches)
-static inline void joint_lin_all_logprobs(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z) {
+void joint_lin_all_logprobs(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z) {
   const int mz = jl.est_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM;
 #define LIN_CALL(NT_) { joint_lin_logprobs<NT_>(w, jl, carry_theta, LIN_MODE_THETA); joint_lin_logprobs<NT_>(w, jl, carry_z, mz); }
   LIN_NT_SWITCH(LIN_CALL)
 #undef LIN_CALL
 }
 // both softmax-weighted gradients in one launch
-static inline void joint_lin_all_grads(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z) {
+void joint_lin_all_grads(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z) {
 #define LIN_CALL(NT_) joint_lin_grads<NT_>(w, jl, carry_theta, carry_z)
   LIN_NT_SWITCH(LIN_CALL)
 #undef LIN_CALL
 }
 #undef LIN_NT_SWITCH
+
+template <int NT>
+static void launch_lin_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N, float obs_noise,
+                             float mean_edge, float sig_edge, hipStream_t stream) {
+  const size_t lds = lin_lds_bytes(d, N, NT, false);
+  if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_lin_logprobs<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_lin_logprobs<NT>, dim3(1, n), dim3(256), lds, stream, jw.x, jw.mask, theta, (const float*)nullptr,
+                     reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, N, 1, 1, 0.f, 1.f, 0, 0,
+                     obs_noise, mean_edge, sig_edge, jw.any_mask);
+}
+void joint_lin_score_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N, float obs_noise,
+                           float mean_edge, float sig_edge, hipStream_t stream) {
+  switch ((d + 15) / 16) {
+    case 1: launch_lin_given<1>(jw, theta, g, out, n, d, N, obs_noise, mean_edge, sig_edge, stream); break;
+    case 2: launch_lin_given<2>(jw, theta, g, out, n, d, N, obs_noise, mean_edge, sig_edge, stream); break;
+    case 3: launch_lin_given<3>(jw, theta, g, out, n, d, N, obs_noise, mean_edge, sig_edge, stream); break;
+    case 4: launch_lin_given<4>(jw, theta, g, out, n, d, N, obs_noise, mean_edge, sig_edge, stream); break;
+    case 5: launch_lin_given<5>(jw, theta, g, out, n, d, N, obs_noise, mean_edge, sig_edge, stream); break;
+    case 6: launch_lin_given<6>(jw, theta, g, out, n, d, N, obs_noise, mean_edge, sig_edge, stream); break;
+    default: launch_lin_given<7>(jw, theta, g, out, n, d, N, obs_noise, mean_edge, sig_edge, stream); break;
+  }
+}
+#endif  // DIBS_TU_LIN

@@ -88,6 +88,7 @@ __device__ __forceinline__ void nn_gemm_x_tw(const float* X, const float* TW, co
 // LN[a][j] = sum_h logN(W1[j][a][h]; 0, sig_p): the graph-dependent part of the parameter prior is sum_aj g[a][j] LN[a][j]
 // (nonlinearGaussian.py:264-269).  It does not depend on the sample: one table per particle and step instead of H logN
 // evaluations per element of every sampled graph.   grid = (ceil(d*d / 256), Mloc)
+#ifdef DIBS_TU_NN
 __global__ void k_nn_prior_table(const float* __restrict__ theta, size_t P, float* __restrict__ ln_tab, int d, int H, float sigp) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
   if (e >= d * d) return;
@@ -97,6 +98,7 @@ __global__ void k_nn_prior_table(const float* __restrict__ theta, size_t P, floa
   for (int h = 0; h < H; ++h) t += lin_logn(w[h], 0.f, sigp);
   ln_tab[(size_t)m * d * d + e] = t;
 }
+#endif
 
 // sample graph s into GS (row-major [a][j]); with a prior table returns this thread's share of sum g LN
 __device__ __forceinline__ float nn_build_graph(float* GS, int mode, Key2 key, uint64_t nbits, int s, const uint32_t* thr_m,
@@ -450,6 +452,7 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
 // subkey(m, j) = row m*d+j of split(key, M*d); per stax layer: rng, layer_rng = split(rng) (the activation layer consumes
 // one too); Dense: k1, k2 = split(layer_rng); W = normal(k1, (in, out)) * sig; b = normal(k2, (out,)) * sig.
 // one thread per (local particle, node)
+#ifdef DIBS_TU_NN
 __global__ void k_init_theta_nn(float* __restrict__ theta, size_t P, Key2 key, int m0, int Mloc, int M_global, int d, int H, int bias,
                                 float sig, int layout) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -475,8 +478,16 @@ __global__ void k_init_theta_nn(float* __restrict__ theta, size_t P, Key2 key, i
     }
   }
 }
+#endif
 
-// ---- host side -----------------------------------------------------------------------------------
+// ---- host side (defined in tu_nn.hip) ---------------------------------------------------------------
+void joint_nn_dispatch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P);
+void joint_nn_score_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N, const NNParams& np_,
+                          size_t P, hipStream_t stream);
+// theta = stax initialisation stream of sample_parameters (nonlinearGaussian.py:155-186)
+void joint_nn_init_theta(float* theta, size_t P, Key2 key, int m0, int Mloc, int M, int d, const NNParams& np_, int layout, hipStream_t stream);
+
+#ifdef DIBS_TU_NN
 template <int NT>
 static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P) {
   const int spb = 2;
@@ -505,7 +516,7 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
                      jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask);
 }
 
-static inline void joint_nn_dispatch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P) {
+void joint_nn_dispatch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P) {
   switch ((jl.d + 15) / 16) {
     case 1: joint_nn_launch<1>(w, jl, carry, mode, np_, P); break;
     case 2: joint_nn_launch<2>(w, jl, carry, mode, np_, P); break;
@@ -516,3 +527,31 @@ static inline void joint_nn_dispatch(JointWork* w, const JointLaunch& jl, Key2 c
     default: joint_nn_launch<7>(w, jl, carry, mode, np_, P); break;
   }
 }
+
+template <int NT>
+static void launch_nn_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N,
+                            const NNParams& np_, size_t P, hipStream_t stream) {
+  const size_t lds = nn_lds_bytes(d, N, NT, false);
+  if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_logprobs<NT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_nn_logprobs<NT, 4>), dim3(1, n), dim3(256), lds, stream, jw.x, jw.mask, theta, P, (const float*)nullptr,
+                     reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, N, 1, 1, 0.f, 1.f, 0, 0, np_,
+                     jw.any_mask, (const float*)nullptr);
+}
+void joint_nn_score_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N, const NNParams& np_,
+                          size_t P, hipStream_t stream) {
+  switch ((d + 15) / 16) {
+    case 1: launch_nn_given<1>(jw, theta, g, out, n, d, N, np_, P, stream); break;
+    case 2: launch_nn_given<2>(jw, theta, g, out, n, d, N, np_, P, stream); break;
+    case 3: launch_nn_given<3>(jw, theta, g, out, n, d, N, np_, P, stream); break;
+    case 4: launch_nn_given<4>(jw, theta, g, out, n, d, N, np_, P, stream); break;
+    case 5: launch_nn_given<5>(jw, theta, g, out, n, d, N, np_, P, stream); break;
+    case 6: launch_nn_given<6>(jw, theta, g, out, n, d, N, np_, P, stream); break;
+    default: launch_nn_given<7>(jw, theta, g, out, n, d, N, np_, P, stream); break;
+  }
+}
+void joint_nn_init_theta(float* theta, size_t P, Key2 key, int m0, int Mloc, int M, int d, const NNParams& np_, int layout, hipStream_t stream) {
+  const int nt = Mloc * d;
+  hipLaunchKernelGGL(k_init_theta_nn, dim3((nt + 63) / 64), dim3(64), 0, stream, theta, P, key, m0, Mloc, M, d, np_.H, np_.bias,
+                     np_.sig_param, layout);
+}
+#endif  // DIBS_TU_NN

@@ -1,0 +1,28 @@
+// Host-side launchers of the kernel families that live in their own translation units (tu_*.hip): plain arguments, no templates,
+// so engine.hip does not instantiate those kernels.
+#pragma once
+#include "common.h"
+#include "kernels_kmat.h"
+#include "kernels_lik.h"
+#include "kernels_bge.h"
+
+// ---- tu_bge.hip --------------------------------------------------------------------------------------
+// sampling + queueing (sample = false: parent sets given in `masks`); kf.z != null appends the kernel-matrix blocks
+void bge_launch_sample(bool sample, hipStream_t stream, const uint32_t* thr, uint64_t* masks, double* node_scores, const BgeParams& bp,
+                       Key2 carry, int m0, int M, int Mloc, int d, int S, int W, int layout, const BgeQueues& qs, const KmatFuse& kf);
+size_t bge_sample_lds_bytes(int d, int S, int W);
+void bge_launch_chol(hipStream_t stream, const uint64_t* masks, double* node_scores, const BgeParams& bp, const BgeQueues& qs, int d,
+                     int S);
+void bge_launch_sum_nodes(hipStream_t stream, const double* node_scores, float* out, int d, int S);
+
+// ---- tu_acyc.hip -------------------------------------------------------------------------------------
+struct AcycLaunch {
+  hipStream_t stream;
+  const float* scores;
+  float* part;
+  Key2 carry;
+  int m0, M, Mloc, d, Sa, cpb, units, nblk;  // units != Sa: chains are taken in Threefry pairs
+  float alpha, tau;
+  int layout, tiny;
+};
+void acyc_launch(const AcycLaunch& a, const LikArgs& lik, int lik_blocks, size_t lik_lds);

@@ -1,0 +1,34 @@
+// translation unit: acyclicity-gradient kernel instantiations and their launcher (kernels_acyc.h)
+#define DIBS_TU_ACYC
+#include "launch.h"
+#include "kernels_acyc.h"
+
+template <int NT>
+static void launch_nt(const AcycLaunch& a, const LikArgs& lik, int lik_blocks, size_t lik_lds) {
+  constexpr int DP = 16 * NT, LD = DP + 4;
+  size_t lds = (size_t)(3 * DP + 1) * LD * 4;  // + one slack row (the k pipeline may load one step past the end)
+  if (lik_blocks && lik_lds > lds) lds = lik_lds;
+  const bool paired = a.units != a.Sa;
+  const dim3 grid(a.nblk + lik_blocks, a.Mloc);  // blockIdx.x >= nblk: score-estimator blocks riding along
+  if (paired) {
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_acyc<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_acyc<NT, true>), grid, dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.d, a.Sa, a.cpb, a.alpha,
+                       a.tau, a.layout, a.tiny, a.nblk, lik);
+  } else {
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_acyc<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_acyc<NT, false>), grid, dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.d, a.Sa, a.cpb, a.alpha,
+                       a.tau, a.layout, a.tiny, a.nblk, lik);
+  }
+}
+
+void acyc_launch(const AcycLaunch& a, const LikArgs& lik, int lik_blocks, size_t lik_lds) {
+  switch ((a.d + 15) / 16) {
+    case 1: launch_nt<1>(a, lik, lik_blocks, lik_lds); break;
+    case 2: launch_nt<2>(a, lik, lik_blocks, lik_lds); break;
+    case 3: launch_nt<3>(a, lik, lik_blocks, lik_lds); break;
+    case 4: launch_nt<4>(a, lik, lik_blocks, lik_lds); break;
+    case 5: launch_nt<5>(a, lik, lik_blocks, lik_lds); break;
+    case 6: launch_nt<6>(a, lik, lik_blocks, lik_lds); break;
+    default: launch_nt<7>(a, lik, lik_blocks, lik_lds); break;
+  }
+}
