@@ -1,16 +1,20 @@
 #!/usr/bin/env python
 """SVGD steps/sec of the DiBS hot path on MI355X (BASELINE.json metric: d=50, n_particles=128, BGe).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: spawns the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one SVGD step (svgd.py:226-267 of the reference) over all 128 particles on synthetic ER-2
-linear-Gaussian data that is resident in HBM before the timed region.  N > 1 shards the particles over the
-ranks (strong scaling: total work fixed) with one RCCL all-gather of [z | grad_z] per step.
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field)."""
+One "step" = one SVGD step (svgd.py:226-267 of the reference) over all 128 particles on synthetic ER-2 linear-Gaussian
+data that is resident in HBM before the timed region.  W untimed steps t = 0..W-1 of the trajectory from PRNGKey(1), then
+EXACTLY K steps t = W..W+K-1 timed between barrier + synchronize fences (max over ranks).  The cost of a step depends on t
+(sampled parent sets shrink as the particles sharpen), so the timed window is restored from a snapshot and measured
+`--reps` times: `value` comes from the MEDIAN repetition, all repetitions are listed in `rep_ms_per_step`.
+N > 1 shards the particles over the ranks (strong scaling: total work fixed) with one RCCL all-gather of [z | grad_z] per
+step.  Rank 0 prints ONE JSON line (DESIGN.md "Measurement" explains every field)."""
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -20,22 +24,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 D_VARS, N_PARTICLES, N_OBS, S_MC, SA_MC = 50, 128, 100, 128, 32
-PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA peak
+PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector (packed) == FP32 MFMA peak, 64 FLOP/clk/SIMD
 PEAK_HBM_GBPS = 8000.0
+N_SIMD, CLK_GHZ = 1024, 2.4
+VALU_CYC_PER_INSTR = 4.0  # measured issue rate of plain (unpacked) VALU wave-instructions, scripts/probe/valu_rate.hip
 
 
 def binary_powering_matmuls(n):
     return (n.bit_length() - 1) + (bin(n).count("1") - 1)
 
 
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=7, help="repetitions of the timed window (median reported)")
+    ap.add_argument("--n-particles", type=int, default=N_PARTICLES,
+                    help="128 = BASELINE.json's metric; 1024 = config 4 (particles sharded over the ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
-    K, W, N = args.steps, args.warmup, args.gpus
+    K, W, N, M = args.steps, args.warmup, args.gpus, args.n_particles
+    if N > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -59,7 +79,7 @@ def main():
 
     data, _, _ = make_linear_gaussian_equivalent_model(key=random.PRNGKey(0), n_vars=D_VARS, graph_prior_str="er",
                                                        n_observations=N_OBS)
-    cfg = make_config(n_vars=D_VARS, n_particles=N_PARTICLES, n_observations=N_OBS, n_grad_mc_samples=S_MC,
+    cfg = make_config(n_vars=D_VARS, n_particles=M, n_observations=N_OBS, n_grad_mc_samples=S_MC,
                       n_acyclicity_mc_samples=SA_MC, rank=rank, n_ranks=N, device_id=local_rank)
     # N > 1: engine kernels and the RCCL all-gather share one dedicated (non-default) torch stream
     tstream = torch.cuda.Stream() if N > 1 else None
@@ -86,94 +106,112 @@ def main():
 
     run(0, W)                       # untimed warm-up: steps 0 .. W-1 of the trajectory
     fence()
-    t_begin = time.perf_counter()
-    run(W, K)                       # timed: steps W .. W+K-1
-    fence()
-    elapsed = time.perf_counter() - t_begin
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    snap = {k_: v for k_, v in eng.get_state().items() if v is not None}   # state at t = W (this rank's particles)
+    rep_s = []
+    for rep in range(max(args.reps, 1)):
+        if rep:
+            eng.set_state(**snap)   # untimed: back to t = W
+        fence()
+        t_begin = time.perf_counter()
+        run(W, K)                   # timed: steps W .. W+K-1
+        fence()
+        el = time.perf_counter() - t_begin
+        if dist is not None:
+            tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        rep_s.append(el)
+    elapsed = float(np.median(rep_s))
     steps_per_s = K / elapsed
 
     out = {
-        "metric": "SVGD steps/sec (d=50, n_particles=128, BGe)", "value": steps_per_s, "unit": "steps/s", "n_gpus": N,
+        "metric": f"SVGD steps/sec (d={D_VARS}, n_particles={M}, BGe)", "value": steps_per_s, "unit": "steps/s", "n_gpus": N,
         "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
         "scaling": "strong" if N > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "MarginalDiBS+BGe (score-function estimator), Erdos-Renyi-2 linear-Gaussian data",
-                   "n_vars": D_VARS, "n_particles": N_PARTICLES, "n_observations": N_OBS, "n_grad_mc_samples": S_MC,
+                   "n_vars": D_VARS, "n_particles": M, "n_observations": N_OBS, "n_grad_mc_samples": S_MC,
                    "n_acyclicity_mc_samples": SA_MC, "timed_steps": f"t={W}..{W + K - 1} of one trajectory from PRNGKey(1)",
                    "parallelism": f"particles sharded over {N} rank(s), 1 all-gather/step" if N > 1 else "single GPU"},
+        "reps": len(rep_s), "rep_ms_per_step": [1e3 * r / K for r in rep_s],
+        "rep_spread": (max(rep_s) - min(rep_s)) / elapsed,
     }
 
     if rank == 0 and N == 1:
-        # ---- roofline of the dominant kernel: same K steps replayed with per-kernel HIP events ----
-        eng.init_particles(random.PRNGKey(1))
-        eng.run(0, W)
+        # ---- roofline of the dominant kernel: the same K steps replayed with per-kernel HIP events on the engine's stream ----
+        eng.set_state(**snap)
         eng.set_profiling(True)
         eng.reset_timers()
         eng.run(W, K)
         timers = eng.timers()
-        bge_flops = float(eng.counters()[0])  # executed Cholesky flops (sum n^3/3 over all sampled parent sets)
+        bge_flops = float(eng.counters()[0]) / K   # executed Cholesky flops per step (sum n^3/3 over the queued problems)
         eng.set_profiling(False)
         total_ms = sum(ms for ms, _ in timers.values())
         dom = max(timers, key=lambda k_: timers[k_][0])
         dom_ms, dom_n = timers[dom]
         avg_s = dom_ms / dom_n * 1e-3
         # SURVEY.md 8(d) algorithmic flop counts per step (= per launch: each kernel is launched once per step)
-        dense_bge = N_PARTICLES * S_MC * D_VARS * 2 * D_VARS ** 3 / 3.0          # F_lik(BGe), dense-Cholesky count
-        acyc_flops = N_PARTICLES * SA_MC * binary_powering_matmuls(D_VARS - 1) * 2 * D_VARS ** 3   # F_acyc
-        rocprof_names = {"acyc": "k_acyc<4, true>", "bge_nodes": "k_bge_nodes<4, true>", "bge_big": "k_bge_big<16|32|64, true> (3 launches)"}
-        roof = {"kernel": dom, "rocprof_kernel": rocprof_names.get(dom, "k_" + dom), "bound": "mfma",
-                "pipe": "mfma_f32" if dom == "acyc" else "valu_f32", "avg_launch_us": avg_s * 1e6, "launches": dom_n,
+        acyc_flops = M * SA_MC * binary_powering_matmuls(D_VARS - 1) * 2 * D_VARS ** 3   # F_acyc
+        dense_bge = M * S_MC * D_VARS * 2 * D_VARS ** 3 / 3.0                            # F_lik(BGe), reference's dense count
+        names = {"acyc": "k_acyc<4, true>", "bge_nodes": "k_bge_sample<4, true>", "bge_big": "k_bge_chol<true, false>"}
+        roof = {"kernel": dom, "rocprof_kernel": names.get(dom, "k_" + dom), "avg_launch_us": avg_s * 1e6, "launches": dom_n,
                 "share_of_step": dom_ms / total_ms, "unit": "TFLOP/s", "peak": PEAK_F32_TFLOPS, "traffic": None}
         if dom == "acyc":
-            roof["flops_per_launch"] = acyc_flops
-            roof["flops_model"] = "M*Sa*c(d-1)*2*d^3, c(49)=7 matmuls of binary powering (SURVEY 8(d) F_acyc)"
-            roof["achieved"] = acyc_flops / avg_s / 1e12
-        elif dom in ("bge_nodes", "bge_big"):
-            # the BGe kernels skip the dense count by factorising only R[pa U j]; both figures are given
-            roof["flops_per_launch"] = dense_bge
-            roof["flops_model"] = ("M*S*d*2*d^3/3 dense count (SURVEY 8(d) F_lik) over the whole BGe group; the kernels execute "
-                                   "sum (l+1)^3/3 instead, see executed_tflops")
-            grp_s = (timers["bge_nodes"][0] + timers["bge_big"][0]) / dom_n * 1e-3
-            roof["achieved"] = dense_bge / grp_s / 1e12
-            roof["executed_tflops"] = bge_flops / max(dom_n, 1) / grp_s / 1e12
+            roof.update(bound="mfma", pipe="mfma_f32", flops_per_launch=acyc_flops, achieved=acyc_flops / avg_s / 1e12,
+                        flops_model="M*Sa*c(d-1)*2*d^3, c(49)=7 matmuls of binary powering (SURVEY 8(d) F_acyc)")
+        elif dom == "bge_big":
+            # VALU kernel: the work actually executed (the reference's dense 2 d^3/3-per-determinant count is not what runs:
+            # only R[pa + j] is factorised).  Priced against the f32 vector peak.
+            roof.update(bound="mfma", pipe="valu_f32", flops_per_launch=bge_flops, achieved=bge_flops / avg_s / 1e12,
+                        flops_model="executed Cholesky flops sum (l+1)^3/3, counted on the device; f32 VECTOR peak (bound 'mfma' = "
+                                    "FP32 compute, the pipe says which unit)", dense_equivalent_flops=dense_bge)
+        elif dom == "bge_nodes":
+            # Threefry sampling: integer VALU work, no flops.  Bound = VALU issue: 67 instructions per Threefry-2x32 call.
+            calls = M * (S_MC // 2) * D_VARS * D_VARS
+            floor_s = calls * 67 / 64 / N_SIMD * VALU_CYC_PER_INSTR / (CLK_GHZ * 1e9)
+            roof.update(bound="mfma", pipe="valu_int", unit="fraction of VALU issue", peak=1.0, achieved=floor_s / avg_s,
+                        flops_model="Threefry calls * 67 VALU instr / (1024 SIMD * 1 instr per 4 clk at 2.4 GHz) / measured time")
         else:
-            roof["achieved"] = None
-        roof["frac"] = roof["achieved"] / PEAK_F32_TFLOPS if roof["achieved"] else None
-        pmc = os.path.join(ROOT, "profiles", "round1_pmc_hbm.json")   # separate rocprofv3 --pmc passes of this command
-        if os.path.exists(pmc):
-            rec = json.load(open(pmc)).get(dom)
-            if rec:
-                roof["traffic"] = rec["hbm_bytes_per_launch"]
-                roof["traffic_source"] = "profiles/round1_pmc_hbm.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes)"
+            roof.update(bound="mfma", pipe="valu_f32", achieved=None)
+        roof["frac"] = roof["achieved"] / roof["peak"] if roof.get("achieved") else None
+        for tag in ("round2", "round1"):   # separate rocprofv3 --pmc passes of this command (scripts/collect_profiles.sh)
+            pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm.json")
+            if os.path.exists(pmc):
+                rec = json.load(open(pmc)).get(dom)
+                if rec:
+                    roof["traffic"] = rec["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = f"profiles/{tag}_pmc_hbm.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB -> bytes)"
+                break
         out["roofline"] = roof
-        bytes_step = 16.0 * N_PARTICLES * (2 * D_VARS * D_VARS)
+        bytes_step = 16.0 * M * (2 * D_VARS * D_VARS)
         out["hbm_algorithmic"] = {"bytes_per_step": bytes_step, "achieved_GBps": bytes_step * steps_per_s / 1e9,
                                   "frac_of_8TBps": bytes_step * steps_per_s / 1e9 / PEAK_HBM_GBPS}
         out["kernel_us_per_step"] = {k_: ms / K * 1e3 for k_, (ms, n_) in timers.items()}
+        out["bge_executed_gflop_per_step"] = bge_flops / 1e9
 
         if not args.no_cpu_baseline:
-            # ---- CPU baseline: the oracle's C port on this box's host cores, bounded sample ----
+            # ---- CPU baseline: the oracle's C port on this box's host cores, bounded sample of the SAME window (from t = W) ----
             from oracle.c_oracle import COracle
-            cores = min(os.cpu_count() or 1, N_PARTICLES)   # OpenMP over particles: more threads than particles are idle
-            co = COracle("f64")
-            cfg1 = make_config(n_vars=D_VARS, n_particles=N_PARTICLES, n_observations=N_OBS, n_grad_mc_samples=S_MC,
+            cores = min(os.cpu_count() or 1, M)   # OpenMP over particles: more threads than particles are idle
+            cfg1 = make_config(n_vars=D_VARS, n_particles=M, n_observations=N_OBS, n_grad_mc_samples=S_MC,
                                n_acyclicity_mc_samples=SA_MC)
-            st = co.new_state(cfg1, random.PRNGKey(1))
-            t0 = time.perf_counter()
-            co.run(cfg1, data.x, None, st, 0, 2, bge_mode=0, n_threads=cores)   # the reference's masked d x d slogdet
-            faithful = 2 / (time.perf_counter() - t0)
-            st = co.new_state(cfg1, random.PRNGKey(1))
-            t0 = time.perf_counter()
-            co.run(cfg1, data.x, None, st, 0, 8, bge_mode=1, n_threads=cores)   # same compact Cholesky as the GPU
-            compact = 8 / (time.perf_counter() - t0)
+
+            def cpu(prec, n_steps, mode):
+                co = COracle(prec)
+                st = {k_: (v.astype(co.real) if v.dtype.kind == "f" else v.copy()) for k_, v in snap.items()}
+                st.setdefault("theta", None), st.setdefault("v_theta", None)
+                t0 = time.perf_counter()
+                co.run(cfg1, data.x, None, st, W, n_steps, bge_mode=mode, n_threads=cores)
+                return n_steps / (time.perf_counter() - t0)
+
+            n_cpu = min(max(K, 10), 20)
+            faithful = cpu("f32", n_cpu, 0)   # the reference's algorithm: masked d x d slogdet (LU) per node, float32
             out["cpu_baseline"] = {"value": faithful, "unit": "steps/s", "cores": cores, "kind": "port",
-                                   "sample": "2 steps (t=0,1) of the same workload, f64 C port of the reference algorithm "
-                                             "(masked d x d LU slogdet per node, as func.py:128-145), OpenMP over particles"}
-            out["cpu_baseline_compact"] = {"value": compact, "unit": "steps/s", "cores": cores, "kind": "port",
-                                           "sample": "8 steps (t=0..7), same C port with the GPU's compact parent-set Cholesky"}
+                                   "sample": f"{n_cpu} steps (t={W}..{W + n_cpu - 1}) of the same workload from the same state, f32 C port of the "
+                                             "reference algorithm (masked d x d LU slogdet per node, func.py:128-145), OpenMP over particles"}
+            out["cpu_baseline_compact_f32"] = {"value": cpu("f32", n_cpu, 1), "unit": "steps/s", "cores": cores, "kind": "port",
+                                               "sample": f"{n_cpu} steps, same port with the GPU's compact parent-set Cholesky"}
+            out["cpu_baseline_f64"] = {"value": cpu("f64", 2, 0), "unit": "steps/s", "cores": cores, "kind": "port",
+                                       "sample": "2 steps, f64 build of the reference algorithm"}
     eng.close()
     if rank == 0:
         print(json.dumps(out))

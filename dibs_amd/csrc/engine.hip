@@ -573,7 +573,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     }
     {
       KTimer tm(e, DIBS_K_BGE_BIG);
-      bge_launch_chol(e->stream, e->masks, e->node_scores, bp, e->bq, e->d, e->S);
+      bge_launch_chol(e->stream, e->masks, e->node_scores, bp, e->bq, e->d, e->S, e->profiling ? e->counters : nullptr);
     }
     {
       const int ny = e->d < 8 ? e->d : 8;  // blocks per particle (2 / 4 / 8 / 16 measured: 26 / 19 / 17 / 19 us)
@@ -887,7 +887,7 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
       HIP_OK(hipMemsetAsync(sq.counts, 0, BGE_NQ * sizeof(unsigned int), e->stream));
       bge_launch_sample(false, e->stream, nullptr, d_masks.p, d_ns.p, bp, Key2{0, 0}, 0, 1, 1, d, S, W, 0, sq,
                         KmatFuse{nullptr, nullptr, 0, 0, 0, 0.f, 0.f});
-      bge_launch_chol(e->stream, d_masks.p, d_ns.p, bp, sq, d, S);
+      bge_launch_chol(e->stream, d_masks.p, d_ns.p, bp, sq, d, S, nullptr);
       bge_launch_sum_nodes(e->stream, d_ns.p, d_out.p + q0, d, S);
       HIP_OK(hipStreamSynchronize(e->stream));
     }

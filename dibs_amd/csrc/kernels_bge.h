@@ -25,6 +25,10 @@
 #include "common.h"
 #include "kernels_kmat.h"
 
+// problems interleaved per lane in the register tiers n <= 4 / 8 / 12 (see bge_chol_lane)
+#define BGE_NPL0 4
+#define BGE_NPL1 2
+#define BGE_NPL2 2
 #define BGE_NQ 9  // queue tiers: q = (n + 3) / 4 - 1 for n <= 32, 8 for larger problems
 
 struct BgeParams {
@@ -260,47 +264,64 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_sample(const uint32_t* __res
 // ------------------------------------------------------------------------------------------------
 // K3  queued factorisations
 // ------------------------------------------------------------------------------------------------
-// One problem per LANE, n <= NMAX: indices and the lower triangle in registers, fully unrolled.  Rows n .. NMAX-1 are padding:
-// their index is d (the zero row / column of Rp) and their diagonal is set to 1, so the unrolled code is the same for every lane
-// and the padding pivots are exactly 1 (log2 = 0).  `mat` = offset (floats) of this problem's matrix (R or Q, of node j) from `R`.
-template <int NMAX, bool W2>
-__device__ __forceinline__ void bge_chol_lane(const float* __restrict__ R, int mat, int ldr, int d, uint64_t w0, uint64_t w1, int j,
-                                              int li /* index-set size = n - 1 */, float& ld2, float& last) {
-  int idx[NMAX];
+// NPL problems per LANE, n <= NMAX: indices and the lower triangle in registers, fully unrolled (right-looking: the updates of
+// a column step are independent).  Rows n .. NMAX-1 are padding: their index is d (the zero row / column of Rp) and their
+// diagonal is set to 1, so the unrolled code is the same for every lane and the padding pivots are exactly 1 (log2 = 0).
+// Small problems are latency-bound at the two waves per SIMD this kernel runs with (index extraction and the pivot chain are
+// serial): NPL independent problems per lane are interleaved by the compiler.
+// `mat` = offset (floats) of a problem's matrix (R or Q, of node j) from `R`.
+template <int NMAX, bool W2, int NPL>
+__device__ __forceinline__ void bge_chol_lane(const float* __restrict__ R, const int (&mat)[NPL], int ldr, int d, uint64_t (&w0)[NPL],
+                                              uint64_t (&w1)[NPL], const int (&j)[NPL], const int (&li)[NPL] /* index-set size = n - 1 */,
+                                              float (&ld2)[NPL], float (&last)[NPL]) {
+  int idx[NPL][NMAX];
 #pragma unroll
-  for (int t = 0; t < NMAX; ++t) {
-    int b = d;
-    if (w0) { b = __ffsll((long long)w0) - 1; w0 &= w0 - 1; }
-    else if (W2 && w1) { b = 64 + __ffsll((long long)w1) - 1; w1 &= w1 - 1; }
-    idx[t] = (t == li) ? j : b;
-  }
-  float A[NMAX][NMAX];
+  for (int t = 0; t < NMAX; ++t)
 #pragma unroll
-  for (int r = 0; r < NMAX; ++r) {
-    const int ro = mat + idx[r] * ldr;
+    for (int u = 0; u < NPL; ++u) {
+      int b = d;
+      if (w0[u]) { b = __ffsll((long long)w0[u]) - 1; w0[u] &= w0[u] - 1; }
+      else if (W2 && w1[u]) { b = 64 + __ffsll((long long)w1[u]) - 1; w1[u] &= w1[u] - 1; }
+      idx[u][t] = (t == li[u]) ? j[u] : b;
+    }
+  float A[NPL][NMAX][NMAX];
 #pragma unroll
-    for (int c = 0; c <= r; ++c) A[r][c] = R[ro + idx[c]];
-    if (r > li) A[r][r] = 1.0f;
-  }
-  float lsum = 0.f, lst = 1.f;
+  for (int r = 0; r < NMAX; ++r)
+#pragma unroll
+    for (int u = 0; u < NPL; ++u) {
+      const int ro = mat[u] + idx[u][r] * ldr;
+#pragma unroll
+      for (int c = 0; c <= r; ++c) A[u][r][c] = R[ro + idx[u][c]];
+      if (r > li[u]) A[u][r][r] = 1.0f;
+    }
+  float lsum[NPL], lst[NPL], inv[NPL];
+#pragma unroll
+  for (int u = 0; u < NPL; ++u) { lsum[u] = 0.f; lst[u] = 1.f; }
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
-    float dk = A[k][k];
 #pragma unroll
-    for (int p = 0; p < k; ++p) dk = fmaf(-A[k][p], A[k][p], dk);
-    lsum += __log2f(dk);
-    lst = (k == li) ? dk : lst;
-    const float inv = __builtin_amdgcn_rsqf(dk);
-#pragma unroll
-    for (int r = k + 1; r < NMAX; ++r) {
-      float v = A[r][k];
-#pragma unroll
-      for (int p = 0; p < k; ++p) v = fmaf(-A[r][p], A[k][p], v);
-      A[r][k] = v * inv;
+    for (int u = 0; u < NPL; ++u) {
+      const float dk = A[u][k][k];
+      lsum[u] += __log2f(dk);
+      lst[u] = (k == li[u]) ? dk : lst[u];
+      inv[u] = __builtin_amdgcn_rsqf(dk);
     }
+#pragma unroll
+    for (int r = k + 1; r < NMAX; ++r)
+#pragma unroll
+      for (int u = 0; u < NPL; ++u) A[u][r][k] *= inv[u];
+#pragma unroll
+    for (int c = k + 1; c < NMAX; ++c)
+#pragma unroll
+      for (int r = c; r < NMAX; ++r)
+#pragma unroll
+        for (int u = 0; u < NPL; ++u) A[u][r][c] = fmaf(-A[u][r][k], A[u][c][k], A[u][r][c]);
   }
-  ld2 = lsum - __log2f(lst);  // leading pivots only (the padding pivots are 1)
-  last = lst;
+#pragma unroll
+  for (int u = 0; u < NPL; ++u) {
+    ld2[u] = lsum[u] - __log2f(lst[u]);  // leading pivots only (the padding pivots are 1)
+    last[u] = lst[u];
+  }
 }
 
 // acc -= bcast_quad(b, lane C) * own   -- one VALU instruction (DPP quad_perm broadcast of the first source)
@@ -324,15 +345,15 @@ __device__ __forceinline__ float bcast_quad(const float& v, int c) {
   return o;
 }
 
-// column step K of the quad factorisation as a template recursion: every register index is a compile-time constant
+// column step K of the quad factorisation as a template recursion: every register index is a compile-time constant.
+// Right-looking: the pivot column is scaled, then every later column c receives its rank-1 update
+//   L[a][c] -= L[a][K] * bcast(L[c/4][K], lane c%4)        (a >= c/4)
+// -- all updates of a step are independent (ILP at two waves per SIMD), and only the first group of a step reads registers
+// written by the asm statement in front of it.
 template <int NB, int K>
 struct BgeQuadCol {
   static __device__ __forceinline__ void run(float (&L)[NB][4 * NB], int li, float& lsum, float& lst) {
-    constexpr int kb = K >> 2, kq = K & 3;
-#pragma unroll
-    for (int p = 0; p < K; ++p)
-#pragma unroll
-      for (int a = kb; a < NB; ++a) fmac_quad(L[a][K], L[kb][p], L[a][p], kq);
+    constexpr int kb = K >> 2, kq = K & 3, N = 4 * NB;
     const float piv = bcast_quad(L[kb][K], kq);
     lsum += __log2f(piv);
     lst = (K == li) ? piv : lst;
@@ -342,6 +363,11 @@ struct BgeQuadCol {
     asm volatile("s_nop 1" : "+v"(inv));
 #pragma unroll
     for (int a = kb; a < NB; ++a) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(L[a][K]) : "v"(inv));
+    if (K + 1 < N) asm volatile("s_nop 1" ::: "memory");  // the scaled column is read through DPP next
+#pragma unroll
+    for (int c = K + 1; c < N; ++c)
+#pragma unroll
+      for (int a = c >> 2; a < NB; ++a) fmac_quad(L[a][c], L[c >> 2][K], L[a][K], c & 3);
     BgeQuadCol<NB, K + 1>::run(L, li, lsum, lst);
   }
 };
@@ -352,9 +378,9 @@ struct BgeQuadCol<NB, 4 * NB> {
 
 // One problem per QUAD, n <= 4 NB.  Lane q of the quad owns rows q, q + 4, ...: L[a][c] is row 4a + q, column c <= 4a + 3
 // (entries right of the diagonal are zero-filled scratch).  Column step k (row k lives in lane k % 4, block k / 4):
-//   L[a][k] -= L[a][p] * bcast(L[k/4][p], lane k%4)   for p < k, a >= k/4        (v_fmac_f32_dpp)
-//   pivot = bcast(L[k/4][k]);  L[a][k] *= rsqrt(pivot)
-// Rows above k inside block k/4 compute garbage that only ever feeds themselves.  `qidx`: this quad's index list in LDS
+//   pivot = bcast(L[k/4][k]);  L[a][k] *= rsqrt(pivot)                            (a >= k/4)
+//   L[a][c] -= L[a][k] * bcast(L[c/4][k], lane c%4)   for c > k, a >= c/4        (v_fmac_f32_dpp)
+// Rows above c inside block c/4 compute garbage that only ever feeds themselves.  `qidx`: this quad's index list in LDS
 // (QS ints, 16-byte aligned).
 #define BGE_QS 36
 template <int NB, bool W2>
@@ -499,7 +525,7 @@ __host__ __device__ inline size_t bge_chol_lds_bytes(int d, bool r_in_lds) {
 // R_LDS: one matrix pair (no interventions) resident in LDS; otherwise R_j / Q_j are read through the caches.
 template <bool R_LDS, bool W2>
 __global__ __launch_bounds__(256) void k_bge_chol(const uint64_t* __restrict__ masks, double* __restrict__ node_scores, BgeParams bp,
-                                                  BgeQueues qs, int d, int S) {
+                                                  BgeQueues qs, int d, int S, unsigned long long* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ unsigned int cnt_s[BGE_NQ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -510,7 +536,7 @@ __global__ __launch_bounds__(256) void k_bge_chol(const uint64_t* __restrict__ m
 #pragma unroll
   for (int qi = 0; qi < BGE_NQ; ++qi) {
     cnt[qi] = cnt_s[qi];
-    const unsigned int per = qi < 4 ? 256u : (qi < 8 ? 64u : (unsigned int)nwg);
+    const unsigned int per = qi == 0 ? 256u * BGE_NPL0 : (qi == 1 ? 256u * BGE_NPL1 : (qi == 2 ? 256u * BGE_NPL2 : (qi == 3 ? 256u : (qi < 8 ? 64u : (unsigned int)nwg))));
     units[qi] = (cnt[qi] + per - 1u) / per;
     total += units[qi];
   }
@@ -532,6 +558,59 @@ __global__ __launch_bounds__(256) void k_bge_chol(const uint64_t* __restrict__ m
   const float* Rm = R_LDS ? Rs : Rg;
   const long qoff = R_LDS ? (long)msz : (long)(bp.Qp - bp.Rp);
 
+  float flops = 0.f;
+  // one problem: decode, index mask (parents or complement), matrix offset
+  auto load = [&](bool has, uint32_t code, int& jj, int& l, int& li, int& mat, bool& comp, uint64_t& w0, uint64_t& w1) {
+    w0 = 0ull;
+    w1 = 0ull;
+    jj = d;  // (no problem: every index is the padding index)
+    if (has) {
+      jj = (int)(code / (uint32_t)S) % d;
+      w0 = masks[(size_t)code * W];
+      if (W2) w1 = masks[(size_t)code * W + 1];
+    }
+    l = __popcll(w0) + __popcll(w1);
+    comp = has && (l + 1 > d - l);
+    bge_index_mask(w0, w1, jj, d, comp);
+    li = has ? (comp ? d - 1 - l : l) : 0;  // rows before j
+    mat = (int)((comp ? qoff : 0) + ((has && bp.n_mats > 1) ? (long)jj * msz : 0));
+  };
+  auto store = [&](bool writer, uint32_t code, int jj, int l, int li, bool comp, float ld2, float last) {
+    if (writer) node_scores[code] = bge_score(bp, jj, l, d, comp, ld2, last);
+    if (counters) {  // profiling: executed Cholesky flops, n^3 / 3 per problem
+      const float n = (float)(li + 1);
+      flops += writer ? n * n * n * (1.0f / 3.0f) : 0.f;
+    }
+  };
+#define BGE_LANE_TIER(NMAX_, NPL_)                                                                             \
+  {                                                                                                            \
+    int jj[NPL_], l[NPL_], li[NPL_], mat[NPL_];                                                                \
+    bool comp[NPL_], has[NPL_];                                                                                \
+    uint32_t code[NPL_];                                                                                       \
+    uint64_t w0[NPL_], w1[NPL_];                                                                               \
+    float ld2[NPL_], last[NPL_];                                                                               \
+    _Pragma("unroll") for (int v = 0; v < NPL_; ++v) {                                                         \
+      const unsigned int pi = local * (256u * NPL_) + 256u * v + tid;                                          \
+      has[v] = pi < n_q;                                                                                       \
+      code[v] = has[v] ? list[pi] : 0u;                                                                        \
+    }                                                                                                          \
+    _Pragma("unroll") for (int v = 0; v < NPL_; ++v) load(has[v], code[v], jj[v], l[v], li[v], mat[v], comp[v], w0[v], w1[v]); \
+    bge_chol_lane<NMAX_, W2, NPL_>(Rm, mat, ldr, d, w0, w1, jj, li, ld2, last);                                \
+    _Pragma("unroll") for (int v = 0; v < NPL_; ++v) store(has[v], code[v], jj[v], l[v], li[v], comp[v], ld2[v], last[v]); \
+  }
+#define BGE_QUAD_TIER(NB_)                                                                                     \
+  {                                                                                                            \
+    const unsigned int pi = local * 64u + (tid >> 2);                                                          \
+    const bool has = pi < n_q;                                                                                 \
+    const uint32_t code = has ? list[pi] : 0u;                                                                 \
+    int jj, l, li, mat;                                                                                        \
+    bool comp;                                                                                                 \
+    uint64_t w0, w1;                                                                                           \
+    float ld2, last;                                                                                           \
+    load(has, code, jj, l, li, mat, comp, w0, w1);                                                             \
+    bge_chol_quad<NB_, W2>(Rm, mat, ldr, d, reinterpret_cast<int*>(wbase) + (lane >> 2) * BGE_QS, w0, w1, jj, li, ld2, last); \
+    store(has && (tid & 3) == 0, code, jj, l, li, comp, ld2, last);                                            \
+  }
   for (unsigned int u = blockIdx.x; u < total; u += gridDim.x) {
     int qi = BGE_NQ - 1;
     unsigned int base = 0;
@@ -542,40 +621,40 @@ __global__ __launch_bounds__(256) void k_bge_chol(const uint64_t* __restrict__ m
     const uint32_t* list = qs.list + (size_t)qi * qs.cap;
     const unsigned int n_q = cnt[0] * (qi == 0) + cnt[1] * (qi == 1) + cnt[2] * (qi == 2) + cnt[3] * (qi == 3) + cnt[4] * (qi == 4) +
                              cnt[5] * (qi == 5) + cnt[6] * (qi == 6) + cnt[7] * (qi == 7) + cnt[8] * (qi == 8);
-    // problem of this lane / quad / wave
-    unsigned int pi;
-    if (qi < 4) pi = local * 256u + tid;
-    else if (qi < 8) pi = local * 64u + (tid >> 2);
-    else pi = local * (unsigned int)nwg + wave;
-    const bool has = pi < n_q && (qi < 8 || wave < nwg);
-    const uint32_t code = has ? list[pi] : 0u;
-    const int s = code % S, mj = code / S, j = mj % d;
-    uint64_t w0 = 0, w1 = 0;
-    if (has) {
-      w0 = masks[(size_t)code * W];
-      if (W2) w1 = masks[(size_t)code * W + 1];
-    }
-    const int l = __popcll(w0) + __popcll(w1);
-    const bool comp = has && (l + 1 > d - l);
-    bge_index_mask(w0, w1, j, d, comp);
-    const int li = has ? (comp ? d - 1 - l : l) : 0;  // rows before j
-    const int mat = (int)((comp ? qoff : 0) + (bp.n_mats > 1 ? (long)j * msz : 0));
-    float ld2 = 0.f, last = 1.f;
     switch (qi) {
-      case 0: bge_chol_lane<4, W2>(Rm, mat, ldr, d, w0, w1, has ? j : d, li, ld2, last); break;
-      case 1: bge_chol_lane<8, W2>(Rm, mat, ldr, d, w0, w1, has ? j : d, li, ld2, last); break;
-      case 2: bge_chol_lane<12, W2>(Rm, mat, ldr, d, w0, w1, has ? j : d, li, ld2, last); break;
-      case 3: bge_chol_lane<16, W2>(Rm, mat, ldr, d, w0, w1, has ? j : d, li, ld2, last); break;
-      case 4: bge_chol_quad<5, W2>(Rm, mat, ldr, d, reinterpret_cast<int*>(wbase) + (lane >> 2) * BGE_QS, w0, w1, has ? j : d, li, ld2, last); break;
-      case 5: bge_chol_quad<6, W2>(Rm, mat, ldr, d, reinterpret_cast<int*>(wbase) + (lane >> 2) * BGE_QS, w0, w1, has ? j : d, li, ld2, last); break;
-      case 6: bge_chol_quad<7, W2>(Rm, mat, ldr, d, reinterpret_cast<int*>(wbase) + (lane >> 2) * BGE_QS, w0, w1, has ? j : d, li, ld2, last); break;
-      case 7: bge_chol_quad<8, W2>(Rm, mat, ldr, d, reinterpret_cast<int*>(wbase) + (lane >> 2) * BGE_QS, w0, w1, has ? j : d, li, ld2, last); break;
+      case 0: BGE_LANE_TIER(4, BGE_NPL0) break;
+      case 1: BGE_LANE_TIER(8, BGE_NPL1) break;
+      case 2: BGE_LANE_TIER(12, BGE_NPL2) break;
+      case 3: BGE_LANE_TIER(16, 1) break;
+      case 4: BGE_QUAD_TIER(5) break;
+      case 5: BGE_QUAD_TIER(6) break;
+      case 6: BGE_QUAD_TIER(7) break;
+      case 7: BGE_QUAD_TIER(8) break;
       default:
-        if (W2 && wave < nwg && has) bge_chol_wave(Rm, mat, ldr, d, wbase, w0, w1, j, li, ld2, last);
+        if (W2) {
+          const unsigned int pi = local * (unsigned int)nwg + wave;
+          const bool has = pi < n_q && wave < nwg;
+          const uint32_t code = has ? list[pi] : 0u;
+          int jj, l, li, mat;
+          bool comp;
+          uint64_t w0, w1;
+          float ld2 = 0.f, last = 1.f;
+          load(has, code, jj, l, li, mat, comp, w0, w1);
+          if (has) bge_chol_wave(Rm, mat, ldr, d, wbase, w0, w1, jj, li, ld2, last);
+          store(has && lane == 0, code, jj, l, li, comp, ld2, last);
+        }
         break;
     }
-    const bool writer = has && (qi < 4 || (qi < 8 ? (tid & 3) == 0 : lane == 0));
-    if (writer) node_scores[(size_t)mj * S + s] = bge_score(bp, j, l, d, comp, ld2, last);
+  }
+#undef BGE_LANE_TIER
+#undef BGE_QUAD_TIER
+  if (counters) {  // one atomic per block (same-address atomics from every wave cost tens of microseconds)
+    __shared__ float fl_s[4];
+    const float tot = wave_sum(flops);
+    if (lane == 0) fl_s[wave] = tot;
+    __syncthreads();
+    const float bt = fl_s[0] + fl_s[1] + fl_s[2] + fl_s[3];
+    if (tid == 0 && bt > 0.f) atomicAdd(counters, (unsigned long long)bt);
   }
 }
 

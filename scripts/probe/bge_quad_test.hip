@@ -22,9 +22,11 @@ __global__ void k_quad(const float* Rp, int d, const uint64_t* w0s, const int* j
 template <int NMAX>
 __global__ void k_lane(const float* Rp, int d, const uint64_t* w0s, const int* js, const int* lis, float* ld2, float* last) {
   const int pr = blockIdx.x * 64 + threadIdx.x;
-  float a, b;
-  bge_chol_lane<NMAX, false>(Rp, 0, d + 1, d, w0s[pr], 0ull, js[pr], lis[pr], a, b);
-  ld2[pr] = a; last[pr] = b;
+  float a[1], b[1];
+  uint64_t w0[1] = {w0s[pr]}, w1[1] = {0ull};
+  const int mat[1] = {0}, jj[1] = {js[pr]}, li[1] = {lis[pr]};
+  bge_chol_lane<NMAX, false, 1>(Rp, mat, d + 1, d, w0, w1, jj, li, a, b);
+  ld2[pr] = a[0]; last[pr] = b[0];
 }
 
 int main() {
