@@ -16,95 +16,107 @@
 template <int NT>
 __device__ __forceinline__ int acyc_pc(int c) { return (c & 15) * NT + (c >> 4); }
 
+// k-steps S .. KS-1 of one tile row as a template recursion (see lds_matmul)
+template <int NT, int KS, int S>
+__device__ __forceinline__ void acyc_steps(f32x4 (&acc)[NT], float (&af)[2], float (&bf)[2][NT], const float* ap, const float* bq) {
+  constexpr int DP = 16 * NT, LD = DP + 4;
+  if constexpr (S == 0) {  // prologue: fragments of step 0
+    af[0] = ap[0];
+    if constexpr (NT == 4) {
+      const float4 t4 = *reinterpret_cast<const float4*>(bq);
+      bf[0][0] = t4.x; bf[0][1] = t4.y; bf[0][2] = t4.z; bf[0][3] = t4.w;
+    } else {
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) bf[0][tj] = bq[tj];
+    }
+  }
+  if constexpr (S + 1 < KS) {  // fragments of step S + 1
+    constexpr int kk0 = (S + 1) << 2, n = (S + 1) & 1;
+    af[n] = ap[(kk0 & 15) * NT + (kk0 >> 4)];
+    if constexpr (NT == 4) {
+      const float4 t4 = *reinterpret_cast<const float4*>(bq + kk0 * LD);
+      bf[n][0] = t4.x; bf[n][1] = t4.y; bf[n][2] = t4.z; bf[n][3] = t4.w;
+    } else {
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) bf[n][tj] = bq[kk0 * LD + tj];
+    }
+  }
+  constexpr int c = S & 1;
+#pragma unroll
+  for (int tj = 0; tj < NT; ++tj) {
+    if constexpr (S == 0) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc[tj]) : "v"(af[c]), "v"(bf[c][tj]));
+    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[tj]) : "v"(af[c]), "v"(bf[c][tj]));
+  }
+  if constexpr (S + 1 < KS) acyc_steps<NT, KS, S + 1>(acc, af, bf, ap, bq);
+}
+
 // C = A * B.  Operands are OFFSETS (in floats) into the kernel's LDS array so that every access is a ds_* instruction
-// (a runtime-selected generic pointer would turn them into flat accesses).  The next k-step's fragments are loaded
-// while the current MFMAs issue.
-// ODD: the number of k-steps (kp / 4) is odd.  A template parameter, not a runtime `if` around the last MFMA: the accumulators
-// must not meet a control-flow join between an MFMA and the s_nop that covers its latency -- hipcc places register copies
-// for the join right behind the (opaque) asm MFMA and reads the accumulator too early.
-// ZC (needs >= 2 k-steps): the first MFMA of every tile takes C = 0 as an inline constant instead of a zeroed accumulator.
-template <int NT, bool ODD, bool ZC>
-__device__ __forceinline__ void lds_matmul(float* __restrict__ lds, int c_off, int a_off, int b_off, int kp, int lane,
-                                           int wave) {
+// (a runtime-selected generic pointer would turn them into flat accesses).
+// KS = number of k-steps (ceil(d / 4)), a template parameter: the whole tile row is straight-line code -- every LDS offset is
+// an immediate, no loop counter, no address arithmetic (this kernel's time is the SUM of its MFMA and VALU issue cycles), and the
+// accumulators never meet a control-flow join between an MFMA and the s_nop that covers its latency (hipcc places register
+// copies for a join right behind the opaque asm MFMA and would read the accumulator too early).
+// The fragments of step s + 1 are loaded before the MFMAs of step s issue; the first MFMA of every tile takes C = 0 as an inline
+// constant instead of a zeroed accumulator.
+template <int NT, int KS>
+__device__ __forceinline__ void lds_matmul(float* __restrict__ lds, int c_off, int a_off, int b_off, int lane, int wave) {
   constexpr int DP = 16 * NT, LD = DP + 4;
   for (int ti = wave; ti < NT; ti += 4) {
     f32x4 acc[NT];
-    if constexpr (!ZC) {
-#pragma unroll
-      for (int tj = 0; tj < NT; ++tj) acc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
     // A[row][k]: k = k0 + kk -> physical ((k0 & 15) + kk) * NT + (k0 >> 4)
-    const int ap = a_off + (ti * 16 + (lane & 15)) * LD + (lane >> 4) * NT;
+    const float* ap = lds + a_off + (ti * 16 + (lane & 15)) * LD + (lane >> 4) * NT;
     // B[k][tj * 16 + col], tj = 0..NT-1 -> physical col * NT + tj (contiguous)
-    const int bq = b_off + (lane >> 4) * LD + (lane & 15) * NT;
-    // two-stage register pipeline over the kp / 4 k-steps (step s: k0 = 4 s); the loads of the following step are
-    // issued before the MFMAs of the current one.  A step index == nsteps is loaded but never used (addresses stay
-    // inside the LDS allocation: one slack row is allocated behind the last buffer).
-    const int ksteps = kp >> 2, nsteps = ksteps & ~1;  // the pipelined loop takes the steps in pairs; an odd last step follows it
-    float a0, a1, b0[NT], b1[NT];
-#define ACYC_LOAD(A_, B_, S_)                                                     \
-    {                                                                             \
-      const int kk0 = (S_) << 2;                                                  \
-      A_ = lds[ap + (kk0 & 15) * NT + (kk0 >> 4)];                                \
-      if constexpr (NT == 4) {                                                    \
-        const float4 t4 = *reinterpret_cast<const float4*>(lds + bq + kk0 * LD);  \
-        B_[0] = t4.x; B_[1] = t4.y; B_[2] = t4.z; B_[3] = t4.w;                   \
-      } else {                                                                    \
-        _Pragma("unroll") for (int tj = 0; tj < NT; ++tj) B_[tj] = lds[bq + kk0 * LD + tj]; \
-      }                                                                           \
-    }
-    // MFMA as inline asm with the accumulator tied in place ("+a"): with the builtin, hipcc renamed the accumulators
-    // across the pipelined loop (v_accvgpr_read / _mov / _write + s_nop at the loop head), serialising every iteration.
-    // Hazards hipcc cannot see around asm: accumulator init -> first MFMA (s_nop below) and last MFMA -> accumulator
-    // read (s_nop after the loop); back-to-back MFMAs on the same accumulator need none.
-#define ACYC_MFMA(A_, B_) \
-    _Pragma("unroll") for (int tj = 0; tj < NT; ++tj) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[tj]) : "v"(A_), "v"(B_[tj]));
-#define ACYC_MFMA_Z(A_, B_) \
-    _Pragma("unroll") for (int tj = 0; tj < NT; ++tj) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(acc[tj]) : "v"(A_), "v"(B_[tj]));
-    ACYC_LOAD(a0, b0, 0)
-    int st0 = 0;
-    if constexpr (ZC) {
-      ACYC_LOAD(a1, b1, 1)
-      ACYC_MFMA_Z(a0, b0)
-      ACYC_LOAD(a0, b0, 2)
-      ACYC_MFMA(a1, b1)
-      st0 = 2;
-    } else {
-      asm volatile("s_nop 4" ::: "memory");
-    }
-#undef ACYC_MFMA_Z
-#pragma unroll 1
-    for (int st = st0; st < nsteps; st += 2) {
-      ACYC_LOAD(a1, b1, st + 1)
-      ACYC_MFMA(a0, b0)
-      ACYC_LOAD(a0, b0, st + 2)
-      ACYC_MFMA(a1, b1)
-    }
-    if constexpr (ODD) { ACYC_MFMA(a0, b0) }  // (its fragments were loaded by the last pass, or by the prologue when ksteps == 1)
+    const float* bq = lds + b_off + (lane >> 4) * LD + (lane & 15) * NT;
+    float af[2], bf[2][NT];
+    // MFMA as inline asm with the accumulator tied in place: with the builtin, hipcc renamed the accumulators across the
+    // pipelined steps (v_accvgpr_read / _mov / _write + s_nop).  Hazards hipcc cannot see around asm: last MFMA -> accumulator
+    // read (s_nop below); back-to-back MFMAs on the same accumulator need none.
+    acyc_steps<NT, KS, 0>(acc, af, bf, ap, bq);
     // last MFMA -> accumulator read: one wait for the whole group (volatile asm statements keep their order, so every
     // accumulator's first read sits behind the s_nop)
     asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[NT - 1]));
 #pragma unroll
     for (int tj = 0; tj < NT - 1; ++tj) asm volatile("" : "+v"(acc[tj]));
-#undef ACYC_LOAD
-#undef ACYC_MFMA
+    // C tile -> LDS straight from the accumulator registers (ds_write2_b32 takes two arbitrary data VGPRs: no gather moves into a
+    // register quad for ds_write_b128).  The stores are asm: hipcc (ROCm 7.2) emitted `ds_write_b32 vaddr, aN` (AGPR data operand)
+    // for part of such a tile, which stored wrong values on gfx950 (scripts/probe/acyc_probe.hip); "v" constraints rule that out.
+    // LDS byte address of row r = 0 (the dynamic array does not start at 0: static __shared__ variables precede it)
+    typedef __attribute__((address_space(3))) float lds_float;
+    const unsigned o4 = (unsigned)(uintptr_t)(lds_float*)(lds + c_off + (ti * 16 + (lane >> 4) * 4) * LD + (lane & 15) * NT);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int o = c_off + (ti * 16 + (lane >> 4) * 4 + r) * LD + (lane & 15) * NT;
-      float tmp[NT];
+      // (the offset fields hold 8 bits of dwords: rows beyond that get their own address register)
+      constexpr bool imm = 3 * LD + NT <= 256;
+      const unsigned orow = imm ? o4 : o4 + r * LD * 4;
+      const int ro = imm ? r * LD : 0;
 #pragma unroll
-      for (int tj = 0; tj < NT; ++tj) {
-        // Force the MFMA result through a VGPR: hipcc (ROCm 7.2) otherwise emits `ds_write_b32 vaddr, aN` (AGPR data
-        // operand) for part of the tile, which stored wrong values on gfx950 (scripts/probe/acyc_probe.hip).
-        tmp[tj] = acc[tj][r];
-        asm volatile("" : "+v"(tmp[tj]));
-      }
-      if constexpr (NT == 4) {
-        *reinterpret_cast<float4*>(lds + o) = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
-      } else {
-#pragma unroll
-        for (int tj = 0; tj < NT; ++tj) lds[o + tj] = tmp[tj];
-      }
+      for (int tj = 0; tj + 1 < NT; tj += 2)
+        asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(orow), "v"(acc[tj][r]), "v"(acc[tj + 1][r]), "n"(imm ? r * LD + tj : tj),
+                     "n"(imm ? r * LD + tj + 1 : tj + 1)
+                     : "memory");
+      if constexpr (NT & 1) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(orow), "v"(acc[NT - 1][r]), "n"(((imm ? r * LD : 0) + NT - 1) * 4) : "memory");
+      (void)ro;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (hipcc does not count asm LDS operations)
+  }
+}
+
+// a matrix of this tile count has 4 NT - 3 .. 4 NT k-steps: one straight-line instantiation each (block-uniform dispatch)
+template <int NT>
+__device__ __forceinline__ void acyc_matmul(float* __restrict__ lds, int c_off, int a_off, int b_off, int ksteps, int lane, int wave) {
+  if constexpr (NT == 1) {
+    switch (ksteps) {
+      case 1: lds_matmul<NT, 1>(lds, c_off, a_off, b_off, lane, wave); break;
+      case 2: lds_matmul<NT, 2>(lds, c_off, a_off, b_off, lane, wave); break;
+      case 3: lds_matmul<NT, 3>(lds, c_off, a_off, b_off, lane, wave); break;
+      default: lds_matmul<NT, 4>(lds, c_off, a_off, b_off, lane, wave); break;
+    }
+  } else {
+    switch (ksteps - (4 * NT - 3)) {
+      case 0: lds_matmul<NT, 4 * NT - 3>(lds, c_off, a_off, b_off, lane, wave); break;
+      case 1: lds_matmul<NT, 4 * NT - 2>(lds, c_off, a_off, b_off, lane, wave); break;
+      case 2: lds_matmul<NT, 4 * NT - 1>(lds, c_off, a_off, b_off, lane, wave); break;
+      default: lds_matmul<NT, 4 * NT>(lds, c_off, a_off, b_off, lane, wave); break;
     }
   }
 }
@@ -123,7 +135,6 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
   const Key2 km = rng_split_row_uniform(carry, (uint32_t)M_global + 1u, (uint32_t)(m0 + m) + 1u, layout);  // dibs.py:595: key used directly
   const uint64_t dd = (uint64_t)d * d, nbits = (uint64_t)Sa * dd;
   const int kp = (d + 3) & ~3;
-  const bool kodd = (kp >> 2) & 1;
   const float inv_d = 1.0f / (float)d;
   const float* sm = scores + (size_t)m * dd;
   // thread t owns column pj = t % DP and rows pi0 + q * R of the d x d matrix: the same elements in every chain, and all
@@ -183,8 +194,10 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
               }
               if (fast) {
                 const float u0 = rng_uniform(y0, ulo, 1.0f), u1 = rng_uniform(y1, ulo, 1.0f);
-                g = u0 / (u0 + (1.0f - u0) * ea);
-                gnext[q] = u1 / (u1 + (1.0f - u1) * ea);
+                // (v_rcp_f32, 1 ulp: the IEEE division sequence is ten instructions per draw, and this kernel's time is the SUM of its
+                //  MFMA and VALU issue cycles)
+                g = u0 * __builtin_amdgcn_rcpf(fmaf(1.0f - u0, ea, u0));
+                gnext[q] = u1 * __builtin_amdgcn_rcpf(fmaf(1.0f - u1, ea, u1));
               } else {
                 g = 1.0f / (1.0f + expf(-tau * (rng_logistic(y0, tiny) + ea)));
                 gnext[q] = 1.0f / (1.0f + expf(-tau * (rng_logistic(y1, tiny) + ea)));
@@ -203,16 +216,12 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
         const int hb = 31 - __builtin_clz((unsigned)ex);
         for (int b = hb - 1; b >= 0; --b) {
           int dst = (cur == BUF) ? 2 * BUF : BUF;
-          if (kp < 8) lds_matmul<NT, true, false>(smem, dst, cur, cur, kp, lane, wave);
-          else if (kodd) lds_matmul<NT, true, true>(smem, dst, cur, cur, kp, lane, wave);
-          else lds_matmul<NT, false, true>(smem, dst, cur, cur, kp, lane, wave);
+          acyc_matmul<NT>(smem, dst, cur, cur, kp >> 2, lane, wave);
           __syncthreads();
           cur = dst;
           if ((ex >> b) & 1) {
             dst = (cur == BUF) ? 2 * BUF : BUF;
-            if (kp < 8) lds_matmul<NT, true, false>(smem, dst, cur, 0, kp, lane, wave);
-            else if (kodd) lds_matmul<NT, true, true>(smem, dst, cur, 0, kp, lane, wave);
-            else lds_matmul<NT, false, true>(smem, dst, cur, 0, kp, lane, wave);
+            acyc_matmul<NT>(smem, dst, cur, 0, kp >> 2, lane, wave);
             __syncthreads();
             cur = dst;
           }
