@@ -89,6 +89,12 @@ struct dibs_engine {
 extern "C" const char* dibs_last_error(void) { return g_err.c_str(); }
 extern "C" int dibs_abi_version(void) { return DIBS_ABI_VERSION; }
 
+static NNParams nn_params(const dibs_config& c) {
+  NNParams p{c.nn_hidden[0], c.nn_activation, c.nn_bias, (float)c.nn_obs_noise, (float)c.nn_sig_param, c.nn_n_hidden, {0, 0, 0, 0}};
+  for (int l = 0; l < c.nn_n_hidden && l < DIBS_MAX_HIDDEN_LAYERS; ++l) p.hidden[l] = c.nn_hidden[l];
+  return p;
+}
+
 static int64_t theta_size(const dibs_config& c) {
   const int d = c.n_vars;
   if (!c.joint) return 0;
@@ -231,9 +237,11 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
       return fail("BGe + reparam estimator: n_vars must be <= 64 on the device");
   }
   if (c.likelihood == DIBS_LIK_DENSENN) {
-    if (c.nn_n_hidden != 1) return fail("DenseNonlinearGaussian: exactly one hidden layer is supported on the device");
-    if (c.nn_hidden[0] < 1 || c.nn_hidden[0] > 64) return fail("DenseNonlinearGaussian: hidden width must be in [1, 64]");
-    if (c.n_observations > 128) return fail("DenseNonlinearGaussian: n_observations must be <= 128");
+    // one hidden layer of <= 64 units with <= 128 observations runs on the MFMA kernels of kernels_nn.h, every other stack on the
+    // general path of kernels_nn_generic.h
+    if (c.nn_n_hidden < 1 || c.nn_n_hidden > DIBS_MAX_HIDDEN_LAYERS) return fail("DenseNonlinearGaussian: 1 to 4 hidden layers");
+    for (int l = 0; l < c.nn_n_hidden; ++l)
+      if (c.nn_hidden[l] < 1) return fail("DenseNonlinearGaussian: hidden widths must be >= 1");
     if (c.nn_activation < 0 || c.nn_activation > 3) return fail("Invalid activation function");  // nonlinearGaussian.py:61 (KeyError)
   }
   if (c.graph_prior == DIBS_PRIOR_ER) {
@@ -248,8 +256,6 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
     const int nt = (c.n_vars + 15) / 16;
     if (c.likelihood == DIBS_LIK_LINGAUSS && lin_lds_bytes(c.n_vars, c.n_observations, nt, true) > LDS_LIMIT)
       return fail("LinearGaussian: n_vars / n_observations too large for the LDS-resident kernels (n_vars <= 112 at 100 observations)");
-    if (c.likelihood == DIBS_LIK_DENSENN && nn_lds_bytes(c.n_vars, c.n_observations, nt, true) > LDS_LIMIT)
-      return fail("DenseNonlinearGaussian: n_vars / n_observations too large for the LDS-resident kernels (n_vars <= 112 at 100 observations)");
   }
   int ndev = 0;
   HIP_OK(hipGetDeviceCount(&ndev));
@@ -434,7 +440,7 @@ extern "C" int dibs_engine_init_particles(dibs_engine* e, const uint32_t key[2])
                          (uint64_t)e->m0 * e->P, tl, (float)e->cfg.lin_mean_edge, (float)e->cfg.lin_sig_edge,
                          (float)e->cfg.lin_min_edge, L);
     } else if (e->cfg.likelihood == DIBS_LIK_DENSENN) {
-      const NNParams np_{e->cfg.nn_hidden[0], e->cfg.nn_activation, e->cfg.nn_bias, (float)e->cfg.nn_obs_noise, (float)e->cfg.nn_sig_param};
+      const NNParams np_ = nn_params(e->cfg);
       joint_nn_init_theta(e->theta, (size_t)e->P, tsub, e->m0, e->Mloc, e->M, e->d, np_, L, e->stream);
     } else {
       return fail("sample_parameters not implemented for this likelihood");
@@ -614,7 +620,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
                    e->baseline2, pack, (size_t)e->E, (size_t)(2 * e->D), (size_t)(2 * e->D + e->P), e->m0, e->M, e->Mloc, e->d,
                    e->N, e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny, c.grad_estimator_z, c.score_function_baseline,
                    0.f, 0.f, 0.f};
-    const NNParams np_{c.nn_hidden[0], c.nn_activation, c.nn_bias, (float)c.nn_obs_noise, (float)c.nn_sig_param};
+    const NNParams np_ = nn_params(c);
     {
       KTimer tm(e, DIBS_K_NN_THETA);
       joint_nn_dispatch(&e->jw, jl, carry_theta, LIN_MODE_THETA, np_, (size_t)e->P);
@@ -894,7 +900,6 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
   } else if (c.likelihood == DIBS_LIK_LINGAUSS || c.likelihood == DIBS_LIK_DENSENN) {
     if (!theta) return fail("theta required");
     const bool nn = c.likelihood == DIBS_LIK_DENSENN;
-    if (nn && n_ho > 128) return fail("DenseNonlinearGaussian: at most 128 observations per scoring call");
     JointWorkGuard jg;
     if (joint_set_data(&jg.jw, x_ho, mask_ho, n_ho, d)) return fail("joint_set_data failed");
     const size_t P = nn ? (size_t)e->P : dd;
@@ -905,7 +910,7 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
     HIP_OK(hipMemcpy(d_th.p, theta, (size_t)n * P * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_g.p, g, (size_t)n * dd * 4, hipMemcpyHostToDevice));
     if (nn) {
-      const NNParams np_{c.nn_hidden[0], c.nn_activation, c.nn_bias, (float)c.nn_obs_noise, (float)c.nn_sig_param};
+      const NNParams np_ = nn_params(c);
       joint_nn_score_given(jg.jw, d_th.p, d_g.p, d_out.p, n, d, n_ho, np_, P, e->stream);
     } else {
       joint_lin_score_given(jg.jw, d_th.p, d_g.p, d_out.p, n, d, n_ho, (float)c.lin_obs_noise, (float)c.lin_mean_edge,

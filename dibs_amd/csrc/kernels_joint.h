@@ -19,6 +19,8 @@ struct JointWork {
   float* wsm;      // [Mloc, S] softmax weights scratch
   float* ln_tab;   // [Mloc, d, d] DenseNN: per-particle first-layer prior table (kernels_nn.h), else null
   int any_mask;
+  float* nng_scratch;         // general DenseNN path (kernels_nn_generic.h): activation records, grown on first use
+  size_t nng_scratch_floats;
 };
 
 struct JointLaunch {
@@ -546,6 +548,8 @@ int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) {
   w->mask = nullptr;
   w->ln_tab = nullptr;
   w->any_mask = 0;
+  w->nng_scratch = nullptr;
+  w->nng_scratch_floats = 0;
   if (hipMalloc((void**)&w->wsm, (size_t)Mloc * S * 4) != hipSuccess) return 1;
   if (hipMalloc((void**)&w->ln_tab, (size_t)Mloc * d * d * 4) != hipSuccess) return 1;
   return 0;
@@ -555,6 +559,9 @@ void joint_free(JointWork* w) {
   if (w->mask) hipFree(w->mask);
   if (w->wsm) hipFree(w->wsm);
   if (w->ln_tab) hipFree(w->ln_tab);
+  if (w->nng_scratch) hipFree(w->nng_scratch);
+  w->nng_scratch = nullptr;
+  w->nng_scratch_floats = 0;
   w->ln_tab = nullptr;
   w->x = nullptr;
   w->mask = nullptr;

@@ -11,9 +11,13 @@
 #include <stdint.h>
 #include "kernels_joint.h"
 
+#ifndef DIBS_MAX_HIDDEN_LAYERS
+#define DIBS_MAX_HIDDEN_LAYERS 4
+#endif
 struct NNParams {
-  int H, act, bias;
+  int H, act, bias;  // H = width of the first hidden layer (the tuned one-hidden-layer kernels below)
   float obs_noise, sig_param;
+  int n_hidden, hidden[DIBS_MAX_HIDDEN_LAYERS];
 };
 
 __device__ __forceinline__ float nn_act(int a, float v) {
@@ -481,6 +485,8 @@ __global__ void k_init_theta_nn(float* __restrict__ theta, size_t P, Key2 key, i
 #endif
 
 // ---- host side (defined in tu_nn.hip) ---------------------------------------------------------------
+// true: the tuned one-hidden-layer kernels of this file apply; false: the general path of kernels_nn_generic.h runs
+bool joint_nn_fast_path(int d, int N, const NNParams& np_);
 void joint_nn_dispatch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P);
 void joint_nn_score_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N, const NNParams& np_,
                           size_t P, hipStream_t stream);
@@ -488,6 +494,8 @@ void joint_nn_score_given(const JointWork& jw, const float* theta, const int32_t
 void joint_nn_init_theta(float* theta, size_t P, Key2 key, int m0, int Mloc, int M, int d, const NNParams& np_, int layout, hipStream_t stream);
 
 #ifdef DIBS_TU_NN
+#include "kernels_nn_generic.h"
+
 template <int NT>
 static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P) {
   const int spb = 2;
@@ -516,7 +524,48 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
                      jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask);
 }
 
+bool joint_nn_fast_path(int d, int N, const NNParams& np_) {
+  return np_.n_hidden == 1 && np_.H >= 1 && np_.H <= 64 && N <= 128 && nn_lds_bytes(d, N, (d + 15) / 16, true) <= (size_t)160 * 1024;
+}
+
+// scratch of the general path: grown on first use (activation records of the work items; see kernels_nn_generic.h)
+static float* nng_scratch(JointWork* w, size_t floats) {
+  if (w->nng_scratch_floats < floats) {
+    if (w->nng_scratch) hipFree(w->nng_scratch);
+    w->nng_scratch = nullptr;
+    w->nng_scratch_floats = 0;
+    if (hipMalloc((void**)&w->nng_scratch, floats * 4) != hipSuccess) return nullptr;
+    w->nng_scratch_floats = floats;
+  }
+  return w->nng_scratch;
+}
+
+static void joint_nng_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_) {
+  const NNNet net = nn_net(jl.d, np_);
+  const size_t lds = (((size_t)jl.d * jl.d + 3) & ~(size_t)3) * 4 + 128;
+  const size_t need1 = (size_t)jl.S * jl.Mloc * 256 * net.hsum, need2 = (size_t)jl.Mloc * 2 * net.hsum * jl.d * jl.N;
+  float* scr = nng_scratch(w, need1 > need2 ? need1 : need2);
+  if (!scr) return;  // (the next hipGetLastError / sync reports the failed allocation)
+  float* lp = mode == LIN_MODE_THETA ? jl.logprobs_th : jl.logprobs_z;
+  if (lds > 48 * 1024) {
+    hipFuncSetAttribute((const void*)k_nng_logprobs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)k_nng_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  hipLaunchKernelGGL(k_nng_logprobs, dim3(jl.S, jl.Mloc), dim3(256), lds, jl.stream, w->x, w->mask, jl.theta, jl.scores, jl.thr, lp, carry, mode,
+                     jl.m0, jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, w->any_mask, scr);
+  float* out = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off : jl.w_lik;
+  const size_t ostride = mode == LIN_MODE_THETA ? jl.pack_stride : (size_t)jl.d * jl.d;
+  float* tcopy = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr;
+  hipLaunchKernelGGL(k_nng_grad, dim3(jl.Mloc), dim3(256), lds, jl.stream, w->x, w->mask, jl.theta, jl.scores, jl.thr, lp, out, ostride, tcopy,
+                     jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S,
+                     jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask, scr);
+}
+
 void joint_nn_dispatch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P) {
+  if (!joint_nn_fast_path(jl.d, jl.N, np_)) {
+    joint_nng_launch(w, jl, carry, mode, np_);
+    return;
+  }
   switch ((jl.d + 15) / 16) {
     case 1: joint_nn_launch<1>(w, jl, carry, mode, np_, P); break;
     case 2: joint_nn_launch<2>(w, jl, carry, mode, np_, P); break;
@@ -539,6 +588,16 @@ static void launch_nn_given(const JointWork& jw, const float* theta, const int32
 }
 void joint_nn_score_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N, const NNParams& np_,
                           size_t P, hipStream_t stream) {
+  if (!joint_nn_fast_path(d, N, np_)) {
+    const NNNet net = nn_net(d, np_);
+    const size_t lds = (((size_t)d * d + 3) & ~(size_t)3) * 4 + 128;
+    float* scr = nng_scratch(const_cast<JointWork*>(&jw), (size_t)n * 256 * net.hsum);
+    if (!scr) return;
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_nng_logprobs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_nng_logprobs, dim3(1, n), dim3(256), lds, stream, jw.x, jw.mask, theta, (const float*)nullptr,
+                       reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, N, 1, 0.f, 1.f, 0, 0, np_, jw.any_mask, scr);
+    return;
+  }
   switch ((d + 15) / 16) {
     case 1: launch_nn_given<1>(jw, theta, g, out, n, d, N, np_, P, stream); break;
     case 2: launch_nn_given<2>(jw, theta, g, out, n, d, N, np_, P, stream); break;
@@ -551,7 +610,7 @@ void joint_nn_score_given(const JointWork& jw, const float* theta, const int32_t
 }
 void joint_nn_init_theta(float* theta, size_t P, Key2 key, int m0, int Mloc, int M, int d, const NNParams& np_, int layout, hipStream_t stream) {
   const int nt = Mloc * d;
-  hipLaunchKernelGGL(k_init_theta_nn, dim3((nt + 63) / 64), dim3(64), 0, stream, theta, P, key, m0, Mloc, M, d, np_.H, np_.bias,
-                     np_.sig_param, layout);
+  (void)P;
+  hipLaunchKernelGGL(k_nng_init_theta, dim3((nt + 63) / 64), dim3(64), 0, stream, theta, key, m0, Mloc, M, d, np_, layout);
 }
 #endif  // DIBS_TU_NN

@@ -391,6 +391,63 @@ def test_joint_densenn_step_stages(c_oracle64, d, M, S, Sa, H, act, bias, est, i
     eng.close()
 
 
+@pytest.mark.parametrize("d,M,S,Sa,hidden,act,bias,est,interv,steps,N", [
+    (20, 4, 32, 8, (8, 8), "relu", True, "reparam", False, (2,), 60),       # two hidden layers
+    (10, 3, 16, 4, (6, 4, 3), "tanh", True, "reparam", True, (1, 2), 40),   # three hidden layers, interventions
+    (8, 3, 16, 4, (5, 5), "sigmoid", False, "score", False, (1,), 30),      # no bias, score-function estimator for Z
+    (12, 3, 16, 4, (80,), "leakyrelu", True, "reparam", False, (2,), 40),   # one layer wider than the MFMA kernels take
+    (6, 3, 16, 4, (5,), "relu", True, "reparam", True, (1,), 150),          # more observations than the MFMA kernels take
+    (20, 3, 16, 4, (32,), "relu", True, "reparam", False, (2,), 60),        # (32,): MFMA path, listed next to (8, 8) for comparison
+])
+def test_joint_densenn_general_stacks(c_oracle64, d, M, S, Sa, hidden, act, bias, est, interv, steps, N):
+    """DenseNonlinearGaussian with an arbitrary tuple of hidden layers / width / observation count (nonlinearGaussian.py:35-81,
+    155-186, 248-326): the general device path of kernels_nn_generic.h against the oracle, stage by stage."""
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=(N, d)).astype(np.float32)
+    mask = (rng.random((N, d)) < 0.1).astype(np.int32) if interv else None
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=N, edges_per_node=1 if d <= 6 else 2, joint=True,
+                      likelihood="densenn", grad_estimator_z=est, n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa,
+                      nn_hidden=hidden, nn_activation=act, nn_bias=bias, has_interventions=interv)
+    st = c_oracle64.new_state(cfg, prng.PRNGKey(7))
+    eng = _engine(cfg, x, mask)
+    eng.init_particles(prng.PRNGKey(7))
+    g0 = eng.get_state()
+    assert (g0["key"] == st["key"]).all() and rel_err(g0["theta"], st["theta"]) < 1e-6, "stax init stream of the whole stack"
+    for t in steps:
+        _sync_states(eng, st)
+        dbg = c_oracle64.step(cfg, x, mask, st, t, debug=True)
+        eng.run(t, 1)
+        g = eng.get_state()
+        assert (g["key"] == st["key"]).all()
+        assert rel_err(eng.read("LOGPROBS_THETA"), dbg["logprobs_th"]) < 2e-5
+        assert rel_err(eng.read("LOGPROBS_Z"), dbg["logprobs_z"]) < 2e-5
+        assert rel_err(eng.read("GRAD_THETA"), dbg["grad_theta"]) < 2e-3
+        assert rel_err(eng.read("W_LIK"), dbg["w_lik"]) < 2e-3
+        assert rel_err(eng.read("GRAD_Z"), dbg["grad_z"]) < 2e-3
+        assert rel_err(eng.read("PHI_THETA"), dbg["phi_theta"]) < 2e-3
+        assert rel_err(g["theta"], st["theta"]) < 1e-4
+        assert rel_err(g["z"], st["z"]) < 5e-4
+    eng.close()
+
+
+def test_densenn_deep_sample_and_scoring(c_oracle64):
+    """JointDiBS.sample() and the held-out scorer with a two-hidden-layer model (the reference's constructor takes any tuple)."""
+    from dibs_amd.inference import JointDiBS
+    from dibs_amd.inference.scoring import score_graphs
+    from dibs_amd.target import make_nonlinear_gaussian_model
+    from dibs_amd import random
+    data, gm, lm = make_nonlinear_gaussian_model(key=random.PRNGKey(0), n_vars=8, graph_prior_str="er", n_observations=50,
+                                                 hidden_layers=(6, 4))
+    dibs = JointDiBS(x=data.x, graph_model=gm, likelihood_model=lm, n_grad_mc_samples=16, n_acyclicity_mc_samples=4)
+    g, theta = dibs.sample(key=random.PRNGKey(1), n_particles=4, steps=4)
+    assert g.shape == (4, 8, 8) and theta[0][0].shape == (4, 8, 8, 6) and theta[2][0].shape == (4, 8, 6, 4) and theta[4][0].shape == (4, 8, 4, 1)
+    flat = lm.tree_to_flat(theta)
+    cfg = make_config(n_vars=8, n_particles=1, n_observations=50, joint=True, likelihood="densenn", nn_hidden=(6, 4))
+    ref = c_oracle64.score_graphs(cfg, data.x_ho[:50], None, g, flat.astype(np.float64))
+    got = score_graphs(lm, g, flat, data.x_ho[:50], None)
+    assert rel_err(got, ref) < 2e-5
+
+
 def test_densenn_sample_and_scoring(c_oracle64):
     from dibs_amd.inference import JointDiBS
     from dibs_amd.inference.scoring import score_graphs
