@@ -42,6 +42,24 @@ def run_sharded(engine, t_start, n_steps, send, recv, group=None):
         engine.step_update(t, recv.data_ptr())
 
 
+def _gather_particles(eng, n_particles, group):
+    """z (and theta) of all ranks' particles as numpy arrays, on every rank"""
+    import torch
+    import torch.distributed as dist
+    eng.sync()
+    st = eng.get_state()
+    z = torch.from_numpy(st["z"]).cuda()
+    zs = torch.empty((n_particles,) + tuple(z.shape[1:]), dtype=z.dtype, device=z.device)
+    dist.all_gather_into_tensor(zs, z, group=group)
+    ths = None
+    if st["theta"] is not None:
+        th = torch.from_numpy(st["theta"]).cuda()
+        ths = torch.empty((n_particles, th.shape[1]), dtype=th.dtype, device=th.device)
+        dist.all_gather_into_tensor(ths, th, group=group)
+        ths = ths.cpu().numpy()
+    return zs.cpu().numpy(), ths
+
+
 def sample_sharded(dibs, *, key, n_particles, steps, n_dim_particles=None, callback_every=None, callback=None, group=None):
     """``MarginalDiBS.sample`` / ``JointDiBS.sample`` with the particles sharded over the ranks of ``group``.
     Every rank calls it with the same arguments and gets the full result (all particles)."""
@@ -65,19 +83,17 @@ def sample_sharded(dibs, *, key, n_particles, steps, n_dim_particles=None, callb
             for t in (range(0, steps, callback_every) if steps else range(0)):
                 run_sharded(eng, t, callback_every, send, recv, group)
                 if callback:
-                    callback(dibs=dibs, t=t + callback_every, engine=eng)
+                    # same keyword arguments as MarginalDiBS.sample / JointDiBS.sample (svgd.py:318-324, :783-789): ALL particles
+                    stream.synchronize()
+                    zs_all, th_all = _gather_particles(eng, n_particles, group)
+                    kw = dict(dibs=dibs, t=t + callback_every, zs=zs_all)
+                    if dibs._joint:
+                        kw["thetas"] = dibs._theta_out(th_all)
+                    callback(**kw)
         stream.synchronize()
-        eng.sync()
-        st = eng.get_state()
-        z = torch.from_numpy(st["z"]).cuda()
-        zs = torch.empty((n_particles,) + tuple(z.shape[1:]), dtype=z.dtype, device=z.device)
-        dist.all_gather_into_tensor(zs, z, group=group)
-        out_z = zs.cpu().numpy()
+        out_z, th_all = _gather_particles(eng, n_particles, group)
         if dibs._joint:
-            th = torch.from_numpy(st["theta"]).cuda()
-            ths = torch.empty((n_particles, th.shape[1]), dtype=th.dtype, device=th.device)
-            dist.all_gather_into_tensor(ths, th, group=group)
-            return dibs.particle_to_g_lim(out_z), dibs._theta_out(ths.cpu().numpy())
+            return dibs.particle_to_g_lim(out_z), dibs._theta_out(th_all)
         return dibs.particle_to_g_lim(out_z)
     finally:
         eng.close()

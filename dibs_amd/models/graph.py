@@ -53,18 +53,23 @@ class ScaleFreeDAGDistribution:
         """Barabasi-Albert preferential attachment (m = n_edges_per_node), edges new -> old, then a random
         relabelling.  (The reference delegates to igraph.Graph.Barabasi; this is an own generator.)"""
         d, m = self.n_vars, self.n_edges_per_node
-        rng = np.random.default_rng(int(np.asarray(random.as_key(key), np.uint64).sum()))
+        # one subkey for the attachment draws, one for the relabelling (both Threefry streams of dibs_amd.random)
+        k_attach, k_perm = random.split(random.as_key(key))
         mat = np.zeros((d, d), np.int32)
         deg = np.zeros(d)
         for v in range(1, d):
             k = min(m, v)
             w = deg[:v] + 1.0
-            targets = rng.choice(v, size=k, replace=False, p=w / w.sum())
+            # k targets without replacement, probability ~ degree + 1: Gumbel top-k on the uniform stream of this vertex
+            k_attach, sub = random.split(k_attach)
+            u01 = np.asarray(random.uniform(sub, (v,)), np.float64)
+            gumbel = -np.log(-np.log(np.clip(u01, 1e-12, 1.0 - 1e-12)))
+            targets = np.argsort(-(np.log(w / w.sum()) + gumbel), kind="stable")[:k]
             for u in targets:
                 mat[v, u] = 1
                 deg[u] += 1
                 deg[v] += 1
-        perm = random.permutation(key, d)
+        perm = random.permutation(k_perm, d)
         P = np.eye(d, dtype=np.int32)[perm]
         return P.T @ mat @ P
 

@@ -21,9 +21,10 @@ def build():
 
 class COracle:
     def __init__(self, precision="f64"):
-        path = os.path.join(_HERE, "_build", f"liboracle_{precision}.so")
+        asan = bool(os.environ.get("DIBS_ORACLE_ASAN"))   # sanitizer build (oracle/Makefile `asan`; needs LD_PRELOAD of libasan)
+        path = os.path.join(_HERE, "_build", f"liboracle_{precision}{'_asan' if asan else ''}.so")
         if not os.path.exists(path):
-            build()
+            subprocess.run(["make", "-s", "-C", _HERE] + (["asan"] if asan else []), check=True)
         self.lib = C.CDLL(path)
         self.real = np.float64 if precision == "f64" else np.float32
         self.lib.orc_theta_size.restype = C.c_int64
