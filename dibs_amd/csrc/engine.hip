@@ -252,11 +252,7 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
     if ((size_t)2 * 4 * c.n_particles * 4 + 4096 > LDS_LIMIT) return fail("n_particles too large (kernel rows must fit in LDS)");
     if (((size_t)c.n_vars * c.n_vars + (size_t)2 * c.n_vars * c.n_dim) * 4 > LDS_LIMIT) return fail("n_vars * n_dim too large");
   }
-  {  // LDS budgets of the likelihood kernels (x, theta / graph, per-sample operand and residuals are LDS-resident)
-    const int nt = (c.n_vars + 15) / 16;
-    if (c.likelihood == DIBS_LIK_LINGAUSS && lin_lds_bytes(c.n_vars, c.n_observations, nt, true) > LDS_LIMIT)
-      return fail("LinearGaussian: n_vars / n_observations too large for the LDS-resident kernels (n_vars <= 112 at 100 observations)");
-  }
+  // (LinearGaussian: x beyond the LDS capacity takes the Gram-matrix path; DenseNonlinearGaussian the general path)
   int ndev = 0;
   HIP_OK(hipGetDeviceCount(&ndev));
   if (ndev < 1) return fail("no HIP device");
@@ -415,6 +411,8 @@ extern "C" int dibs_engine_set_data(dibs_engine* e, const float* x, const int32_
     if (bge_prepare(&e->bge, e->cfg, e->d, e->N, x, interv_mask, bge_mean_obs)) return 1;
   } else {
     if (joint_set_data(&e->jw, x, interv_mask, e->N, e->d)) return fail("joint_set_data failed");
+    if (e->cfg.likelihood == DIBS_LIK_LINGAUSS && !joint_lin_fast_path(e->d, e->N) && joint_lin_set_gram(&e->jw, x, interv_mask, e->N, e->d))
+      return fail("LinearGaussian: Gram matrices: hipMalloc failed");
   }
   e->has_data = true;
   return 0;
@@ -902,6 +900,7 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
     const bool nn = c.likelihood == DIBS_LIK_DENSENN;
     JointWorkGuard jg;
     if (joint_set_data(&jg.jw, x_ho, mask_ho, n_ho, d)) return fail("joint_set_data failed");
+    if (!nn && !joint_lin_fast_path(d, n_ho) && joint_lin_set_gram(&jg.jw, x_ho, mask_ho, n_ho, d)) return fail("LinearGaussian: Gram matrices: hipMalloc failed");
     const size_t P = nn ? (size_t)e->P : dd;
     DevBuf<float> d_th;
     DevBuf<int32_t> d_g;

@@ -19,6 +19,9 @@ struct JointWork {
   float* wsm;      // [Mloc, S] softmax weights scratch
   float* ln_tab;   // [Mloc, d, d] DenseNN: per-particle first-layer prior table (kernels_nn.h), else null
   int any_mask;
+  double* gram;    // LinearGaussian Gram path (kernels_lin_gram.h): C^(j) [n_gram][d][d], observations not intervened on j
+  double* ncnt;    // [d] their count
+  int n_gram;      // 1 without interventions, else d; 0: not built
   float* nng_scratch;         // general DenseNN path (kernels_nn_generic.h): activation records, grown on first use
   size_t nng_scratch_floats;
 };
@@ -535,6 +538,9 @@ __global__ __launch_bounds__(256) void k_lin_grad(const float* __restrict__ x, c
 int joint_alloc(JointWork* w, int Mloc, int d, int N, int S);
 void joint_free(JointWork* w);
 int joint_set_data(JointWork* w, const float* x, const int32_t* mask, int N, int d);
+// true: x fits the LDS-resident MFMA kernels; false: the Gram-matrix path of kernels_lin_gram.h runs (joint_lin_set_gram builds C)
+bool joint_lin_fast_path(int d, int N);
+int joint_lin_set_gram(JointWork* w, const float* x, const int32_t* mask, int N, int d);
 void joint_lin_all_logprobs(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z);
 void joint_lin_all_grads(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z);
 // log p(theta_i, D | g_i) of n given (graph, parameter) pairs (held-out scoring; dibs_score_graphs)
@@ -542,6 +548,49 @@ void joint_lin_score_given(const JointWork& jw, const float* theta, const int32_
                            float mean_edge, float sig_edge, hipStream_t stream);
 
 #ifdef DIBS_TU_LIN
+#include <stdlib.h>
+#include <vector>
+#include "kernels_lin_gram.h"
+
+bool joint_lin_fast_path(int d, int N) {
+  return !getenv("DIBS_LIN_GRAM") && lin_lds_bytes(d, N, (d + 15) / 16, true) <= (size_t)160 * 1024;
+}
+
+int joint_lin_set_gram(JointWork* w, const float* x, const int32_t* mask, int N, int d) {
+  bool any = false;
+  if (mask)
+    for (size_t i = 0; i < (size_t)N * d; ++i) any |= mask[i] != 0;
+  const int ng = any ? d : 1;
+  std::vector<double> C((size_t)ng * d * d, 0.0), cnt(d, 0.0);
+  for (int jm = 0; jm < ng; ++jm)
+    for (int n = 0; n < N; ++n) {
+      if (any && mask[(size_t)n * d + jm]) continue;
+      const float* xr = x + (size_t)n * d;
+      double* Cj = C.data() + (size_t)jm * d * d;
+      for (int a = 0; a < d; ++a) {
+        const double xa = xr[a];
+        for (int b = 0; b < d; ++b) Cj[(size_t)a * d + b] += xa * (double)xr[b];
+      }
+    }
+  for (int j = 0; j < d; ++j)
+    for (int n = 0; n < N; ++n) cnt[j] += (any && mask[(size_t)n * d + j]) ? 0.0 : 1.0;
+  if (w->gram) hipFree(w->gram);
+  if (w->ncnt) hipFree(w->ncnt);
+  w->gram = nullptr;
+  w->ncnt = nullptr;
+  w->n_gram = 0;
+  if (hipMalloc((void**)&w->gram, C.size() * 8) != hipSuccess) return 1;
+  if (hipMalloc((void**)&w->ncnt, cnt.size() * 8) != hipSuccess) return 1;
+  if (hipMemcpy(w->gram, C.data(), C.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return 1;
+  if (hipMemcpy(w->ncnt, cnt.data(), cnt.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return 1;
+  w->n_gram = ng;
+  return 0;
+}
+
+static size_t ling_lds(int d, int n_gram, bool grad) {
+  const size_t dd = (size_t)d * d;
+  return (n_gram == 1 ? dd * 8 : 0) + (((grad ? 2 : 1) * dd * 4 + 15) & ~(size_t)15) + 128;
+}
 int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) {
   (void)N;
   w->x = nullptr;
@@ -550,6 +599,9 @@ int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) {
   w->any_mask = 0;
   w->nng_scratch = nullptr;
   w->nng_scratch_floats = 0;
+  w->gram = nullptr;
+  w->ncnt = nullptr;
+  w->n_gram = 0;
   if (hipMalloc((void**)&w->wsm, (size_t)Mloc * S * 4) != hipSuccess) return 1;
   if (hipMalloc((void**)&w->ln_tab, (size_t)Mloc * d * d * 4) != hipSuccess) return 1;
   return 0;
@@ -560,6 +612,11 @@ void joint_free(JointWork* w) {
   if (w->wsm) hipFree(w->wsm);
   if (w->ln_tab) hipFree(w->ln_tab);
   if (w->nng_scratch) hipFree(w->nng_scratch);
+  if (w->gram) hipFree(w->gram);
+  if (w->ncnt) hipFree(w->ncnt);
+  w->gram = nullptr;
+  w->ncnt = nullptr;
+  w->n_gram = 0;
   w->nng_scratch = nullptr;
   w->nng_scratch_floats = 0;
   w->ln_tab = nullptr;
@@ -641,12 +698,34 @@ static void joint_lin_grads(JointWork* w, const JointLaunch& jl, Key2 carry_thet
 // log p(theta, D | G_s) for the samples of the theta estimator and of the Z estimator (two launches)
 void joint_lin_all_logprobs(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z) {
   const int mz = jl.est_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM;
+  if (w->n_gram) {  // Gram-matrix path (x does not fit LDS)
+    const size_t lds = ling_lds(jl.d, w->n_gram, false);
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_ling_logprobs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_ling_logprobs, dim3(jl.S, jl.Mloc), dim3(256), lds, jl.stream, w->gram, w->ncnt, w->n_gram, jl.theta, jl.scores, jl.thr,
+                       jl.logprobs_th, carry_theta, (int)LIN_MODE_THETA, jl.m0, jl.M, jl.d, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise,
+                       jl.mean_edge, jl.sig_edge);
+    hipLaunchKernelGGL(k_ling_logprobs, dim3(jl.S, jl.Mloc), dim3(256), lds, jl.stream, w->gram, w->ncnt, w->n_gram, jl.theta, jl.scores, jl.thr,
+                       jl.logprobs_z, carry_z, mz, jl.m0, jl.M, jl.d, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise, jl.mean_edge,
+                       jl.sig_edge);
+    return;
+  }
 #define LIN_CALL(NT_) { joint_lin_logprobs<NT_>(w, jl, carry_theta, LIN_MODE_THETA); joint_lin_logprobs<NT_>(w, jl, carry_z, mz); }
   LIN_NT_SWITCH(LIN_CALL)
 #undef LIN_CALL
 }
 // both softmax-weighted gradients in one launch
 void joint_lin_all_grads(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z) {
+  if (w->n_gram) {
+    const size_t lds = ling_lds(jl.d, w->n_gram, true);
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_ling_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const LinGradJob jt{jl.logprobs_th, jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off, jl.pack_stride,
+                        jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off, nullptr, carry_theta, LIN_MODE_THETA};
+    const LinGradJob jz{jl.logprobs_z, jl.w_lik, (size_t)jl.d * jl.d, nullptr, jl.baseline_out, carry_z,
+                        jl.est_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM};
+    hipLaunchKernelGGL(k_ling_grad, dim3(jl.Mloc, 2), dim3(256), lds, jl.stream, w->gram, w->n_gram, jl.theta, jl.scores, jl.thr, jt, jz, jl.baseline,
+                       jl.m0, jl.M, jl.d, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise, jl.mean_edge, jl.sig_edge, jl.sf_baseline);
+    return;
+  }
 #define LIN_CALL(NT_) joint_lin_grads<NT_>(w, jl, carry_theta, carry_z)
   LIN_NT_SWITCH(LIN_CALL)
 #undef LIN_CALL
@@ -664,6 +743,14 @@ static void launch_lin_given(const JointWork& jw, const float* theta, const int3
 }
 void joint_lin_score_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N, float obs_noise,
                            float mean_edge, float sig_edge, hipStream_t stream) {
+  if (jw.n_gram) {
+    const size_t lds = ling_lds(d, jw.n_gram, false);
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_ling_logprobs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_ling_logprobs, dim3(1, n), dim3(256), lds, stream, jw.gram, jw.ncnt, jw.n_gram, theta, (const float*)nullptr,
+                       reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, 1, 0.f, 1.f, 0, 0, obs_noise, mean_edge,
+                       sig_edge);
+    return;
+  }
   switch ((d + 15) / 16) {
     case 1: launch_lin_given<1>(jw, theta, g, out, n, d, N, obs_noise, mean_edge, sig_edge, stream); break;
     case 2: launch_lin_given<2>(jw, theta, g, out, n, d, N, obs_noise, mean_edge, sig_edge, stream); break;

@@ -281,6 +281,54 @@ def test_joint_lingauss_step_stages(c_oracle64, d, M, S, Sa, est, prior, interv,
     eng.close()
 
 
+@pytest.mark.parametrize("d,M,S,Sa,est,interv,N,force", [
+    (20, 4, 32, 8, "reparam", False, 100, True),    # same sizes as the MFMA path: both device paths against one oracle
+    (20, 4, 32, 8, "score", True, 100, True),
+    (50, 3, 32, 8, "reparam", True, 100, True),
+    (20, 3, 32, 8, "reparam", True, 900, False),    # x [900, 20] does not fit LDS: the engine picks the Gram path by itself
+    (50, 2, 16, 4, "reparam", False, 400, False),
+])
+def test_joint_lingauss_gram_path(c_oracle64, monkeypatch, d, M, S, Sa, est, interv, N, force):
+    """LinearGaussian for any number of observations (linearGaussian.py:292-316): the Gram-matrix path of kernels_lin_gram.h,
+    stage by stage against the oracle; held-out scoring on the same path."""
+    from dibs_amd.inference.scoring import score_graphs
+    from dibs_amd.models import LinearGaussian
+    if force:
+        monkeypatch.setenv("DIBS_LIN_GRAM", "1")
+    rng = np.random.default_rng(3)
+    wts = (rng.random((d, d)) < 2.0 / d) * rng.normal(size=(d, d))
+    x = rng.normal(size=(N, d)).astype(np.float32)
+    for j in range(d):   # some structure in the data (lower-triangular mechanism)
+        x[:, j] += (x[:, :j] @ np.tril(wts.T, -1)[j, :j]).astype(np.float32)
+    mask = (rng.random((N, d)) < 0.1).astype(np.int32) if interv else None
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=N, joint=True, likelihood="lingauss", grad_estimator_z=est,
+                      n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa, has_interventions=interv)
+    st = c_oracle64.new_state(cfg, prng.PRNGKey(3))
+    eng = _engine(cfg, x, mask)
+    eng.init_particles(prng.PRNGKey(3))
+    for t in (1, 3):
+        _sync_states(eng, st)
+        dbg = c_oracle64.step(cfg, x, mask, st, t, debug=True)
+        eng.run(t, 1)
+        g = eng.get_state()
+        assert (g["key"] == st["key"]).all()
+        assert rel_err(eng.read("LOGPROBS_THETA"), dbg["logprobs_th"]) < 2e-5
+        assert rel_err(eng.read("LOGPROBS_Z"), dbg["logprobs_z"]) < 2e-5
+        assert rel_err(eng.read("GRAD_THETA"), dbg["grad_theta"]) < 2e-3
+        assert rel_err(eng.read("W_LIK"), dbg["w_lik"]) < 2e-3
+        assert rel_err(eng.read("GRAD_Z"), dbg["grad_z"]) < 2e-3
+        assert rel_err(eng.read("PHI_THETA"), dbg["phi_theta"]) < 2e-3
+        assert rel_err(g["theta"], st["theta"]) < 1e-4
+        assert rel_err(g["z"], st["z"]) < 1e-4
+    eng.close()
+    gs = (rng.random((5, d, d)) < 0.1).astype(np.int32)
+    gs[:, np.arange(d), np.arange(d)] = 0
+    th = rng.normal(size=(5, d, d)).astype(np.float32)
+    ref = c_oracle64.score_graphs(cfg, x, mask, gs, th.reshape(5, -1).astype(np.float64))
+    got = score_graphs(LinearGaussian(n_vars=d), gs, th, x, mask)
+    assert rel_err(got, ref) < 2e-5
+
+
 def test_golden_joint_lingauss():
     gold = np.load(os.path.join(GOLD, "joint_lingauss_d5.npz"))
     cfg = make_config(n_vars=5, n_particles=3, n_observations=100, edges_per_node=1, joint=True, likelihood="lingauss",
@@ -515,7 +563,7 @@ def test_sharded_engines_match_single_rank(joint):
         e.close()
 
 
-@pytest.mark.parametrize("d,M,S,Sa,interv", [(5, 2, 6, 4, False), (8, 2, 4, 2, True), (12, 1, 4, 2, False)])
+@pytest.mark.parametrize("d,M,S,Sa,interv", [(5, 2, 6, 4, False), (8, 2, 4, 2, True), (12, 1, 4, 2, False), (20, 1, 4, 2, False), (40, 1, 2, 2, True)])
 def test_marginal_bge_reparam_estimator(d, M, S, Sa, interv):
     """MarginalDiBS(grad_estimator_z='reparam'): BGe on Gumbel-soft graphs (dibs.py:395-459 with linearGaussian.py:63-170 on a
     real-valued parent vector).  Checked against the torch-autograd oracle (the C port has no soft BGe), which differentiates
