@@ -119,6 +119,50 @@ def test_marginal_bge_with_interventions(c_oracle64):
     eng.close()
 
 
+@pytest.mark.parametrize("d,M,S,Sa,k,case", [
+    (2, 1, 1, 1, 2, "minimal"),          # smallest legal problem: one particle, one sample, one chain (unpaired Threefry paths)
+    (2, 3, 2, 2, 1, "k1"),               # latent dimension 1
+    (9, 2, 8, 2, 4, "all_intervened"),   # node 3 is intervened in EVERY observation: N_j = 0, its BGe term is 0 (linearGaussian.py:118)
+    (6, 2, 4, 2, 6, "one_observation"),  # a single observation
+    (33, 2, 6, 2, 33, "d33"),            # one variable past two MFMA tiles; 64-bit masks half used
+    (64, 1, 4, 2, 8, "d64"),             # mask word exactly full, n <= 32 via the complement form for every parent set
+    (65, 1, 4, 2, 8, "d65"),             # first size with two mask words and the one-problem-per-wave tier reachable
+])
+def test_marginal_bge_edge_cases(c_oracle64, d, M, S, Sa, k, case):
+    """Edge cases of the marginal step against the oracle: degenerate sizes, latent dimension != n_vars, a node without
+    observational data, mask-word boundaries."""
+    N = 1 if case == "one_observation" else 40
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(N, d)).astype(np.float32)
+    mask = None
+    if case == "all_intervened":
+        mask = (rng.random((N, d)) < 0.1).astype(np.int32)
+        mask[:, 3] = 1
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=N, n_dim=k, edges_per_node=0.4 if d == 2 else (1 if d <= 9 else 2),
+                      n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa, has_interventions=mask is not None)
+    st = c_oracle64.new_state(cfg, prng.PRNGKey(11))
+    eng = _engine(cfg, x, mask)
+    eng.init_particles(prng.PRNGKey(11))
+    g0 = eng.get_state()
+    assert (g0["key"] == st["key"]).all() and rel_err(g0["z"], st["z"]) < 1e-6
+    for t in (0, 1, 4):
+        _sync_states(eng, st)
+        dbg = c_oracle64.step(cfg, x, mask, st, t, debug=True)
+        eng.run(t, 1)
+        g = eng.get_state()
+        assert np.array_equal(_graphs_from_masks(eng.read("PARENT_MASKS"), M, S, d), dbg["g_samples"])
+        assert (g["key"] == st["key"]).all()
+        ns = eng.read("NODE_SCORES").reshape(M, d, S).transpose(0, 2, 1)
+        assert rel_err(ns, dbg["node_scores"]) < (1e-4 if d <= 50 else 5e-4)
+        if case == "all_intervened":
+            assert not ns[:, :, 3].any()
+        assert rel_err(eng.read("W_LIK"), dbg["w_lik"]) < 2e-3 or np.abs(dbg["w_lik"]).max() == 0
+        assert rel_err(eng.read("W_ACYC"), dbg["w_acyc"]) < 1e-5 or np.abs(dbg["w_acyc"]).max() == 0
+        assert rel_err(eng.read("KXX"), dbg["kxx"]) < 1e-5
+        assert rel_err(g["z"], st["z"]) < 1e-4
+    eng.close()
+
+
 def test_score_function_baseline_and_gd_optimizer(c_oracle64):
     d, M = 8, 4
     data, _, _ = make_data(d, seed=1)
