@@ -2,6 +2,8 @@
 #define DIBS_TU_ACYC
 #include "launch.h"
 #include "kernels_acyc.h"
+#include "kernels_acyc_bf16.h"
+#include <stdlib.h>
 
 template <int NT>
 static void launch_nt(const AcycLaunch& a, const LikArgs& lik, int lik_blocks, size_t lik_lds) {
@@ -21,7 +23,25 @@ static void launch_nt(const AcycLaunch& a, const LikArgs& lik, int lik_blocks, s
   }
 }
 
+// 33 <= d <= 64 with paired chains: split-bf16 MFMA kernel (kernels_acyc_bf16.h); DIBS_ACYC_F32=1 keeps the f32-MFMA kernel (A/B runs)
+static bool acyc_use_bf16(const AcycLaunch& a) {
+  static const bool off = getenv("DIBS_ACYC_F32") != nullptr;
+  return !off && a.units != a.Sa && a.d > 32 && a.d <= 64;
+}
+
 void acyc_launch(const AcycLaunch& a, const LikArgs& lik, int lik_blocks, size_t lik_lds) {
+  if (acyc_use_bf16(a)) {
+    size_t lds = 2 * ABF_IMG_BYTES;
+    if (lik_blocks && lik_lds > lds) lds = lik_lds;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+      hipFuncSetAttribute((const void*)k_acyc_bf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      lds_set = lds;
+    }
+    hipLaunchKernelGGL(k_acyc_bf, dim3(a.nblk + lik_blocks, a.Mloc), dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.d, a.Sa, a.cpb,
+                       a.alpha, a.tau, a.layout, a.tiny, a.nblk, lik);
+    return;
+  }
   switch ((a.d + 15) / 16) {
     case 1: launch_nt<1>(a, lik, lik_blocks, lik_lds); break;
     case 2: launch_nt<2>(a, lik, lik_blocks, lik_lds); break;
