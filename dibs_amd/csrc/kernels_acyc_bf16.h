@@ -28,6 +28,16 @@
 // The last power is written as float [row][68] into the free image and read back transposed for
 //   out[a][b] += (M^{d-1})[b][a] * tau * alpha * g (1 - g).
 // grid = (ceil(Sa / 2 / cpb) [+ score-estimator blocks], Mloc), block = 256, dynamic LDS = 2 * 24576
+//
+// Where the time goes at the headline size (2 048 blocks, 94 us; counters of scripts/probe/acyc_bf_probe.hip): 5.5 M MFMAs = 86 k cycles
+// per SIMD, 26 M other vector instructions (a third each: Threefry draws, operand splits, the rest) = ~102 k cycles; SQ_ACTIVE_INST_ANY
+// is 94 % of the launch, i.e. the kernel runs at the sum of the two.  Tried and dropped, each measured on the box:
+//  * fragments of the next tile pair loaded ahead of the current MFMAs: +-0 (three waves per SIMD hide the LDS latency);
+//  * two blocks per CU with 256 registers: 120 us;
+//  * the block's sum kept in `part` (read-modify-write per chain) instead of 16 registers: +10 us;
+//  * M's fragments kept for the whole chain instead of rebuilt for the two "times M" steps: spills, 114 us;
+//  * soft graphs drawn in element order (every lane busy, 40 instead of 56 wave-draws per pair) and handed to the owners through LDS:
+//    93-95 us, within noise of the plain version.
 // ------------------------------------------------------------------------------------------------
 typedef short abf_s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 abf_bf16x8 __attribute__((ext_vector_type(8)));
@@ -114,7 +124,11 @@ __device__ __forceinline__ void abf_matmul(f32x4 (&acc)[ABF_NT], const AbfFrag& 
     if (grp > 0) abf_load_b(b[cb], img, rd_off, grp);
     const abf_bf16x8 ah = __builtin_bit_cast(abf_bf16x8, A.a[ks][0]), am = __builtin_bit_cast(abf_bf16x8, A.a[ks][1]),
                      al = __builtin_bit_cast(abf_bf16x8, A.a[ks][2]);
-    // small terms first; the two tiles alternate so that consecutive MFMAs never share an accumulator
+    // small terms first; the two tiles alternate so that consecutive MFMAs never share an accumulator.
+    // Accuracy against a double reference at d = 50 (scripts/probe/acyc_bf_probe.hip): 2.5e-6 of max |out|, the f32-MFMA kernel 3e-7.
+    // The difference is not the split (x - h - m - l <= 2^-27 x) nor the accumulation order (all ten small products of a tile first,
+    // Ah Bh last: same 2.5e-6) -- the 32-term dot product inside one bf16 MFMA truncates, and with all entries >= 0 that is a bias
+    // of ~2^-24 per product level which the powering multiplies by the exponent.
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       if (ks == 0) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[cb][u][2], ah, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);

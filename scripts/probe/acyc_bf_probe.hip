@@ -105,5 +105,7 @@ int main() {
   run(33, 1, 2, 0.2f, false);
   run(60, 1, 2, 2.0f, false);
   run(50, 128, 32, 0.05f, true);
+  run(40, 128, 32, 0.05f, true);
+  run(64, 128, 32, 0.05f, true);
   return 0;
 }
