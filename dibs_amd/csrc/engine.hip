@@ -572,8 +572,10 @@ static int step_local(dibs_engine* e, int t, float* pack) {
   LikArgs lik{};
   int lik_blocks = 0;
   size_t lik_lds = 0;
-  const bool fork = e->stream2 && !e->profiling && c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z != DIBS_EST_REPARAM &&
-                    (long)e->acyc_nblk * e->Mloc > 512;
+  // (not when the score estimator's blocks ride along in the acyclicity launch: see below)
+  const bool rider = c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z != DIBS_EST_REPARAM && (long)e->acyc_nblk * e->Mloc <= 512 &&
+                     !getenv("DIBS_NO_LIK_FUSE");
+  const bool fork = e->stream2 && !e->profiling && !rider;
   if (fork) {
     hipEventRecord(e->ev_fork, e->stream);
     hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
