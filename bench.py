@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 D_VARS, N_PARTICLES, N_OBS, S_MC, SA_MC = 50, 128, 100, 128, 32
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector (packed) == FP32 MFMA peak, 64 FLOP/clk/SIMD
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBPS = 8000.0
 N_SIMD, CLK_GHZ = 1024, 2.4
 VALU_CYC_PER_INSTR = 4.0  # measured issue rate of plain (unpacked) VALU wave-instructions, scripts/probe/valu_rate.hip
@@ -152,12 +153,22 @@ def main():
         # SURVEY.md 8(d) algorithmic flop counts per step (= per launch: each kernel is launched once per step)
         acyc_flops = M * SA_MC * binary_powering_matmuls(D_VARS - 1) * 2 * D_VARS ** 3   # F_acyc
         dense_bge = M * S_MC * D_VARS * 2 * D_VARS ** 3 / 3.0                            # F_lik(BGe), reference's dense count
-        names = {"acyc": "k_acyc<4, true>", "bge_nodes": "k_bge_sample<4, true>", "bge_big": "k_bge_chol<true, false>"}
+        names = {"acyc": "k_acyc_bf", "bge_nodes": "k_bge_sample<4, true>", "bge_big": "k_bge_chol<true, false>"}
         roof = {"kernel": dom, "rocprof_kernel": names.get(dom, "k_" + dom), "avg_launch_us": avg_s * 1e6, "launches": dom_n,
                 "share_of_step": dom_ms / total_ms, "unit": "TFLOP/s", "peak": PEAK_F32_TFLOPS, "traffic": None}
         if dom == "acyc":
-            roof.update(bound="mfma", pipe="mfma_f32", flops_per_launch=acyc_flops, achieved=acyc_flops / avg_s / 1e12,
-                        flops_model="M*Sa*c(d-1)*2*d^3, c(49)=7 matmuls of binary powering (SURVEY 8(d) F_acyc)")
+            # float products evaluated on the bf16 matrix pipe with three-way split operands (6 bf16 MFMAs per float product block,
+            # kernels_acyc_bf16.h).  `achieved` / `frac` price the ALGORITHMIC float flops against the FP32 peak; the bf16 flops the
+            # kernel actually issues (64-padded tiles, 6 products) are priced against the dense bf16 peak next to it.
+            n_mm = binary_powering_matmuls(D_VARS - 1)
+            bf16_flops = M * SA_MC * n_mm * 6 * 2 * 64 ** 3
+            roof.update(bound="mfma", pipe="mfma_bf16 (3-way split operands: 6 bf16 products per f32 product)", flops_per_launch=acyc_flops,
+                        achieved=acyc_flops / avg_s / 1e12,
+                        flops_model="M*Sa*c(d-1)*2*d^3, c(49)=7 matmuls of binary powering (SURVEY 8(d) F_acyc)",
+                        executed_bf16_tflops=bf16_flops / avg_s / 1e12, peak_bf16_tflops=PEAK_BF16_TFLOPS,
+                        frac_of_bf16_peak=bf16_flops / avg_s / 1e12 / PEAK_BF16_TFLOPS,
+                        duration="kernel alone on the GPU (all launches on one stream while timing); in the timed region it runs on a second "
+                                 "stream beside the BGe kernels, see kernel_us_per_step_concurrent")
         elif dom == "bge_big":
             # VALU kernel: the work actually executed (the reference's dense 2 d^3/3-per-determinant count is not what runs:
             # only R[pa + j] is factorised).  Priced against the f32 vector peak.
@@ -186,6 +197,13 @@ def main():
         out["hbm_algorithmic"] = {"bytes_per_step": bytes_step, "achieved_GBps": bytes_step * steps_per_s / 1e9,
                                   "frac_of_8TBps": bytes_step * steps_per_s / 1e9 / PEAK_HBM_GBPS}
         out["kernel_us_per_step"] = {k_: ms / K * 1e3 for k_, (ms, n_) in timers.items()}
+        # the same replay with the production schedule (acyclicity kernel on the second stream, timed there): overlapping kernels share the GPU
+        eng.set_state(**snap)
+        eng.set_profiling(2)
+        eng.reset_timers()
+        eng.run(W, K)
+        out["kernel_us_per_step_concurrent"] = {k_: ms / K * 1e3 for k_, (ms, n_) in eng.timers().items()}
+        eng.set_profiling(False)
         out["bge_executed_gflop_per_step"] = bge_flops / 1e9
 
         if not args.no_cpu_baseline:

@@ -78,6 +78,7 @@ struct dibs_engine {
   JointWork jw;
   // profiling
   bool profiling;
+  bool profiling_concurrent;  // set_profiling(2): keep the second stream while timing (the acyclicity kernel is timed on its own stream)
   hipEvent_t ev0, ev1;
   hipStream_t stream2;      // the acyclicity kernel (needs only the edge scores) runs beside sampling -> factorisation -> weights: its bf16 MFMAs
                             // overlap with their vector work.  Same arithmetic, same results; DIBS_NO_ACYC_STREAM2 keeps one stream.
@@ -512,16 +513,17 @@ struct KTimer {
   dibs_engine* e;
   int id;
   hipEvent_t a, b;
-  KTimer(dibs_engine* e_, int id_) : e(e_), id(id_), a(nullptr), b(nullptr) {
+  hipStream_t st;
+  KTimer(dibs_engine* e_, int id_, hipStream_t st_ = nullptr) : e(e_), id(id_), a(nullptr), b(nullptr), st(st_ ? st_ : e_->stream) {
     if (e->profiling) {
       hipEventCreate(&a);
       hipEventCreate(&b);
-      hipEventRecord(a, e->stream);
+      hipEventRecord(a, st);
     }
   }
   ~KTimer() {
     if (e->profiling) {
-      hipEventRecord(b, e->stream);
+      hipEventRecord(b, st);
       e->pending.push_back({id, {a, b}});
     }
   }
@@ -575,15 +577,16 @@ static int step_local(dibs_engine* e, int t, float* pack) {
   // (not when the score estimator's blocks ride along in the acyclicity launch: see below)
   const bool rider = c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z != DIBS_EST_REPARAM && (long)e->acyc_nblk * e->Mloc <= 512 &&
                      !getenv("DIBS_NO_LIK_FUSE");
-  const bool fork = e->stream2 && !e->profiling && !rider;
+  const bool fork = e->stream2 && (!e->profiling || e->profiling_concurrent) && !rider;
   if (fork) {
     hipEventRecord(e->ev_fork, e->stream);
     hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
+    KTimer tm(e, DIBS_K_ACYC, e->stream2);
     const AcycLaunch al{e->stream2, e->scores, e->acyc_part, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
                         e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny};
     acyc_launch(al, lik, 0, 0);
-    hipEventRecord(e->ev_join, e->stream2);
   }
+  if (fork) hipEventRecord(e->ev_join, e->stream2);
   if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_REPARAM) {
     const BgeSoftParams sp{e->bge.R, e->bge.Nj, e->bge.alpha_lambd, e->bge.alpha_mu, e->bge.log_t, e->bge.n_mats};
     KTimer tm(e, DIBS_K_BGE_NODES);
@@ -833,6 +836,7 @@ extern "C" int dibs_engine_set_profiling(dibs_engine* e, int32_t enable) {
   hipStreamSynchronize(e->stream);
   drain_timers(e);
   e->profiling = enable != 0;
+  e->profiling_concurrent = enable == 2;
   return 0;
 }
 

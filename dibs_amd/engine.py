@@ -91,7 +91,7 @@ class Engine:
         return out
 
     def set_profiling(self, on):
-        _lib.check(self.lib.dibs_engine_set_profiling(self._h, int(bool(on))))
+        _lib.check(self.lib.dibs_engine_set_profiling(self._h, 2 if on == 2 else int(bool(on))))
 
     def reset_timers(self):
         _lib.check(self.lib.dibs_engine_reset_timers(self._h))

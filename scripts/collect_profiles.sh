@@ -10,8 +10,11 @@ ARGS="--no-cpu-baseline --reps 1 --steps 20 --warmup 5"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 python bench.py > gpurun_out/${TAG}_bench_full.json 2> gpurun_out/${TAG}_bench_err.log
-bash scripts/rocprof_bench.sh ${TAG} --reps 1 --steps 20 --warmup 5 > /dev/null
-bash scripts/rocprof_steady.sh ${TAG} 300 100 > /dev/null
+# kernel stats twice: every kernel on one stream (DIBS_NO_ACYC_STREAM2: each duration is the kernel alone on the GPU -- what bench.py's
+# `roofline` quotes) and the production schedule (the acyclicity kernel on the second stream: overlapping kernels share the GPU)
+DIBS_NO_ACYC_STREAM2=1 bash scripts/rocprof_bench.sh ${TAG} --reps 1 --steps 20 --warmup 5 > /dev/null
+bash scripts/rocprof_bench.sh ${TAG}_concurrent --reps 1 --steps 20 --warmup 5 > /dev/null
+DIBS_NO_ACYC_STREAM2=1 bash scripts/rocprof_steady.sh ${TAG} 300 100 > /dev/null
 LASTN=0 bash scripts/rocprof_pmc.sh ${TAG}_fetch FETCH_SIZE -- python bench.py $ARGS > gpurun_out/${TAG}_pmc_fetch.txt 2>&1
 LASTN=0 bash scripts/rocprof_pmc.sh ${TAG}_write WRITE_SIZE -- python bench.py $ARGS > gpurun_out/${TAG}_pmc_write.txt 2>&1
 LASTN=0 bash scripts/rocprof_pmc.sh ${TAG}_issue "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" -- python bench.py $ARGS > gpurun_out/${TAG}_pmc_issue_window.txt 2>&1
@@ -29,7 +32,7 @@ def parse(path, key):
         if key in d: out[name.strip()] = float(d[key])
     return out
 f, w = parse(f"gpurun_out/{tag}_pmc_fetch.txt", "FETCH_SIZE"), parse(f"gpurun_out/{tag}_pmc_write.txt", "WRITE_SIZE")
-names = {"void k_acyc<4, true>": "acyc", "void k_bge_sample<4, true>": "bge_nodes", "void k_bge_chol<true, false>": "bge_big", "k_lik_weights_score": "lik_weights",
+names = {"k_acyc_bf": "acyc", "void k_bge_sample<4, true>": "bge_nodes", "void k_bge_chol<true, false>": "bge_big", "k_lik_weights_score": "lik_weights",
          "k_kmat": "kmat", "void k_phi_update<8>": "phi_update", "k_edge_scores": "edge", "k_zgrad": "zgrad", "k_wtotal": "wtotal"}
 res = {}
 for k, short in names.items():
