@@ -167,7 +167,7 @@ def main():
                         flops_model="M*Sa*c(d-1)*2*d^3, c(49)=7 matmuls of binary powering (SURVEY 8(d) F_acyc)",
                         executed_bf16_tflops=bf16_flops / avg_s / 1e12, peak_bf16_tflops=PEAK_BF16_TFLOPS,
                         frac_of_bf16_peak=bf16_flops / avg_s / 1e12 / PEAK_BF16_TFLOPS,
-                        duration="kernel alone on the GPU (all launches on one stream while timing); in the timed region it runs on a second "
+                        duration="kernel alone on the GPU (the step is serialised while timing); in the timed region it runs on its second "
                                  "stream beside the BGe kernels, see kernel_us_per_step_concurrent")
         elif dom == "bge_big":
             # VALU kernel: the work actually executed (the reference's dense 2 d^3/3-per-determinant count is not what runs:

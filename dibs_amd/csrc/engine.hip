@@ -577,7 +577,10 @@ static int step_local(dibs_engine* e, int t, float* pack) {
   // (not when the score estimator's blocks ride along in the acyclicity launch: see below)
   const bool rider = c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z != DIBS_EST_REPARAM && (long)e->acyc_nblk * e->Mloc <= 512 &&
                      !getenv("DIBS_NO_LIK_FUSE");
-  const bool fork = e->stream2 && (!e->profiling || e->profiling_concurrent) && !rider;
+  // While per-kernel timing is on (set_profiling(1)) the main stream joins right away, so that every duration is a kernel alone on the
+  // GPU -- but the launch still goes to the second stream: with that (high-priority) queue in existence the same kernel takes 104 us
+  // on the main stream and 96 us on its own.
+  const bool fork = e->stream2 && !rider, join_now = e->profiling && !e->profiling_concurrent;
   if (fork) {
     hipEventRecord(e->ev_fork, e->stream);
     hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
@@ -587,6 +590,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     acyc_launch(al, lik, 0, 0);
   }
   if (fork) hipEventRecord(e->ev_join, e->stream2);
+  if (fork && join_now) hipStreamWaitEvent(e->stream, e->ev_join, 0);
   if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_REPARAM) {
     const BgeSoftParams sp{e->bge.R, e->bge.Nj, e->bge.alpha_lambd, e->bge.alpha_mu, e->bge.log_t, e->bge.n_mats};
     KTimer tm(e, DIBS_K_BGE_NODES);
@@ -716,11 +720,13 @@ static int step_update(dibs_engine* e, int t, const float* pack) {
       int ta = 16;
       while (ta > 4 && (cols * ((e->Mloc + ta - 1) / ta) < 1024 || (size_t)2 * ta * e->M * 4 > 48 * 1024)) ta >>= 1;
       const size_t lds = ((size_t)2 * ta * e->M + (size_t)4 * ta * 64) * 4;
-      const dim3 g((unsigned)cols, (e->Mloc + ta - 1) / ta);
+      const int ngroups = (e->Mloc + ta - 1) / ta;
+      const dim3 g((unsigned)(8 * ngroups * ((cols + 7) / 8)));
 #define PHI_LAUNCH(TA_)                                                                                                        \
       allow_lds(k_phi_update<TA_>, lds);                                                                                         \
       hipLaunchKernelGGL(k_phi_update<TA_>, g, dim3(256), lds, e->stream, pack, (size_t)e->E, val_off, grad_off, (int)len, e->kz, \
-                         e->kt, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize, c.optimizer == DIBS_OPT_RMSPROP);
+                         e->kt, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize, c.optimizer == DIBS_OPT_RMSPROP, \
+                         (int)cols, ngroups);
       if (ta == 16) { PHI_LAUNCH(16) } else if (ta == 8) { PHI_LAUNCH(8) } else { PHI_LAUNCH(4) }
 #undef PHI_LAUNCH
     };

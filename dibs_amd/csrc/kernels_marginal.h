@@ -171,13 +171,19 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
                                                     size_t grad_off, int len, const float* __restrict__ kz,
                                                     const float* __restrict__ kt, int seg_is_theta, float* __restrict__ x,
                                                     float* __restrict__ v, float* __restrict__ phi_out, int m0, int Mloc,
-                                                    int M, float h, float stepsize, int rmsprop) {
+                                                    int M, float h, float stepsize, int rmsprop, int ncols, int ngroups) {
+  // 1-D grid, XCD-aware: workgroups go round-robin to the 8 XCDs, each with its own L2.  Linear id L = 8 (ngroups c_hi + g) + c_lo runs
+  // the `ngroups` particle groups of column slab c = 8 c_hi + c_lo on XCD c_lo, back to back: the slab's [z_b | grad_b] rows (64 KiB) are
+  // fetched into that L2 once instead of once per group (a (cols, groups) grid spread every slab over 4 XCDs and re-read the 5 MB of
+  // packed rows 16 times per launch: 82 MB of L2 misses).
+  const int L = blockIdx.x, c_lo = L & 7, tq = L >> 3, grp = tq % ngroups, bx = (tq / ngroups) * 8 + c_lo;
+  if (bx >= ncols) return;  // (block-uniform)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ksum = smem;                   // [M][TA]  kz + kt
   float* krep = smem + (size_t)TA * M;  // [M][TA]  (2 / h) * kernel whose gradient gives the repulsion
   float* part = krep + (size_t)TA * M;  // [4][TA][64] partial sums
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int a0 = blockIdx.y * TA;
+  const int a0 = grp * TA;
   const float c2h = 2.0f / h;
   for (int e = tid; e < TA * M; e += 256) {
     const int b = e / TA, q = e - b * TA, a = a0 + q;
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
     krep[e] = c2h * r;
   }
   __syncthreads();
-  const int i = blockIdx.x * 64 + lane;
+  const int i = bx * 64 + lane;
   const bool ok = i < len;
   float xa[TA], acc[TA];
 #pragma unroll

@@ -156,8 +156,8 @@ int dibs_engine_read_buffer(dibs_engine* e, int32_t which, void* host, int64_t n
 int64_t dibs_engine_buffer_bytes(const dibs_engine* e, int32_t which);
 int64_t dibs_engine_theta_size(const dibs_engine* e);
 
-/* per-kernel HIP-event timers.  enable=1 brackets every launch with events on the engine stream and keeps all kernels on that one stream
- * (each duration is the kernel alone on the GPU); enable=2 keeps the production schedule -- the acyclicity kernel on the engine's second
+/* per-kernel HIP-event timers.  enable=1 brackets every launch with events on the stream it is launched on and serialises the step
+ * (the main stream waits for the acyclicity kernel before it continues: each duration is the kernel alone on the GPU); enable=2 keeps the production schedule -- the acyclicity kernel on the engine's second
  * stream beside the likelihood kernels -- and times it with events on that stream (durations of overlapping kernels include the sharing). */
 int dibs_engine_set_profiling(dibs_engine* e, int32_t enable);
 int dibs_engine_get_timers(dibs_engine* e, double* total_ms, int64_t* launches, int32_t n); /* arrays of DIBS_K_COUNT */

@@ -40,8 +40,8 @@ int main() {
     const int ta = 16;
     const size_t lds = ((size_t)2 * ta * M + (size_t)4 * ta * 64) * 4;
     const float t = time_us([&] {
-      hipLaunchKernelGGL(k_phi_update<16>, dim3((D + 63) / 64, M / ta), dim3(256), lds, 0, pack, (size_t)E, (size_t)0, (size_t)D, D, kz,
-                         (const float*)nullptr, 0, x, v, phi, 0, M, M, 5.0f, 0.005f, 1);
+      hipLaunchKernelGGL(k_phi_update<16>, dim3(8 * (M / ta) * (((D + 63) / 64 + 7) / 8)), dim3(256), lds, 0, pack, (size_t)E, (size_t)0, (size_t)D, D, kz,
+                         (const float*)nullptr, 0, x, v, phi, 0, M, M, 5.0f, 0.005f, 1, (D + 63) / 64, M / ta);
     });
     printf("k_phi_update<16>  %7.2f us\n", t);
   }
@@ -49,8 +49,8 @@ int main() {
     const int ta = 4;
     const size_t lds = ((size_t)2 * ta * M + (size_t)4 * ta * 64) * 4;
     const float t = time_us([&] {
-      hipLaunchKernelGGL(k_phi_update<4>, dim3((D + 63) / 64, M / ta), dim3(256), lds, 0, pack, (size_t)E, (size_t)0, (size_t)D, D, kz,
-                         (const float*)nullptr, 0, x, v, phi, 0, M, M, 5.0f, 0.005f, 1);
+      hipLaunchKernelGGL(k_phi_update<4>, dim3(8 * (M / ta) * (((D + 63) / 64 + 7) / 8)), dim3(256), lds, 0, pack, (size_t)E, (size_t)0, (size_t)D, D, kz,
+                         (const float*)nullptr, 0, x, v, phi, 0, M, M, 5.0f, 0.005f, 1, (D + 63) / 64, M / ta);
     });
     printf("k_phi_update<4>   %7.2f us\n", t);
   }
