@@ -159,15 +159,21 @@ __device__ __forceinline__ void abf_m0(const f32x4 (&g)[ABF_NT], f32x4 (&v)[ABF_
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_acyc_bf(const float* __restrict__ scores, float* __restrict__ part, Key2 carry, int m0,
-                                                 int M_global, int d, int Sa, int cpb, float alpha, float tau, int layout,
+                                                 int M_global, int Mloc, int d, int Sa, int cpb, float alpha, float tau, int layout,
                                                  int tiny, int n_acyc_blk, LikArgs lik) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* const sb = reinterpret_cast<unsigned char*>(smem);
-  if ((int)blockIdx.x >= n_acyc_blk) {  // score-estimator role (block-uniform): see lik_weights_block
-    lik_weights_block(sb, lik, (int)blockIdx.y, (int)blockIdx.x - n_acyc_blk);
+  // XCD-aware block order (grid = (blocks per particle, particles rounded up to 8)): workgroups go round-robin to the 8 XCDs in the
+  // order of their linear id L; L = 8 (gridDim.x p_hi + u) + p_lo puts all blocks u of particle 8 p_hi + p_lo on XCD p_lo, so a
+  // particle's score matrix is fetched into one L2 instead of all eight (17 MB of L2 misses per launch otherwise).
+  const int L = blockIdx.x + gridDim.x * blockIdx.y, p_lo = L & 7, tq = L >> 3;
+  const int bx = tq % (int)gridDim.x, m = (tq / (int)gridDim.x) * 8 + p_lo;
+  if (m >= Mloc) return;  // (block-uniform)
+  if (bx >= n_acyc_blk) {  // score-estimator role (block-uniform): see lik_weights_block
+    lik_weights_block(sb, lik, m, bx - n_acyc_blk);
     return;
   }
-  const int blk = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = bx, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g4 = lane >> 4, r = lane & 15;
   const int a = 16 * wave + r, b0 = 4 * g4;  // row; first column within a tile
   const Key2 km = rng_split_row_uniform(carry, (uint32_t)M_global + 1u, (uint32_t)(m0 + m) + 1u, layout);  // dibs.py:595: key used directly

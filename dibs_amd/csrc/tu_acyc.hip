@@ -38,8 +38,8 @@ void acyc_launch(const AcycLaunch& a, const LikArgs& lik, int lik_blocks, size_t
       hipFuncSetAttribute((const void*)k_acyc_bf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       lds_set = lds;
     }
-    hipLaunchKernelGGL(k_acyc_bf, dim3(a.nblk + lik_blocks, a.Mloc), dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.d, a.Sa, a.cpb,
-                       a.alpha, a.tau, a.layout, a.tiny, a.nblk, lik);
+    hipLaunchKernelGGL(k_acyc_bf, dim3(a.nblk + lik_blocks, (a.Mloc + 7) & ~7), dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M,
+                       a.Mloc, a.d, a.Sa, a.cpb, a.alpha, a.tau, a.layout, a.tiny, a.nblk, lik);
     return;
   }
   switch ((a.d + 15) / 16) {

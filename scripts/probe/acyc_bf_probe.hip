@@ -41,7 +41,7 @@ static void run(int d, int Mloc, int Sa, float alpha, bool timing) {
   Key2 carry{123u, 456u};
   const dim3 grid(nblk, Mloc);
   hipLaunchKernelGGL((k_acyc<4, true>), grid, dim3(256), lds0, 0, ds, dp0, carry, 0, Mloc, d, Sa, cpb, alpha, 1.0f, 0, 0, nblk, LikArgs{});
-  hipLaunchKernelGGL(k_acyc_bf, grid, dim3(256), lds1, 0, ds, dp1, carry, 0, Mloc, d, Sa, cpb, alpha, 1.0f, 0, 0, nblk, LikArgs{});
+  hipLaunchKernelGGL(k_acyc_bf, dim3(nblk, (Mloc + 7) & ~7), dim3(256), lds1, 0, ds, dp1, carry, 0, Mloc, Mloc, d, Sa, cpb, alpha, 1.0f, 0, 0, nblk, LikArgs{});
   hipError_t e2 = hipDeviceSynchronize();
   hipMemcpy(p0.data(), dp0, np * 4, hipMemcpyDeviceToHost);
   hipMemcpy(p1.data(), dp1, np * 4, hipMemcpyDeviceToHost);
@@ -80,7 +80,7 @@ static void run(int d, int Mloc, int Sa, float alpha, bool timing) {
         hipEventRecord(a, 0);
         for (int it = 0; it < 10; ++it) {
           if (which == 0) hipLaunchKernelGGL((k_acyc<4, true>), grid, dim3(256), lds0, 0, ds, dp0, carry, 0, Mloc, d, Sa, cpb, alpha, 1.0f, 0, 0, nblk, LikArgs{});
-          else hipLaunchKernelGGL(k_acyc_bf, grid, dim3(256), lds1, 0, ds, dp1, carry, 0, Mloc, d, Sa, cpb, alpha, 1.0f, 0, 0, nblk, LikArgs{});
+          else hipLaunchKernelGGL(k_acyc_bf, dim3(nblk, (Mloc + 7) & ~7), dim3(256), lds1, 0, ds, dp1, carry, 0, Mloc, Mloc, d, Sa, cpb, alpha, 1.0f, 0, 0, nblk, LikArgs{});
         }
         hipEventRecord(b, 0); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b); best = fminf(best, ms / 10);
