@@ -11,6 +11,7 @@
 #define DIBS_TU_ENGINE
 #include "../../include/dibs_hip.h"
 #include "launch.h"
+#include <unordered_map>
 #include "kernels_marginal.h"
 #include "kernels_joint.h"
 #include "kernels_nn.h"
@@ -505,7 +506,15 @@ extern "C" int dibs_engine_get_state(dibs_engine* e, float* z, float* v_z, float
 // kernels that may need more than the default 64 KiB of dynamic LDS
 template <typename K>
 static void allow_lds(K kernel, size_t bytes) {
-  if (bytes > 48 * 1024) hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  // (one attribute call per kernel instantiation and size increase, not one per launch: K is a distinct function type only per
+  //  signature, so the high-water mark is kept per function pointer)
+  static std::unordered_map<const void*, size_t> granted;
+  if (bytes <= 48 * 1024) return;
+  size_t& g = granted[(const void*)kernel];
+  if (bytes > g) {
+    hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    g = bytes;
+  }
 }
 
 // ---- profiling helpers -----------------------------------------------------------------------
