@@ -163,6 +163,26 @@ def test_marginal_bge_edge_cases(c_oracle64, d, M, S, Sa, k, case):
     eng.close()
 
 
+@pytest.mark.parametrize("d,Sa", [(33, 4), (34, 2), (40, 4), (47, 2), (48, 4), (49, 2), (52, 4), (63, 2), (64, 4), (50, 3)])
+def test_acyclicity_kernel_sizes_33_to_64(c_oracle64, d, Sa):
+    """k_acyc_bf (float products on the bf16 matrix pipe with three-way split operands, kernels_acyc_bf16.h) at every tile / exponent
+    boundary of its range: d - 1 = 32 (squarings only), 63 (a "times M" step after every squaring), 47 / 48 / 49 (last row tile and
+    last column tile empty, just filled, just started).  Sa = 3 takes the f32-MFMA kernel (chains cannot be paired): same tolerance.
+    reference: graph_utils.py:8-28, dibs.py:557-601"""
+    M, S = 2, 4
+    data, _, _ = make_data(d, seed=2)
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=100, n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa)
+    st = c_oracle64.new_state(cfg, prng.PRNGKey(5))
+    eng = _engine(cfg, data.x)
+    for t in (1, 6):   # alpha = 0.05 t: soft graphs away from 1/2
+        _sync_states(eng, st)
+        dbg = c_oracle64.step(cfg, data.x, None, st, t, debug=True)
+        eng.run(t, 1)
+        assert rel_err(eng.read("W_ACYC"), dbg["w_acyc"]) < 1e-5
+        assert rel_err(eng.get_state()["z"], st["z"]) < 1e-4
+    eng.close()
+
+
 def test_score_function_baseline_and_gd_optimizer(c_oracle64):
     d, M = 8, 4
     data, _, _ = make_data(d, seed=1)
