@@ -83,7 +83,8 @@ struct dibs_engine {
   hipEvent_t ev0, ev1;
   hipStream_t stream2;      // the acyclicity kernel (needs only the edge scores) runs beside sampling -> factorisation -> weights: its bf16 MFMAs
                             // overlap with their vector work.  Same arithmetic, same results; DIBS_NO_ACYC_STREAM2 keeps one stream.
-  hipEvent_t ev_fork, ev_join;
+  hipEvent_t ev_fork, ev_join, ev_k0, ev_k1;
+  bool kmat_early;  // this step's kernel matrices were launched on the second stream (behind the acyclicity kernel)
   double t_ms[DIBS_K_COUNT];
   int64_t t_n[DIBS_K_COUNT];
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
@@ -188,6 +189,8 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
     HIP_OK(hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, prio));
     HIP_OK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&e->ev_k0, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&e->ev_k1, hipEventDisableTiming));
   }
   const size_t Ml = e->Mloc, dd = (size_t)e->d * e->d;
   HIP_OK(dalloc(&e->z, Ml * e->D));
@@ -301,6 +304,8 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (e->stream2) hipStreamDestroy(e->stream2);
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
   if (e->ev_join) hipEventDestroy(e->ev_join);
+  if (e->ev_k0) hipEventDestroy(e->ev_k0);
+  if (e->ev_k1) hipEventDestroy(e->ev_k1);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   for (auto& pe : e->pending) {
@@ -572,6 +577,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
   carry = next_carry(e, carry);
   e->key = carry;
 
+  e->kmat_early = false;
   {
     KTimer tm(e, DIBS_K_EDGE);
     const size_t lds = (size_t)2 * e->dpad * e->ldk * 4;
@@ -598,6 +604,31 @@ static int step_local(dibs_engine* e, int t, float* pack) {
                         e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny};
     acyc_launch(al, lik, 0, 0);
   }
+  // Single rank: the kernel matrices need only z (and theta), which are final when the step starts.  For the joint models, and for the
+  // marginal model once the matrix is large against the sampling work (M D > 4 S d^2), they follow the acyclicity kernel on the second
+  // stream, which otherwise idles until the likelihood chain on the main stream is done; the join before k_wtotal covers them.
+  // Measured: config 3 (joint, 128 particles) 1 400 -> 1 453 steps/s, config 4 (1 024 particles) 329 -> 395.  At the headline size the
+  // latent matrix stays inside the k_bge_sample launch (KmatFuse: 8 us of that kernel's 70; on the second stream 3 999 -> 3 902 steps/s,
+  // and ahead of the acyclicity kernel it delays that kernel).
+  const bool kmat_on_s2 = c.joint || (long)e->M * e->D > 4L * e->S * e->d * e->d;
+  if (fork && kmat_on_s2 && e->Mloc == e->M && !getenv("DIBS_NO_KMAT_EARLY")) {
+    if (join_now) {  // per-kernel timing: one kernel at a time
+      hipEventRecord(e->ev_k1, e->stream2);
+      hipStreamWaitEvent(e->stream, e->ev_k1, 0);
+      hipEventRecord(e->ev_k0, e->stream);
+      hipStreamWaitEvent(e->stream2, e->ev_k0, 0);
+    }
+    KTimer tm(e, DIBS_K_KMAT, e->stream2);
+    auto kmat_lds = [](size_t len) { return (size_t)(((len < KMAT_CH ? len : (size_t)KMAT_CH) + 3) & ~(size_t)3) * 4; };
+    allow_lds(k_kmat, kmat_lds(e->D > e->P ? e->D : e->P));
+    const dim3 kg(e->Mloc, (e->M + KMAT_BT - 1) / KMAT_BT);
+    hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->D), e->stream2, e->z, (size_t)e->D, (size_t)0, (int)e->D, e->kz, 0, e->M,
+                       (float)c.scale_latent, (float)c.h_latent, 1);
+    if (c.joint)
+      hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->P), e->stream2, e->theta, (size_t)e->P, (size_t)0, (int)e->P, e->kt, 0, e->M,
+                         (float)c.scale_theta, (float)c.h_theta, 1);
+    e->kmat_early = true;
+  }
   if (fork) hipEventRecord(e->ev_join, e->stream2);
   if (fork && join_now) hipStreamWaitEvent(e->stream, e->ev_join, 0);
   if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_REPARAM) {
@@ -612,7 +643,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
       KmatFuse kf{nullptr, nullptr, 0, 0, 0, 0.f, 0.f};
       e->kmat_fused = false;
       // single rank, vector fits one LDS chunk: the latent kernel matrix rides along (see KmatFuse)
-      if (e->Mloc == e->M && e->D <= KMAT_CH && (size_t)e->D * 4 + 64 <= 80 * 1024 && !getenv("DIBS_NO_KMAT_FUSE")) {
+      if (!e->kmat_early && e->Mloc == e->M && e->D <= KMAT_CH && (size_t)e->D * 4 + 64 <= 80 * 1024 && !getenv("DIBS_NO_KMAT_FUSE")) {
         kf = KmatFuse{e->z, e->kz, (int)e->D, e->M, (e->d + 3) / 4, (float)c.scale_latent, (float)c.h_latent};
         e->kmat_fused = true;
       }
@@ -674,7 +705,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     }
   }
   if (fork) {
-    hipStreamWaitEvent(e->stream, e->ev_join, 0);
+    hipStreamWaitEvent(e->stream, e->ev_join, 0);  // (covers the kernel matrices: they precede the acyclicity kernel on that stream)
   } else {
     KTimer tm(e, DIBS_K_ACYC);
     const AcycLaunch al{e->stream, e->scores, e->acyc_part, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
@@ -707,7 +738,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
 static int step_update(dibs_engine* e, int t, const float* pack) {
   (void)t;
   const dibs_config& c = e->cfg;
-  if (!e->kmat_fused || c.joint) {
+  if (!e->kmat_early && (!e->kmat_fused || c.joint)) {
     KTimer tm(e, DIBS_K_KMAT);
     const int ksym = e->Mloc == e->M;  // single rank: the slab is the whole (symmetric) matrix
     auto kmat_lds = [](size_t len) { return (size_t)(((len < KMAT_CH ? len : (size_t)KMAT_CH) + 3) & ~(size_t)3) * 4; };
