@@ -186,7 +186,14 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
     // measured at the headline size: serial 3 906 steps/s; second stream at least / normal / greatest priority 3 906 / 3 964 / 4 001
     const char* pr = getenv("DIBS_ACYC_PRIO");
     const int prio = pr ? (atoi(pr) > 0 ? hi : (atoi(pr) < 0 ? lo : (lo + hi) / 2)) : hi;
-    HIP_OK(hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, prio));
+    // (an optimisation only: without it every kernel goes to the engine stream)
+    if (hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, prio) != hipSuccess &&
+        hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess) {
+      e->stream2 = nullptr;
+      (void)hipGetLastError();
+    }
+  }
+  if (e->stream2) {
     HIP_OK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&e->ev_k0, hipEventDisableTiming));

@@ -27,7 +27,8 @@
 // from the soft graph the thread drew itself -- M needs no image after the first squaring.
 // The last power is written as float [row][68] into the free image and read back transposed for
 //   out[a][b] += (M^{d-1})[b][a] * tau * alpha * g (1 - g).
-// grid = (ceil(Sa / 2 / cpb) [+ score-estimator blocks], Mloc), block = 256, dynamic LDS = 2 * 24576
+// grid = (ceil(Sa / 2 / cpb) [+ score-estimator blocks], Mloc rounded up to 8; re-indexed XCD-aware inside), block = 256,
+// dynamic LDS = 2 * 24576
 //
 // Where the time goes at the headline size (2 048 blocks, 94 us; counters of scripts/probe/acyc_bf_probe.hip): 5.5 M MFMAs = 86 k cycles
 // per SIMD, 26 M other vector instructions (a third each: Threefry draws, operand splits, the rest) = ~102 k cycles; SQ_ACTIVE_INST_ANY
