@@ -9,7 +9,10 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 
 Pinning status: the reference has no tests / golden vectors and cannot be imported here (needs jax),
 so the floating-point part is "parity unpinned" at the JAX boundary; the PRNG bit-streams are pinned
-by public known-answer values (oracle/prng.py, tests/test_prng.py).
+by public known-answer values (oracle/prng.py, tests/test_prng.py), and the model formulas restated
+here are pinned against independent ground truth in tests/test_known_answers.py (BGe: normal-Wishart
+evidence in closed form via scipy, score equivalence; LinearGaussian: scipy.stats; acyclicity
+constraint, graph priors, kernels, RMSprop: hand-computed values).
 
 Every function cites the reference file:line it follows (paths relative to /root/reference).
 """

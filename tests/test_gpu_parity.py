@@ -464,6 +464,38 @@ def test_score_graphs_and_mixture(c_oracle64):
     assert np.isfinite(neg_ave_log_likelihood(dist=mixj, eltwise_log_likelihood=jd.eltwise_log_likelihood_observ, x=dataj.x_ho))
 
 
+@pytest.mark.parametrize("d", [3, 8, 20, 50, 70])
+def test_device_bge_scores_against_closed_forms(d):
+    """The device's hard-graph BGe scorer against ground truth that does not involve the oracle (tests/test_known_answers.py pins the oracle
+    the same way): a complete DAG in any variable order scores the normal-Wishart evidence of the data (Geiger & Heckerman 2002 with the
+    constants of linearGaussian.py:63-118), evaluated here in double with scipy; Markov-equivalent graphs score the same."""
+    import math
+    from scipy import special
+    from dibs_amd.inference.scoring import score_graphs
+    data, _, lm = make_data(d, seed=4)
+    x = np.asarray(data.x, np.float64)
+    n, am, al = x.shape[0], 1.0, d + 2.0
+    t = am * (al - d - 1) / (am + 1)
+    xbar = x.mean(0, keepdims=True)
+    R = t * np.eye(d) + (x - xbar).T @ (x - xbar) + n * am / (n + am) * xbar.T @ xbar
+    want = (-0.5 * n * d * math.log(math.pi) + 0.5 * d * math.log(am / (am + n)) + special.multigammaln(0.5 * (al + n), d)
+            - special.multigammaln(0.5 * al, d) + 0.5 * al * d * math.log(t) - 0.5 * (al + n) * np.linalg.slogdet(R)[1])
+    rng = np.random.default_rng(d)
+    gs = []
+    for _ in range(4):
+        order = rng.permutation(d)
+        g = np.zeros((d, d), np.int32)
+        for a in range(d):
+            g[order[a], order[a + 1:]] = 1
+        gs.append(g)
+    chain = np.zeros((d, d), np.int32)
+    chain[np.arange(d - 1), np.arange(1, d)] = 1
+    gs += [chain, chain.T.copy()]                       # a chain and its reversal are Markov equivalent
+    got = np.asarray(score_graphs(lm, np.stack(gs), None, data.x, None), np.float64)
+    assert np.abs(got[:4] - want).max() < 2e-5 * abs(want), (got[:4], want)
+    assert abs(got[4] - got[5]) < 2e-5 * abs(got[4])
+
+
 @pytest.mark.parametrize("d,M,S,Sa,H,act,bias,est,interv,steps,N", [
     (5, 3, 16, 4, 4, "relu", True, "reparam", True, (1, 2), 60),
     (6, 3, 16, 4, 3, "tanh", False, "score", False, (1, 2), 60),
