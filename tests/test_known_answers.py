@@ -168,3 +168,90 @@ def test_svgd_kernels_and_rmsprop_known_values():
     x, v = O.opt_update(cfg, _xt([2.0, -4.0]), _xt([1.0, 1.0]), _xt([0.0, 1.0]))
     assert np.allclose(np.asarray(v), [0.4, 0.9 + 1.6], rtol=1e-15)
     assert np.allclose(np.asarray(x), [1.0 - 0.005 * 2.0 / math.sqrt(0.4 + 1e-8), 1.0 + 0.005 * 4.0 / math.sqrt(2.5 + 1e-8)], rtol=1e-15)
+
+
+def test_svgd_transform_is_liu_wang_2016():
+    """One SVGD step with plain gradient descent moves every particle by  + stepsize * phi*(x_a),
+        phi*(x_a) = 1/n sum_b [ k(x_b, x_a) grad log p(x_b) + grad_{x_b} k(x_b, x_a) ]        (Liu & Wang 2016, eq. 8)
+    with the RBF kernel's gradient in closed form, -2 / h (x_b - x_a) k.  The reference hands -phi* to an optimizer that subtracts
+    (svgd.py:194-224, 265): sign, 1/n scale and the kernel's argument order are what this pins."""
+    rng = np.random.default_rng(7)
+    M, d, k = 3, 2, 2
+    cfg = O.Config()
+    cfg.joint, cfg.scale_latent, cfg.h_latent, cfg.optimizer, cfg.stepsize = False, 1.5, 4.0, "gd", 0.01
+    z = rng.normal(size=(M, d, k, 2))
+    score = rng.normal(size=(M, d, k, 2))          # any "grad log p" per particle
+    zt = _xt(z)
+    kxx = O.kernel_mat(cfg, zt, None)
+    phi_z, _ = O.svgd_phi(cfg, zt, None, kxx, _xt(score), None)
+    z_new, _ = O.opt_update(cfg, phi_z, zt, torch.zeros_like(zt))
+    want = z.copy()
+    for a in range(M):
+        acc = np.zeros_like(z[0])
+        for b in range(M):
+            kba = 1.5 * math.exp(-((z[b] - z[a]) ** 2).sum() / 4.0)
+            acc += kba * score[b] + (-2.0 / 4.0) * (z[b] - z[a]) * kba
+        want[a] += 0.01 * acc / M
+    assert np.allclose(np.asarray(z_new), want, rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("act,bias", [("relu", True), ("tanh", False), ("leakyrelu", True), ("sigmoid", True)])
+def test_dense_nonlinear_gaussian_log_joint_against_numpy(act, bias):
+    """Per-node MLP on the parent-masked inputs (nonlinearGaussian.py:35-81, 248-326): node j sees x o G[:, j]; Gaussian prior on every
+    leaf, the first-layer weights counted only for actual parents; Gaussian likelihood on non-intervened entries."""
+    rng = np.random.default_rng(11)
+    d, n, hid = 4, 6, (5, 3)
+    g = np.triu((rng.random((d, d)) < 0.6).astype(float), 1)
+    x = rng.normal(size=(n, d))
+    interv = (rng.random((n, d)) < 0.25).astype(float)
+    sizes = (d,) + hid + (1,)
+    Ws = [rng.normal(size=(d, sizes[i], sizes[i + 1])) for i in range(len(sizes) - 1)]
+    bs = [rng.normal(size=(d, sizes[i + 1])) for i in range(len(sizes) - 1)]
+    f = {"relu": lambda v: np.maximum(v, 0), "tanh": np.tanh, "sigmoid": special.expit, "leakyrelu": lambda v: np.where(v > 0, v, 0.01 * v)}[act]
+    want = 0.0
+    for j in range(d):
+        h = x * g[:, j][None, :]
+        for li, w in enumerate(Ws):
+            h = h @ w[j] + (bs[li][j] if bias else 0.0)
+            if li < len(Ws) - 1:
+                h = f(h)
+        want += ((1 - interv[:, j]) * stats.norm.logpdf(x[:, j], h[:, 0], math.sqrt(0.2))).sum()
+        want += (g[:, j][:, None] * stats.norm.logpdf(Ws[0][j], 0.0, 1.3)).sum()
+        want += sum(stats.norm.logpdf(w[j], 0.0, 1.3).sum() for w in Ws[1:])
+        if bias:
+            want += sum(stats.norm.logpdf(b[j], 0.0, 1.3).sum() for b in bs)
+    hp = O.DenseNNParams(hidden_layers=hid, obs_noise=0.2, sig_param=1.3, activation=act, bias=bias)
+    theta = []
+    for w, b in zip(Ws, bs):
+        theta.append(_xt(w))
+        if bias:
+            theta.append(_xt(b))
+    got = float(O.densenn_log_joint(_xt(g), theta, _xt(x), _xt(interv), hp))
+    assert abs(got - want) < 1e-10 * abs(want)
+
+
+def test_score_function_estimator_against_exact_enumeration():
+    """dibs.py:325-391 estimates  grad_Z log E_{p(G | Z)}[p(D | G)]  by Monte Carlo.  For three variables the expectation is a sum over
+    the 64 graphs without self-loops: the estimator (4 000 samples) has to agree with autograd of the enumerated sum within its
+    Monte-Carlo error.  Pins the estimator (ratio form, signs, the alpha inside p(G | Z)) to the quantity it is defined to estimate."""
+    from oracle import prng
+    d, k, t = 3, 2, 8.0
+    x = _data(15, d, seed=3)
+    rng = np.random.default_rng(1)
+    z = _xt(rng.normal(size=(d, k, 2)) * 0.7)
+    cfg = O.Config()
+    cfg.n_grad_mc_samples, cfg.alpha_linear = 4000, 0.05
+    xt, interv = _xt(x), torch.zeros((15, d), dtype=torch.float64)
+    pairs = [(i, j) for i in range(d) for j in range(d) if i != j]
+    zz = z.clone().requires_grad_(True)
+    terms = []
+    for bits in itertools.product((0.0, 1.0), repeat=len(pairs)):
+        g = torch.zeros((d, d), dtype=torch.float64)
+        for (i, j), b in zip(pairs, bits):
+            g[i, j] = b
+        terms.append(O.latent_log_prob(g, zz, cfg.alpha_linear * t) + O.bge_log_marginal(g, xt, interv, cfg.bge).detach())
+    exact = torch.autograd.grad(torch.logsumexp(torch.stack(terms), 0), zz)[0].numpy().reshape(-1)
+    est, _, _ = O.grad_z_likelihood_score_function(cfg, z, None, torch.zeros((), dtype=torch.float64), t, prng.PRNGKey(3), xt, interv)
+    est = est.numpy().reshape(-1)
+    cos = float(est @ exact / (np.linalg.norm(est) * np.linalg.norm(exact)))
+    assert cos > 0.97 and abs(np.linalg.norm(est) / np.linalg.norm(exact) - 1.0) < 0.2, (cos, est, exact)
