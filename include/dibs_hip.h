@@ -48,7 +48,8 @@ typedef struct dibs_config {
   int32_t optimizer;        /* DIBS_OPT_*                                           svgd.py:117-122   */
   int32_t rng_layout;       /* DIBS_RNG_*  (jax_threefry_partitionable)                              */
   int32_t logistic_minval_tiny; /* 0: uniform minval = finfo.eps (jax default), 1: finfo.tiny        */
-  int32_t has_interventions;/* 0: interv_mask all zero                              svgd.py:86-87     */
+  int32_t has_interventions;/* advisory: 0 = interv_mask all zero (the engine derives everything from the mask passed to
+                               dibs_engine_set_data; the field only records the caller's view)          svgd.py:86-87     */
   int32_t nn_n_hidden;      /* DenseNonlinearGaussian: len(hidden_layers)           nonlinearGaussian.py:105 */
   int32_t nn_hidden[DIBS_MAX_HIDDEN_LAYERS];
   int32_t nn_activation;    /* DIBS_ACT_*                                                            */
