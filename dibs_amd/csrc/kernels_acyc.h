@@ -9,6 +9,18 @@
 //     resident in LDS.  Each block handles CPB chains of one particle and writes their SUM.
 //     reference: graph_utils.py:8-28, dibs.py:121-140, 557-601
 // grid = (ceil(Sa / CPB), Mloc), block = 256; dynamic LDS = 3 * DP * LD * 4, DP = 16 NT, LD = DP + 2
+//
+// Serves d <= 32 and 65 <= d <= 112 (and unpaired PRNG layouts); 33 <= d <= 64 runs on kernels_acyc_bf16.h.  At the headline size
+// (d = 50, measured while this was the production kernel): 5.96 M MFMAs = 186 k MFMA cycles per SIMD + 20.1 M other vector
+// instructions = 78 k cycles of the ~350 k the launch takes (141.5 us, 32 % of the FP32 peak; f32 MFMAs do not overlap with the
+// vector work of co-resident waves).  Measured on the box and reverted:
+//  * border strips on v_mfma_f32_4x4x1_16b_f32 (3 x 3 core tiles on three waves, rows / columns 48-51 as 16 independent 4 x 4 blocks
+//    per instruction on the fourth wave): MFMA cycles per product 6 656 -> 4 576, correct, but 148 us -- the border wave has 8 issue
+//    cycles per k-step to hide four LDS operand loads behind; with deeper prefetch 198-222 VGPRs, two blocks per CU, 163-173 us;
+//  * unpadded 52-row buffers with an XOR swizzle (39 KiB per block, four blocks per CU, the 2 048 pair-units in exactly two rounds):
+//    148 us -- the launch is bound by issue per SIMD, not by the tail round;
+//  * A fragments as one ds_read_b128 per four k-steps (conflict-free): 148 us -- LDS is not the limiter either;
+//  * a second stream beside the BGe kernels: -1 % (it pays with the bf16 kernel, whose MFMAs do overlap with vector work).
 // ------------------------------------------------------------------------------------------------
 // Matrices live in LDS as [DP rows][LD] with the COLUMNS PERMUTED: logical column c sits at pc(c) = (c & 15) * NT + (c >> 4),
 // so the NT values {c, c+16, c+32, ...} that one lane needs for the B fragments of a k-step (and produces in the C tile)
