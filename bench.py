@@ -153,7 +153,7 @@ def main():
         # SURVEY.md 8(d) algorithmic flop counts per step (= per launch: each kernel is launched once per step)
         acyc_flops = M * SA_MC * binary_powering_matmuls(D_VARS - 1) * 2 * D_VARS ** 3   # F_acyc
         dense_bge = M * S_MC * D_VARS * 2 * D_VARS ** 3 / 3.0                            # F_lik(BGe), reference's dense count
-        names = {"acyc": "k_acyc_bf", "bge_nodes": "k_bge_sample<4, true>", "bge_big": "k_bge_chol<true, false>"}
+        names = {"acyc": "k_acyc_bf<true>", "bge_nodes": "k_bge_sample<4, true>", "bge_big": "k_bge_chol<true, false>"}
         roof = {"kernel": dom, "rocprof_kernel": names.get(dom, "k_" + dom), "avg_launch_us": avg_s * 1e6, "launches": dom_n,
                 "share_of_step": dom_ms / total_ms, "unit": "TFLOP/s", "peak": PEAK_F32_TFLOPS, "traffic": None}
         if dom == "acyc":

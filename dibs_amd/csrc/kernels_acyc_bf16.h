@@ -105,46 +105,52 @@ __device__ __forceinline__ abf_bf16x8 abf_tr_pair(const unsigned char* p) {
   return __builtin_bit_cast(abf_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-// B fragments (3 pieces) of the two tiles tp, tp + 1 for k-step ks
-__device__ __forceinline__ void abf_load_b(abf_bf16x8 (&b)[2][3], const unsigned char* img, int rd_off, int grp) {
-  const int ks = grp >> 1, tp = (grp & 1) * 2;
+// One group = k-step ks of the tile pair (tp, tp + 1): 6 fragment reads and 6 MFMAs per tile.  NU = 1: only tile tp (the other one lies
+// beyond column d - 1).  Small terms first; the two tiles alternate so that consecutive MFMAs never share an accumulator.
+// Accuracy against a double reference at d = 50 (scripts/probe/acyc_bf_probe.hip): 2.5e-6 of max |out|, the f32-MFMA kernel 3e-7.
+// The difference is not the split (x - h - m - l <= 2^-27 x) nor the accumulation order (all ten small products of a tile first,
+// Ah Bh last: same 2.5e-6) -- the 32-term dot product inside one bf16 MFMA truncates, and with all entries >= 0 that is a bias
+// of ~2^-24 per product level which the powering multiplies by the exponent.
+template <int NU>
+__device__ __forceinline__ void abf_group(f32x4 (&acc)[ABF_NT], const AbfFrag& A, const unsigned char* img, int rd_off, int ks, int tp) {
+  abf_bf16x8 b[NU][3];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < NU; ++u)
 #pragma unroll
     for (int p = 0; p < 3; ++p) b[u][p] = abf_tr_pair(img + rd_off + p * ABF_PIECE_BYTES + (tp + u) * ABF_TILE_BYTES + ks * 32 * 32);
+  const abf_bf16x8 ah = __builtin_bit_cast(abf_bf16x8, A.a[ks][0]), am = __builtin_bit_cast(abf_bf16x8, A.a[ks][1]),
+                   al = __builtin_bit_cast(abf_bf16x8, A.a[ks][2]);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    if (ks == 0) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u][2], ah, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    else acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u][2], ah, acc[tp + u], 0, 0, 0);
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u][0], al, acc[tp + u], 0, 0, 0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u][1], am, acc[tp + u], 0, 0, 0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u][1], ah, acc[tp + u], 0, 0, 0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u][0], am, acc[tp + u], 0, 0, 0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u][0], ah, acc[tp + u], 0, 0, 0);
 }
-// acc[tj] (row r of the wave's rows, columns 16 tj + 4 g + i) = (rows of A) * (matrix behind the image)
-// four groups (k-step, tile pair) of 12 fragment reads + 12 MFMAs.  (Loading group n + 1 ahead of group n's MFMAs changed nothing
-// at three waves per SIMD -- the other waves cover the LDS latency -- and costs 24 registers.)
+// acc[tj] (row r of the wave's rows, columns 16 tj + 4 g + i) = (rows of A) * (matrix behind the image); four_tiles: d > 48, else the
+// fourth column tile is all padding and stays zero.  (Loading the next group's fragments ahead of the current MFMAs changed nothing at
+// three waves per SIMD -- the other waves cover the LDS latency -- and costs 24 registers.)
+template <bool FOUR>
 __device__ __forceinline__ void abf_matmul(f32x4 (&acc)[ABF_NT], const AbfFrag& A, const unsigned char* img, int rd_off) {
-  abf_bf16x8 b[2][2][3];  // (indexed by group parity; only one half is live at a time)
-  abf_load_b(b[0], img, rd_off, 0);
-#pragma unroll
-  for (int grp = 0; grp < 4; ++grp) {
-    const int ks = grp >> 1, tp = (grp & 1) * 2, cb = grp & 1;
-    if (grp > 0) abf_load_b(b[cb], img, rd_off, grp);
-    const abf_bf16x8 ah = __builtin_bit_cast(abf_bf16x8, A.a[ks][0]), am = __builtin_bit_cast(abf_bf16x8, A.a[ks][1]),
-                     al = __builtin_bit_cast(abf_bf16x8, A.a[ks][2]);
-    // small terms first; the two tiles alternate so that consecutive MFMAs never share an accumulator.
-    // Accuracy against a double reference at d = 50 (scripts/probe/acyc_bf_probe.hip): 2.5e-6 of max |out|, the f32-MFMA kernel 3e-7.
-    // The difference is not the split (x - h - m - l <= 2^-27 x) nor the accumulation order (all ten small products of a tile first,
-    // Ah Bh last: same 2.5e-6) -- the 32-term dot product inside one bf16 MFMA truncates, and with all entries >= 0 that is a bias
-    // of ~2^-24 per product level which the powering multiplies by the exponent.
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (ks == 0) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[cb][u][2], ah, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      else acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[cb][u][2], ah, acc[tp + u], 0, 0, 0);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[cb][u][0], al, acc[tp + u], 0, 0, 0);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[cb][u][1], am, acc[tp + u], 0, 0, 0);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[cb][u][1], ah, acc[tp + u], 0, 0, 0);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[cb][u][0], am, acc[tp + u], 0, 0, 0);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[cb][u][0], ah, acc[tp + u], 0, 0, 0);
+  abf_group<2>(acc, A, img, rd_off, 0, 0);
+  if constexpr (FOUR) {
+    abf_group<2>(acc, A, img, rd_off, 0, 2);
+    abf_group<2>(acc, A, img, rd_off, 1, 0);
+    abf_group<2>(acc, A, img, rd_off, 1, 2);
+  } else {
+    abf_group<1>(acc, A, img, rd_off, 0, 2);
+    abf_group<2>(acc, A, img, rd_off, 1, 0);
+    abf_group<1>(acc, A, img, rd_off, 1, 2);
+    acc[3] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 }
 
@@ -159,6 +165,8 @@ __device__ __forceinline__ void abf_m0(const f32x4 (&g)[ABF_NT], f32x4 (&v)[ABF_
     }
 }
 
+// FOUR: d > 48 (all four row / column tiles in use); the d <= 48 instantiation skips the fourth wave's products and the fourth column tile
+template <bool FOUR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_acyc_bf(const float* __restrict__ scores, float* __restrict__ part, Key2 carry, int m0,
                                                  int M_global, int Mloc, int d, int Sa, int cpb, float alpha, float tau, int layout,
                                                  int tiny, int n_acyc_blk, LikArgs lik) {
@@ -190,6 +198,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // The 8-byte chunk c of image row k sits at position (c + (k >> 2)) % 4 of the row: the 16 lanes of one ds_write_b64 group (16 rows,
   // one chunk each) then cover all 32 banks instead of 8 (rows are 8 banks long), and a reading group still sees its 4 x 16 block as
   // 128 contiguous bytes.
+  // d <= 48: the fourth wave's rows (48..63) are all padding -- it skips products and splits (its image rows are zeroed once below and
+  // nothing overwrites them) -- and the fourth column tile is skipped by every wave: 9 of 16 tile products instead of 16.
+  const bool row_active = FOUR || 16 * wave < d;
   const int wr_off = a * 32 + ((g4 + (r >> 2)) & 3) * 8;
   const int rd_off = (4 * g4 + (r >> 2)) * 32 + (((r & 3) + g4) & 3) * 8;
   float* const po = part + ((size_t)m * n_acyc_blk + blk) * dd + (size_t)a * d;
@@ -242,28 +253,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       abf_make_frag(acc, A);
       int cur = 0;  // image holding the running power
       abf_store_image(sb, wr_off, A);
+      if (!FOUR && !row_active) abf_store_image(sb + ABF_IMG_BYTES, wr_off, A);  // (all zero; the previous chain's float copy may have covered these rows)
       __syncthreads();
       // left-to-right binary powering of e = d - 1 (>= 32 here)
       const int ex = d - 1;
       const int hb = 31 - __builtin_clz((unsigned)ex);
       for (int bit = hb - 1; bit >= 0; --bit) {
         const bool mult = (ex >> bit) & 1, last_sq = bit == 0 && !mult;
-        abf_matmul(acc, A, sb + cur, rd_off);  // P <- P P
+        if (row_active) abf_matmul<FOUR>(acc, A, sb + cur, rd_off);  // P <- P P
         cur ^= ABF_IMG_BYTES;
         if (!last_sq) {
-          abf_make_frag(acc, A);
-          abf_store_image(sb + cur, wr_off, A);
+          if (row_active) {
+            abf_make_frag(acc, A);
+            abf_store_image(sb + cur, wr_off, A);
+          }
           __syncthreads();
           if (mult) {  // P <- M P
             f32x4 mv[ABF_NT];
             AbfFrag A0;
             abf_m0(g, mv, a, b0, d, inv_d);
             abf_make_frag(mv, A0);
-            abf_matmul(acc, A0, sb + cur, rd_off);
+            if (row_active) abf_matmul<FOUR>(acc, A0, sb + cur, rd_off);
             cur ^= ABF_IMG_BYTES;
             if (bit != 0) {
-              abf_make_frag(acc, A);
-              abf_store_image(sb + cur, wr_off, A);
+              if (row_active) {
+                abf_make_frag(acc, A);
+                abf_store_image(sb + cur, wr_off, A);
+              }
               __syncthreads();
             }
           }

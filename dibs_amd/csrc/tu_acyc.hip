@@ -33,13 +33,24 @@ void acyc_launch(const AcycLaunch& a, const LikArgs& lik, int lik_blocks, size_t
   if (acyc_use_bf16(a)) {
     size_t lds = 2 * ABF_IMG_BYTES;
     if (lik_blocks && lik_lds > lds) lds = lik_lds;
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-      hipFuncSetAttribute((const void*)k_acyc_bf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      lds_set = lds;
+    const dim3 grid(a.nblk + lik_blocks, (a.Mloc + 7) & ~7);
+    if (a.d > 48) {
+      static size_t lds_set = 0;
+      if (lds > lds_set) {
+        hipFuncSetAttribute((const void*)k_acyc_bf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = lds;
+      }
+      hipLaunchKernelGGL(k_acyc_bf<true>, grid, dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.Mloc, a.d, a.Sa, a.cpb, a.alpha,
+                         a.tau, a.layout, a.tiny, a.nblk, lik);
+    } else {
+      static size_t lds_set = 0;
+      if (lds > lds_set) {
+        hipFuncSetAttribute((const void*)k_acyc_bf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = lds;
+      }
+      hipLaunchKernelGGL(k_acyc_bf<false>, grid, dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.Mloc, a.d, a.Sa, a.cpb, a.alpha,
+                         a.tau, a.layout, a.tiny, a.nblk, lik);
     }
-    hipLaunchKernelGGL(k_acyc_bf, dim3(a.nblk + lik_blocks, (a.Mloc + 7) & ~7), dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M,
-                       a.Mloc, a.d, a.Sa, a.cpb, a.alpha, a.tau, a.layout, a.tiny, a.nblk, lik);
     return;
   }
   switch ((a.d + 15) / 16) {

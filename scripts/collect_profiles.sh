@@ -32,7 +32,7 @@ def parse(path, key):
         if key in d: out[name.strip()] = float(d[key])
     return out
 f, w = parse(f"gpurun_out/{tag}_pmc_fetch.txt", "FETCH_SIZE"), parse(f"gpurun_out/{tag}_pmc_write.txt", "WRITE_SIZE")
-names = {"k_acyc_bf": "acyc", "void k_bge_sample<4, true>": "bge_nodes", "void k_bge_chol<true, false>": "bge_big", "k_lik_weights_score": "lik_weights",
+names = {"void k_acyc_bf<true>": "acyc", "void k_bge_sample<4, true>": "bge_nodes", "void k_bge_chol<true, false>": "bge_big", "k_lik_weights_score": "lik_weights",
          "k_kmat": "kmat", "void k_phi_update<8>": "phi_update", "k_edge_scores": "edge", "k_zgrad": "zgrad", "k_wtotal": "wtotal"}
 res = {}
 for k, short in names.items():

@@ -37,11 +37,13 @@ static void run(int d, int Mloc, int Sa, float alpha, bool timing) {
   constexpr int DP = 64, LD = DP + 4;
   const size_t lds0 = (3 * DP + 1) * LD * 4, lds1 = 2 * ABF_IMG_BYTES;
   hipFuncSetAttribute((const void*)k_acyc<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
-  hipFuncSetAttribute((const void*)k_acyc_bf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+  hipFuncSetAttribute((const void*)k_acyc_bf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+  hipFuncSetAttribute((const void*)k_acyc_bf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
   Key2 carry{123u, 456u};
   const dim3 grid(nblk, Mloc);
   hipLaunchKernelGGL((k_acyc<4, true>), grid, dim3(256), lds0, 0, ds, dp0, carry, 0, Mloc, d, Sa, cpb, alpha, 1.0f, 0, 0, nblk, LikArgs{});
-  hipLaunchKernelGGL(k_acyc_bf, dim3(nblk, (Mloc + 7) & ~7), dim3(256), lds1, 0, ds, dp1, carry, 0, Mloc, Mloc, d, Sa, cpb, alpha, 1.0f, 0, 0, nblk, LikArgs{});
+  if (d > 48) hipLaunchKernelGGL(k_acyc_bf<true>, dim3(nblk, (Mloc + 7) & ~7), dim3(256), lds1, 0, ds, dp1, carry, 0, Mloc, Mloc, d, Sa, cpb, alpha, 1.0f, 0, 0, nblk, LikArgs{});
+  else hipLaunchKernelGGL(k_acyc_bf<false>, dim3(nblk, (Mloc + 7) & ~7), dim3(256), lds1, 0, ds, dp1, carry, 0, Mloc, Mloc, d, Sa, cpb, alpha, 1.0f, 0, 0, nblk, LikArgs{});
   hipError_t e2 = hipDeviceSynchronize();
   hipMemcpy(p0.data(), dp0, np * 4, hipMemcpyDeviceToHost);
   hipMemcpy(p1.data(), dp1, np * 4, hipMemcpyDeviceToHost);
@@ -80,7 +82,8 @@ static void run(int d, int Mloc, int Sa, float alpha, bool timing) {
         hipEventRecord(a, 0);
         for (int it = 0; it < 10; ++it) {
           if (which == 0) hipLaunchKernelGGL((k_acyc<4, true>), grid, dim3(256), lds0, 0, ds, dp0, carry, 0, Mloc, d, Sa, cpb, alpha, 1.0f, 0, 0, nblk, LikArgs{});
-          else hipLaunchKernelGGL(k_acyc_bf, dim3(nblk, (Mloc + 7) & ~7), dim3(256), lds1, 0, ds, dp1, carry, 0, Mloc, Mloc, d, Sa, cpb, alpha, 1.0f, 0, 0, nblk, LikArgs{});
+          else if (d > 48) hipLaunchKernelGGL(k_acyc_bf<true>, dim3(nblk, (Mloc + 7) & ~7), dim3(256), lds1, 0, ds, dp1, carry, 0, Mloc, Mloc, d, Sa, cpb, alpha, 1.0f, 0, 0, nblk, LikArgs{});
+  else hipLaunchKernelGGL(k_acyc_bf<false>, dim3(nblk, (Mloc + 7) & ~7), dim3(256), lds1, 0, ds, dp1, carry, 0, Mloc, Mloc, d, Sa, cpb, alpha, 1.0f, 0, 0, nblk, LikArgs{});
         }
         hipEventRecord(b, 0); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b); best = fminf(best, ms / 10);
