@@ -612,14 +612,15 @@ def test_densenn_sample_and_scoring(c_oracle64):
     assert abs(np.exp(mix.logp).sum() - 1) < 1e-6
 
 
-@pytest.mark.parametrize("joint", [False, True])
-def test_sharded_engines_match_single_rank(joint):
+@pytest.mark.parametrize("joint,d", [(False, 20), (True, 20), (False, 50), (False, 40), (True, 50)])
+def test_sharded_engines_match_single_rank(joint, d):
     """The N > 1 path of bench.py / dibs_amd.distributed on ONE GPU: engines for rank 0..R-1 of R in one process, the
     all-gather replaced by a device-side concat.  Must be bit-identical to the single-rank engine (PRNG rows are global,
-    phi sums over b in global order)."""
+    phi sums over b in global order).  d = 50 / 40: both instantiations of the split-bf16 acyclicity kernel, on the ranks with the score
+    estimator's blocks riding along in its launch and on its own stream for the single engine."""
     import torch
     from dibs_amd.engine import Engine
-    d, M, R, steps = 20, 16, 4, 5
+    M, R, steps = 16, 4, 5
     data, _, _ = make_data(d, seed=3, joint=joint)
     kw = dict(joint=True, likelihood="lingauss") if joint else {}
     cfg1 = make_config(n_vars=d, n_particles=M, n_observations=100, n_grad_mc_samples=32, n_acyclicity_mc_samples=8, **kw)
