@@ -208,8 +208,10 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
                 const float u0 = rng_uniform(y0, ulo, 1.0f), u1 = rng_uniform(y1, ulo, 1.0f);
                 // (v_rcp_f32, 1 ulp: the IEEE division sequence is ten instructions per draw, and this kernel's time is the SUM of its
                 //  MFMA and VALU issue cycles)
-                g = u0 * __builtin_amdgcn_rcpf(fmaf(1.0f - u0, ea, u0));
-                gnext[q] = u1 * __builtin_amdgcn_rcpf(fmaf(1.0f - u1, ea, u1));
+                // saturated edges (exp(-alpha s) below the rounding of the denominator) give exactly 1, as the reference's sigmoid does
+                const float den0 = fmaf(1.0f - u0, ea, u0), den1 = fmaf(1.0f - u1, ea, u1);
+                g = den0 == u0 ? 1.0f : u0 * __builtin_amdgcn_rcpf(den0);
+                gnext[q] = den1 == u1 ? 1.0f : u1 * __builtin_amdgcn_rcpf(den1);
               } else {
                 g = 1.0f / (1.0f + expf(-tau * (rng_logistic(y0, tiny) + ea)));
                 gnext[q] = 1.0f / (1.0f + expf(-tau * (rng_logistic(y1, tiny) + ea)));
@@ -244,7 +246,8 @@ __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, 
       for (int q = 0; q < EPT; ++q) {
         const int i = pi0 + q * R;
         if (pact && i < d && i != pj) {
-          const float g = smem[i * LD + pcj] * fd;
+          float g = smem[i * LD + pcj] * fd;
+          g = g > 0.99999988f ? 1.0f : g;  // (g / d) * d of a saturated edge may round to 1 - 2^-24 or 1 + 2^-23: g (1 - g) has to be 0 there
           out[q] += smem[cur + pj * LD + acyc_pc<NT>(i)] * tau * alpha * g * (1.0f - g);
         }
       }

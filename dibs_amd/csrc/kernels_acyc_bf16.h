@@ -237,8 +237,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
               threefry2x32_uk(tk, c0, c0 + (uint32_t)(nbits >> 1), y0, y1);
               if (fast) {
                 const float u0 = rng_uniform(y0, ulo, 1.0f), u1 = rng_uniform(y1, ulo, 1.0f);
-                gv = u0 * __builtin_amdgcn_rcpf(fmaf(1.0f - u0, ea, u0));
-                gnext[tj][i] = u1 * __builtin_amdgcn_rcpf(fmaf(1.0f - u1, ea, u1));
+                // (saturated edges -- exp(-alpha s) below the rounding of the denominator, every step once alpha s > ~17 -- must give exactly
+                //  1 as the reference's sigmoid does: g (1 - g) = 0 multiplies matrix-power entries of any size; u * rcp(u) is 1 +- 1 ulp)
+                const float den0 = fmaf(1.0f - u0, ea, u0), den1 = fmaf(1.0f - u1, ea, u1);
+                gv = den0 == u0 ? 1.0f : u0 * __builtin_amdgcn_rcpf(den0);
+                gnext[tj][i] = den1 == u1 ? 1.0f : u1 * __builtin_amdgcn_rcpf(den1);
               } else {
                 gv = 1.0f / (1.0f + expf(-tau * (rng_logistic(y0, tiny) + ea)));
                 gnext[tj][i] = 1.0f / (1.0f + expf(-tau * (rng_logistic(y1, tiny) + ea)));

@@ -183,6 +183,26 @@ def test_acyclicity_kernel_sizes_33_to_64(c_oracle64, d, Sa):
     eng.close()
 
 
+@pytest.mark.parametrize("d,Sa", [(20, 4), (40, 4), (50, 4), (50, 3), (70, 2)])
+def test_acyclicity_gradient_of_saturated_soft_graphs_is_zero(c_oracle64, d, Sa):
+    """Once alpha * score leaves the range where float32 resolves sigmoid from 0 / 1 (every edge after the first few hundred steps of a
+    run with alpha_linear = 1) the reference's soft graph is exactly 0 / 1 and g (1 - g) = 0 kills the acyclicity gradient of that edge
+    whatever the matrix-power entry behind it.  The kernels draw g = u / (u + (1 - u) exp(-alpha s)) with an approximate reciprocal:
+    the saturated case has to come out as exactly 1, not 1 +- 2^-24 (found by tests/tools/gpu_fuzz.py).  dibs.py:121-140, 557-601"""
+    M = 2
+    data, _, _ = make_data(d, seed=1)
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=100, n_grad_mc_samples=4, n_acyclicity_mc_samples=Sa, n_dim=1)
+    st = c_oracle64.new_state(cfg, prng.PRNGKey(3))
+    st["z"] = np.sign(st["z"]) * (6.0 + np.abs(st["z"]))   # one latent dimension: |score| = |u_i v_j| >= 36, alpha |s| >= 720 at t = 20
+    eng = _engine(cfg, data.x)
+    _sync_states(eng, st)
+    dbg = c_oracle64.step(cfg, data.x, None, st, 20, debug=True)
+    eng.run(20, 1)
+    assert np.abs(np.asarray(dbg["w_acyc"])).max() < 1e-30   # (double resolves sigmoid a little further out than float: ~1e-85, not 0)
+    assert not eng.read("W_ACYC").any(), "saturated soft graphs must have an exactly zero acyclicity gradient"
+    eng.close()
+
+
 def test_score_function_baseline_and_gd_optimizer(c_oracle64):
     d, M = 8, 4
     data, _, _ = make_data(d, seed=1)
