@@ -502,23 +502,24 @@ __device__ __forceinline__ void bge_chol_wave(const float* __restrict__ R, int m
   wave_lds_fence();
 }
 
+// LDS of k_bge_chol:  [R | Q (optional)] [quad-tier index lists: 4 waves x 16 quads x BGE_QS ints] [one-problem-per-wave tier: nwg factors].
+// The two scratch regions are disjoint on purpose: the waves of a block walk the work units without block barriers, so one wave may
+// already be in the per-wave tier while its neighbour still builds quad index lists.  (Until the randomised test of tests/tools/gpu_fuzz.py
+// ran d = 96 / 112 with thousands of queued problems the regions were one array indexed by wave * max(sizes) but sized for nwg < 4 waves:
+// the quad lists of waves >= nwg lay beyond the allocation -- NaN node scores at d > 80.)
+__host__ __device__ inline size_t bge_quad_bytes() { return (size_t)16 * BGE_QS * 4; }
 // waves of a block that can work in the one-problem-per-wave tier (each needs a d x d factor in LDS)
 __host__ __device__ inline int bge_generic_waves(int d, bool r_in_lds) {
   const size_t r = r_in_lds ? (((size_t)2 * (d + 1) * (d + 1) * 4 + 15) & ~(size_t)15) : 0;
-  const size_t room = (size_t)160 * 1024 - 2048 - r, per = bge_generic_wave_bytes(d);
+  const size_t room = (size_t)160 * 1024 - 2048 - r - 4 * bge_quad_bytes(), per = bge_generic_wave_bytes(d);
   const int nw = (int)(room / per);
   return nw > 4 ? 4 : (nw < 1 ? 1 : nw);
-}
-__host__ __device__ inline size_t bge_chol_wave_bytes(int d, bool generic) {
-  const size_t quad = (size_t)16 * BGE_QS * 4;
-  const size_t g = generic ? bge_generic_wave_bytes(d) : 0;
-  return quad > g ? quad : g;
 }
 // d <= 64: every problem has n <= 32 rows (complement form), the per-wave tier and its LDS are not needed
 __host__ __device__ inline size_t bge_chol_lds_bytes(int d, bool r_in_lds) {
   const size_t r = r_in_lds ? (((size_t)2 * (d + 1) * (d + 1) * 4 + 15) & ~(size_t)15) : 0;
   const bool generic = d > 64;
-  return r + (size_t)(generic ? bge_generic_waves(d, r_in_lds) : 4) * bge_chol_wave_bytes(d, generic);
+  return r + 4 * bge_quad_bytes() + (generic ? (size_t)bge_generic_waves(d, r_in_lds) * bge_generic_wave_bytes(d) : 0);
 }
 
 // grid = any (persistent: work units are dealt round-robin, largest tier first), block = 256; dynamic LDS = bge_chol_lds_bytes()
@@ -552,7 +553,8 @@ __global__ __launch_bounds__(256) void k_bge_chol(const uint64_t* __restrict__ m
     }
     __syncthreads();
   }
-  unsigned char* wbase = smem_raw + r_bytes + (size_t)wave * bge_chol_wave_bytes(d, W2);
+  int* const qbase = reinterpret_cast<int*>(smem_raw + r_bytes + (size_t)wave * bge_quad_bytes());
+  unsigned char* const gbase = smem_raw + r_bytes + 4 * bge_quad_bytes() + (size_t)(wave < nwg ? wave : 0) * bge_generic_wave_bytes(d);
   const int W = W2 ? 2 : 1;
   // matrix offset of a problem relative to `Rm`: LDS holds [R | Q]; global memory holds Rp and Qp as separate arrays
   const float* Rm = R_LDS ? Rs : Rg;
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(256) void k_bge_chol(const uint64_t* __restrict__ m
     uint64_t w0, w1;                                                                                           \
     float ld2, last;                                                                                           \
     load(has, code, jj, l, li, mat, comp, w0, w1);                                                             \
-    bge_chol_quad<NB_, W2>(Rm, mat, ldr, d, reinterpret_cast<int*>(wbase) + (lane >> 2) * BGE_QS, w0, w1, jj, li, ld2, last); \
+    bge_chol_quad<NB_, W2>(Rm, mat, ldr, d, qbase + (lane >> 2) * BGE_QS, w0, w1, jj, li, ld2, last); \
     store(has && (tid & 3) == 0, code, jj, l, li, comp, ld2, last);                                            \
   }
   for (unsigned int u = blockIdx.x; u < total; u += gridDim.x) {
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(256) void k_bge_chol(const uint64_t* __restrict__ m
           uint64_t w0, w1;
           float ld2 = 0.f, last = 1.f;
           load(has, code, jj, l, li, mat, comp, w0, w1);
-          if (has) bge_chol_wave(Rm, mat, ldr, d, wbase, w0, w1, jj, li, ld2, last);
+          if (has) bge_chol_wave(Rm, mat, ldr, d, gbase, w0, w1, jj, li, ld2, last);
           store(has && lane == 0, code, jj, l, li, comp, ld2, last);
         }
         break;

@@ -68,6 +68,8 @@ def test_init_particles_matches_oracle(c_oracle64):
     (50, 4, 128, 32, "er", (0, 2), "legacy"),
     (70, 2, 32, 8, "er", (1,), "legacy"),           # > 64 variables: two mask words, 80x80 MFMA tiles
     (112, 2, 16, 4, "er", (1,), "legacy"),          # engine maximum: 112x112 tiles, every BGe tier up to the one-problem-per-wave one
+    (96, 8, 64, 8, "er", (1,), "legacy"),           # thousands of queued problems at d > 80: only two waves of a factorisation block fit the
+    (112, 6, 64, 4, "sf", (2,), "partitionable"),   # one-problem-per-wave tier, all four need quad index lists (LDS layout bug found by gpu_fuzz.py)
     (3, 1, 4, 2, "uniform", (0, 1), "legacy"),      # smallest sensible problem, a single particle
     (20, 5, 32, 8, "er", (2,), "partitionable"),   # jax_threefry_partitionable=True streams (no call pairing)
     (5, 3, 16, 4, "sf", (0, 1), "partitionable"),

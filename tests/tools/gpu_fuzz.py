@@ -61,6 +61,17 @@ def draw(rng):
             hidden = [(5,), (8,), (4, 3), (6, 6), (70,)][int(rng.integers(5))]
             kw.update(nn_hidden=hidden, nn_activation=str(rng.choice(["relu", "tanh", "sigmoid", "leakyrelu"])), nn_bias=bool(rng.random() < 0.7),
                       nn_obs_noise=float(rng.choice([0.1, 0.4])))
+    if os.environ.get("FUZZ_BIG"):   # larger particle counts / sample counts / graphs: other block splits, tiers and queue sizes
+        kw["n_particles"] = int(rng.choice([16, 24, 40, 64, 128]))
+        kw["n_grad_mc_samples"] = int(rng.choice([32, 64, 128]))
+        kw["n_acyclicity_mc_samples"] = int(rng.choice([8, 16, 32]))
+        if fam != "densenn":
+            kw["n_vars"] = d = int(rng.choice([20, 40, 50, 64, 70, 96, 112]))
+            kw["n_dim"] = int(rng.choice([d, d, d // 2]))
+            kw["edges_per_node"] = 2
+            if "bge_alpha_lambd" in kw:
+                kw["bge_alpha_lambd"] = d + 2 + 1.5
+        kw["n_observations"] = N = int(rng.choice([20, 100, 130]))
     interv = rng.random() < 0.3 and N > 1
     kw["has_interventions"] = bool(interv)
     t = int(rng.choice([0, 1, 2, 7, 30]))
@@ -120,8 +131,15 @@ def main():
                 e, note = min(e, 0.0), note + " (saturated: not compared)"
             if not np.isfinite(g["z"]).all():
                 e, note = float("inf"), note + " non-finite"
-            if fam == "bge" and not np.array_equal(graphs_from_masks(eng.read("PARENT_MASKS"), M, S, d), dbg["g_samples"]):
-                note += " graphs-differ"
+            if fam == "bge":
+                # a Bernoulli draw flips where the uniform falls between the float32 and the float64 value of sigmoid(alpha s): a handful of
+                # the M S d^2 bits at the larger sizes (for the reference's float32 arithmetic against the f64 oracle as well)
+                gg = graphs_from_masks(eng.read("PARENT_MASKS"), kw["n_particles"], kw["n_grad_mc_samples"], kw["n_vars"])
+                nflip = int((gg != dbg["g_samples"]).sum())
+                if nflip > max(2, 1e-5 * gg.size):
+                    note += f" graphs-differ({nflip} of {gg.size})"
+                elif nflip:
+                    e, note = min(e, 0.0), note + f" ({nflip} Bernoulli boundary flips of {gg.size}: not compared)"
             if not (g["key"] == st["key"]).all():
                 note += " key-differs"
             worst = max(worst, e)

@@ -37,8 +37,9 @@ for trial in range(max(want) + 1):
         dbg = co.step(cfg, x, mask, st, step, debug=True)
         eng.run(step, 1)
         g = eng.get_state()
+        if st.get("theta") is not None: print(f"   theta rel {rel(g['theta'], st['theta']):.3e} max|theta| {np.abs(st['theta']).max():.3e}")
         print(f" step {step}: z rel {rel(g['z'], st['z']):.3e} v_z rel {rel(g['v_z'], st['v_z']):.3e}  oracle z finite {np.isfinite(st['z']).all()}  device z finite {np.isfinite(g['z']).all()}  baseline oracle {st['baseline'][:3]} device {g['baseline'][:3]}")
-        names = {"SCORES": "scores", "NODE_SCORES": "node_scores", "LOGPROBS_Z": "logprobs_z", "W_LIK": "w_lik", "W_ACYC": "w_acyc", "GRAD_Z": "grad_z", "KXX": "kxx", "PHI_Z": "phi_z"}
+        names = {"SCORES": "scores", "NODE_SCORES": "node_scores", "LOGPROBS_Z": "logprobs_z", "W_LIK": "w_lik", "W_ACYC": "w_acyc", "GRAD_Z": "grad_z", "KXX": "kxx", "PHI_Z": "phi_z", "LOGPROBS_THETA": "logprobs_theta", "GRAD_THETA": "grad_theta", "PHI_THETA": "phi_theta"}
         for bn, on in names.items():
             if on not in dbg: continue
             try:
