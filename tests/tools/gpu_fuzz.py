@@ -72,6 +72,8 @@ def draw(rng):
             if "bge_alpha_lambd" in kw:
                 kw["bge_alpha_lambd"] = d + 2 + 1.5
         kw["n_observations"] = N = int(rng.choice([20, 100, 130]))
+    if os.environ.get("FUZZ_SCALE") and fam != "bge":
+        kw["n_observations"] = N = int(rng.choice([N, 200, 333, 500]))
     interv = rng.random() < 0.3 and N > 1
     kw["has_interventions"] = bool(interv)
     t = int(rng.choice([0, 1, 2, 7, 30]))
@@ -89,6 +91,8 @@ def main():
         fam, kw, interv, t = draw(rng)
         d, M, S, N = kw["n_vars"], kw["n_particles"], kw["n_grad_mc_samples"], kw["n_observations"]
         x = (rng.normal(size=(N, d)) @ (np.eye(d) + 0.3 * np.triu(rng.normal(size=(d, d)), 1))).astype(np.float32)
+        if os.environ.get("FUZZ_SCALE"):   # badly scaled / shifted data, more observations than the LDS-resident kernels take
+            x = (x * np.float32(rng.choice([1.0, 0.05, 8.0])) + np.float32(rng.choice([0.0, 0.0, 3.0]))).astype(np.float32)
         mask = (rng.random((N, d)) < 0.15).astype(np.int32) if interv else None
         try:
             cfg = make_config(**kw)

@@ -15,6 +15,8 @@ for trial in range(max(want) + 1):
     fam, kw, interv, t = draw(rng)
     d, M, S, N = kw["n_vars"], kw["n_particles"], kw["n_grad_mc_samples"], kw["n_observations"]
     x = (rng.normal(size=(N, d)) @ (np.eye(d) + 0.3 * np.triu(rng.normal(size=(d, d)), 1))).astype(np.float32)
+    if os.environ.get("FUZZ_SCALE"):
+        x = (x * np.float32(rng.choice([1.0, 0.05, 8.0])) + np.float32(rng.choice([0.0, 0.0, 3.0]))).astype(np.float32)
     mask = (rng.random((N, d)) < 0.15).astype(np.int32) if interv else None
     try:
         cfg = make_config(**kw); eng = Engine(cfg)
