@@ -100,7 +100,8 @@ def main():
         except Exception as e:  # a documented limit of the device lowering (reported, not counted)
             print(f"[{trial}] rejected: {type(e).__name__}: {str(e)[:90]}   {fam} d={d}")
             continue
-        eng.set_data(x, mask)
+        mean_obs = rng.normal(size=d).astype(np.float32) if (fam == "bge" and os.environ.get("FUZZ_SCALE") and rng.random() < 0.5) else None
+        eng.set_data(x, mask, mean_obs)   # (BGe prior mean: linearGaussian.py:35-48)
         st = co.new_state(cfg, prng.PRNGKey(int(rng.integers(1 << 30))))
         # RMSprop from v = 0 moves EVERY coordinate by ~3.2 stepsize in the direction of sign(phi): coordinates whose phi is below the float32
         # noise of the sum get a coin flip (in the reference as well).  A trajectory starts at t = 0 with a clean prior gradient; a trial
@@ -117,7 +118,7 @@ def main():
             if st.get("theta") is not None:
                 sk.update(theta=st["theta"], v_theta=st["v_theta"])
             eng.set_state(**sk)
-            dbg = co.step(cfg, x, mask, st, step, debug=True)
+            dbg = co.step(cfg, x, mask, st, step, debug=True, mean_obs=mean_obs)
             eng.run(step, 1)
             g = eng.get_state()
             e = rel(g["z"], st["z"])
