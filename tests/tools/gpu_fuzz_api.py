@@ -136,7 +136,7 @@ def section_bc(rng, n):
         mask = (rng.random((N, d)) < 0.15).astype(np.int32) if rng.random() < 0.3 else None
         kw["has_interventions"] = mask is not None
         key = prng.PRNGKey(int(rng.integers(1 << 30)))
-        steps = 4
+        steps = int(rng.integers(2, 25))
         ref = Engine(make_config(**kw))
         ref.set_data(x, mask)
         ref.init_particles(key)
@@ -154,7 +154,9 @@ def section_bc(rng, n):
         e2 = Engine(make_config(**kw))
         e2.set_data(x, mask)
         e2.set_state(**snap)
-        e2.run(a, steps - a)
+        b = int(rng.integers(a, steps + 1))     # second chunk boundary on the same engine (b == a / b == steps: empty chunks)
+        e2.run(a, b - a)
+        e2.run(b, steps - b)
         s2 = e2.get_state()
         e2.close()
         okc = np.array_equal(s2["z"], sref["z"]) and (s2["key"] == sref["key"]).all() and \
