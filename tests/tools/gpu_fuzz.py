@@ -72,6 +72,15 @@ def draw(rng):
             if "bge_alpha_lambd" in kw:
                 kw["bge_alpha_lambd"] = d + 2 + 1.5
         kw["n_observations"] = N = int(rng.choice([20, 100, 130]))
+    if os.environ.get("FUZZ_PARTICLES"):   # many particles, small graphs: kernel-matrix / phi block splits, LDS table limits
+        kw["n_particles"] = int(rng.choice([200, 256, 500, 1024]))
+        kw["n_vars"] = d = int(rng.choice([3, 5, 8, 12, 20]))
+        kw["n_dim"] = int(rng.choice([d, 2]))
+        kw["n_grad_mc_samples"] = int(rng.choice([2, 8, 16]))
+        kw["n_acyclicity_mc_samples"] = int(rng.choice([2, 4]))
+        kw["edges_per_node"] = 0.4 if d <= 3 else (1 if d <= 9 else 2)
+        kw.pop("bge_alpha_lambd", None)
+        kw["n_observations"] = N = int(rng.choice([20, 100]))
     if os.environ.get("FUZZ_SCALE") and fam != "bge":
         kw["n_observations"] = N = int(rng.choice([N, 200, 333, 500]))
     interv = rng.random() < 0.3 and N > 1
