@@ -777,3 +777,18 @@ def test_kernel_matrix_fusion_is_transparent(monkeypatch):
         outs.append((eng.read("KXX").copy(), eng.get_state()["z"].copy()))
         eng.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("mode,n,seed", [("", 25, 101), ("FUZZ_BIG", 6, 102), ("FUZZ_SCALE", 12, 103)])
+def test_randomised_differential(monkeypatch, mode, n, seed):
+    """A fixed-seed slice of tests/tools/gpu_fuzz.py (random sizes, priors, estimators, optimizers, interventions, PRNG layouts and model
+    families, one or two steps each against the f64 oracle) as a regression net: the full runs found two defects this round."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "tools"))
+    import gpu_fuzz
+    for m in ("FUZZ_BIG", "FUZZ_SCALE", "FUZZ_PARTICLES"):
+        monkeypatch.delenv(m, raising=False)
+    if mode:
+        monkeypatch.setenv(mode, "1")
+    monkeypatch.setattr(sys, "argv", ["gpu_fuzz.py", str(n), str(seed)])
+    assert gpu_fuzz.main() == 0
