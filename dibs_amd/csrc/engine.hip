@@ -33,12 +33,12 @@ static int fail(const std::string& m) {
 // and for the complement form of kernels_bge.h R_j^-1 and logdet R_j.  Computed once per data set on the host in double,
 // uploaded as f32 / f64.  Owns its device buffers.
 struct BgeStats {
-  float *R = nullptr, *Rp = nullptr, *Qp = nullptr;
+  float *R = nullptr, *Rp = nullptr, *Qp = nullptr;  // Qp = Rp + n_mats (d+1)^2: ONE allocation (see bge_upload)
   double *gam = nullptr, *Nj = nullptr, *ldR = nullptr;
   int n_mats = 1;
   double alpha_lambd = 0, alpha_mu = 0, log_t = 0;
   void release() {
-    void* ptrs[] = {R, Rp, Qp, gam, Nj, ldR};
+    void* ptrs[] = {R, Rp, gam, Nj, ldR};
     for (void* p_ : ptrs)
       if (p_) hipFree(p_);
     R = Rp = Qp = nullptr;
@@ -410,8 +410,11 @@ static int bge_prepare(BgeStats* st, const dibs_config& cfg, int d, int N, const
                                      0.5 * (al - d + 2 * l + 1) * log(small_t);
     }
   HIP_OK(dalloc(&st->R, R.size()));
-  HIP_OK(dalloc(&st->Rp, Rp.size()));
-  HIP_OK(dalloc(&st->Qp, Qp.size()));
+  // R and Q = R^-1 in one allocation: the factorisation kernel addresses a problem's matrix as a 32-bit float offset from Rp, and two
+  // separate hipMalloc blocks can lie more than 2^31 floats apart on a 288 GB device (intermittent memory faults with interventions or
+  // d > 80, where the matrices are not LDS-resident; found by tests/tools/gpu_fuzz.py)
+  HIP_OK(dalloc(&st->Rp, Rp.size() + Qp.size()));
+  st->Qp = st->Rp + Rp.size();
   HIP_OK(dalloc(&st->gam, gam.size()));
   HIP_OK(dalloc(&st->Nj, Nj.size()));
   HIP_OK(dalloc(&st->ldR, ldR.size()));

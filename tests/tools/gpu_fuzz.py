@@ -72,6 +72,13 @@ def draw(rng):
             if "bge_alpha_lambd" in kw:
                 kw["bge_alpha_lambd"] = d + 2 + 1.5
         kw["n_observations"] = N = int(rng.choice([20, 100, 130]))
+    if os.environ.get("FUZZ_NN") and fam == "densenn":   # per-node MLPs on larger graphs (BASELINE config 5 is d = 100)
+        kw["n_vars"] = d = int(rng.choice([30, 50, 64, 65, 80, 100]))
+        kw["n_dim"] = d
+        kw["n_particles"] = int(rng.choice([2, 4, 8]))
+        kw["n_grad_mc_samples"] = int(rng.choice([2, 8, 16]))
+        kw["n_observations"] = N = int(rng.choice([20, 100, 128, 140]))
+        kw["edges_per_node"] = 2
     if os.environ.get("FUZZ_PARTICLES"):   # many particles, small graphs: kernel-matrix / phi block splits, LDS table limits
         kw["n_particles"] = int(rng.choice([200, 256, 500, 1024]))
         kw["n_vars"] = d = int(rng.choice([3, 5, 8, 12, 20]))
@@ -103,6 +110,8 @@ def main():
         if os.environ.get("FUZZ_SCALE"):   # badly scaled / shifted data, more observations than the LDS-resident kernels take
             x = (x * np.float32(rng.choice([1.0, 0.05, 8.0])) + np.float32(rng.choice([0.0, 0.0, 3.0]))).astype(np.float32)
         mask = (rng.random((N, d)) < 0.15).astype(np.int32) if interv else None
+        if os.environ.get("FUZZ_VERBOSE"):
+            print(f"[{trial}] start t={t} {fam} " + " ".join(f"{k_}={v}" for k_, v in kw.items() if k_ != "likelihood"), flush=True)
         try:
             cfg = make_config(**kw)
             eng = Engine(cfg)
