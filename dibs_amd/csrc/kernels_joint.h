@@ -591,6 +591,11 @@ static size_t ling_lds(int d, int n_gram, bool grad) {
   const size_t dd = (size_t)d * d;
   return (n_gram == 1 ? dd * 8 : 0) + (((grad ? 2 : 1) * dd * 4 + 15) & ~(size_t)15) + 128;
 }
+// the n_gram argument of the Gram kernels: a single matrix stays in LDS only while it fits beside the operands (d <= 101 for the gradient
+// kernel); beyond that it is read through the caches (-1).  (Found by tests/tools/gpu_fuzz.py: d = 112 with 500 observations failed to launch.)
+static int ling_ngram_arg(int d, int n_gram, bool grad) {
+  return (n_gram == 1 && ling_lds(d, 1, grad) > (size_t)160 * 1024) ? -1 : n_gram;
+}
 int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) {
   (void)N;
   w->x = nullptr;
@@ -699,12 +704,13 @@ static void joint_lin_grads(JointWork* w, const JointLaunch& jl, Key2 carry_thet
 void joint_lin_all_logprobs(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z) {
   const int mz = jl.est_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM;
   if (w->n_gram) {  // Gram-matrix path (x does not fit LDS)
-    const size_t lds = ling_lds(jl.d, w->n_gram, false);
+    const int ng = ling_ngram_arg(jl.d, w->n_gram, false);
+    const size_t lds = ling_lds(jl.d, ng, false);
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_ling_logprobs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_ling_logprobs, dim3(jl.S, jl.Mloc), dim3(256), lds, jl.stream, w->gram, w->ncnt, w->n_gram, jl.theta, jl.scores, jl.thr,
+    hipLaunchKernelGGL(k_ling_logprobs, dim3(jl.S, jl.Mloc), dim3(256), lds, jl.stream, w->gram, w->ncnt, ng, jl.theta, jl.scores, jl.thr,
                        jl.logprobs_th, carry_theta, (int)LIN_MODE_THETA, jl.m0, jl.M, jl.d, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise,
                        jl.mean_edge, jl.sig_edge);
-    hipLaunchKernelGGL(k_ling_logprobs, dim3(jl.S, jl.Mloc), dim3(256), lds, jl.stream, w->gram, w->ncnt, w->n_gram, jl.theta, jl.scores, jl.thr,
+    hipLaunchKernelGGL(k_ling_logprobs, dim3(jl.S, jl.Mloc), dim3(256), lds, jl.stream, w->gram, w->ncnt, ng, jl.theta, jl.scores, jl.thr,
                        jl.logprobs_z, carry_z, mz, jl.m0, jl.M, jl.d, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise, jl.mean_edge,
                        jl.sig_edge);
     return;
@@ -716,13 +722,14 @@ void joint_lin_all_logprobs(JointWork* w, const JointLaunch& jl, Key2 carry_thet
 // both softmax-weighted gradients in one launch
 void joint_lin_all_grads(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z) {
   if (w->n_gram) {
-    const size_t lds = ling_lds(jl.d, w->n_gram, true);
+    const int ng = ling_ngram_arg(jl.d, w->n_gram, true);
+    const size_t lds = ling_lds(jl.d, ng, true);
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_ling_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const LinGradJob jt{jl.logprobs_th, jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off, jl.pack_stride,
                         jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off, nullptr, carry_theta, LIN_MODE_THETA};
     const LinGradJob jz{jl.logprobs_z, jl.w_lik, (size_t)jl.d * jl.d, nullptr, jl.baseline_out, carry_z,
                         jl.est_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM};
-    hipLaunchKernelGGL(k_ling_grad, dim3(jl.Mloc, 2), dim3(256), lds, jl.stream, w->gram, w->n_gram, jl.theta, jl.scores, jl.thr, jt, jz, jl.baseline,
+    hipLaunchKernelGGL(k_ling_grad, dim3(jl.Mloc, 2), dim3(256), lds, jl.stream, w->gram, ng, jl.theta, jl.scores, jl.thr, jt, jz, jl.baseline,
                        jl.m0, jl.M, jl.d, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise, jl.mean_edge, jl.sig_edge, jl.sf_baseline);
     return;
   }
@@ -744,9 +751,10 @@ static void launch_lin_given(const JointWork& jw, const float* theta, const int3
 void joint_lin_score_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N, float obs_noise,
                            float mean_edge, float sig_edge, hipStream_t stream) {
   if (jw.n_gram) {
-    const size_t lds = ling_lds(d, jw.n_gram, false);
+    const int ng = ling_ngram_arg(d, jw.n_gram, false);
+    const size_t lds = ling_lds(d, ng, false);
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_ling_logprobs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_ling_logprobs, dim3(1, n), dim3(256), lds, stream, jw.gram, jw.ncnt, jw.n_gram, theta, (const float*)nullptr,
+    hipLaunchKernelGGL(k_ling_logprobs, dim3(1, n), dim3(256), lds, stream, jw.gram, jw.ncnt, ng, theta, (const float*)nullptr,
                        reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, 1, 0.f, 1.f, 0, 0, obs_noise, mean_edge,
                        sig_edge);
     return;

@@ -16,7 +16,7 @@ __device__ __forceinline__ void ling_cw(const double* __restrict__ Cs, const dou
   for (int e = tid; e < d * d; e += 256) {
     const int j = e / d, a = e - j * d;  // (j-major: the threads of a wave share the column of W and, with interventions, the matrix)
     if (!need_all && WG[a * d + j] == 0.f) continue;
-    const double* Ca = (n_gram > 1 ? gram + (size_t)j * d * d : Cs) + (size_t)a * d;
+    const double* Ca = (n_gram == 1 ? Cs : gram + (n_gram > 1 ? (size_t)j * d * d : 0)) + (size_t)a * d;  // (n_gram == -1: one matrix, read through the caches)
     double v = 0.0;
     for (int b = 0; b < d; ++b) {
       const float w = WG[b * d + j];
@@ -28,7 +28,8 @@ __device__ __forceinline__ void ling_cw(const double* __restrict__ Cs, const dou
 
 // ------------------------------------------------------------------------------------------------
 // log p(theta, D | G_s), one sample per block.  grid = (S, Mloc) [mode GIVEN: (1, n graphs)], block = 256
-// dynamic LDS = d*d*4 (W) + (n_gram == 1 ? d*d*8 : 0) (C) + 64
+// dynamic LDS = d*d*4 (W) + (n_gram == 1 ? d*d*8 : 0) (C) + 64;  n_gram: 1 = one Gram matrix, LDS-resident; d = one per node (interventions);
+// -1 = one matrix that does not fit LDS beside the operands (d > 100), read through the caches
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ling_logprobs(const double* __restrict__ gram, const double* __restrict__ ncnt, int n_gram,
                                                        const float* __restrict__ theta, const float* __restrict__ scores,
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void k_ling_logprobs(const double* __restrict_
   const double lognorm_x = -0.5 * log((double)obs_noise) - 0.918938533204672742;
   // sum_j [ N_j lognorm - (C_jj - 2 w.c + w.Cw) / (2 obs_noise) ]
   for (int j = tid; j < d; j += 256) {
-    const double cjj = (n_gram > 1 ? gram + (size_t)j * dd : Cs)[(size_t)j * d + j];
+    const double cjj = (n_gram == 1 ? Cs : gram + (n_gram > 1 ? (size_t)j * dd : 0))[(size_t)j * d + j];
     part += ncnt[j] * lognorm_x - inv2 * cjj;
   }
   ling_cw(Cs, gram, n_gram, WG, d, tid, false, [&](int a, int j, double v, double caj) {

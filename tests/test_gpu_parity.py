@@ -373,6 +373,8 @@ def test_joint_lingauss_step_stages(c_oracle64, d, M, S, Sa, est, prior, interv,
     (50, 3, 32, 8, "reparam", True, 100, True),
     (20, 3, 32, 8, "reparam", True, 900, False),    # x [900, 20] does not fit LDS: the engine picks the Gram path by itself
     (50, 2, 16, 4, "reparam", False, 400, False),
+    (112, 2, 8, 4, "score", False, 500, False),     # one Gram matrix that no longer fits LDS beside the operands (d > 100): read through the caches
+    (104, 2, 8, 4, "reparam", False, 300, False),   # (launch failure found by tests/tools/gpu_fuzz.py)
 ])
 def test_joint_lingauss_gram_path(c_oracle64, monkeypatch, d, M, S, Sa, est, interv, N, force):
     """LinearGaussian for any number of observations (linearGaussian.py:292-316): the Gram-matrix path of kernels_lin_gram.h,
