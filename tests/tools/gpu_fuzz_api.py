@@ -43,6 +43,9 @@ def section_a(rng, co, n):
         fam = str(rng.choice(["bge", "lingauss", "densenn"]))
         d = int(rng.choice([2, 3, 6, 17, 33, 50, 64, 65, 80])) if fam != "densenn" else int(rng.choice([2, 5, 12, 20]))
         N = int(rng.choice([1, 7, 100, 150]))
+        if os.environ.get("FUZZ_BIG"):   # larger graphs, observation counts beyond the LDS-resident kernels
+            d = int(rng.choice([64, 80, 96, 104, 112])) if fam != "densenn" else int(rng.choice([20, 50, 100]))
+            N = int(rng.choice([20, 130, 300, 500]))
         kw = model_kw(rng, fam)
         x = data(rng, N, d)
         mask = (rng.random((N, d)) < 0.2).astype(np.int32) if rng.random() < 0.4 and N > 1 else None
@@ -127,6 +130,11 @@ def section_bc(rng, n):
         N = int(rng.choice([5, 100, 140]))
         S = int(rng.choice([2, 8, 32, 128])) if d <= 33 else int(rng.choice([2, 8, 32]))
         Sa = int(rng.choice([1, 2, 4, 8, 32]))
+        if os.environ.get("FUZZ_BIG"):
+            d = int(rng.choice([50, 64, 80, 96, 112])) if fam != "densenn" else int(rng.choice([12, 30, 65]))
+            M = R * int(rng.choice([2, 8, 16]))
+            N = int(rng.choice([20, 130, 300]))
+            S = int(rng.choice([8, 32, 64]))
         kw = dict(n_vars=d, n_particles=M, n_observations=N, n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa,
                   edges_per_node=0.4 if d <= 3 else (1 if d <= 9 else 2), graph_prior=str(rng.choice(["er", "sf"])),
                   rng_layout=str(rng.choice(["legacy", "legacy", "partitionable"])), **model_kw(rng, fam))
