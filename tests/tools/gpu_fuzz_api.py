@@ -190,6 +190,8 @@ def section_d(rng, n):
         d = int(rng.choice([2, 3, 5, 8, 12]))
         M, S, Sa = int(rng.choice([1, 2])), int(rng.choice([1, 2, 4])), int(rng.choice([1, 2]))
         N = int(rng.choice([5, 40]))
+        if os.environ.get("FUZZ_SOFT_BIG"):   # the upper end of the soft-graph BGe kernel's range (torch-autograd oracle: slow)
+            d, M, S, Sa = int(rng.choice([20, 33, 50, 64])), 1, int(rng.choice([1, 2])), 1
         x = data(rng, N, d)
         interv = rng.random() < 0.3
         mask = (rng.random((N, d)) < 0.15).astype(np.int32) if interv else None
@@ -228,9 +230,13 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
     co = COracle("f64")
-    bad_a = section_a(rng, co, n)
-    bad_bc = section_bc(rng, n)
-    bad_d = section_d(rng, max(n // 3, 5))
+    if os.environ.get("FUZZ_SOFT_BIG"):
+        bad_a = bad_bc = 0
+        bad_d = section_d(rng, n)
+    else:
+        bad_a = section_a(rng, co, n)
+        bad_bc = section_bc(rng, n)
+        bad_d = section_d(rng, max(n // 3, 5))
     print(f"A (scorers) {bad_a} bad, B/C (sharding, chunking) {bad_bc} bad, D (BGe reparam) {bad_d} bad")
     return 1 if bad_a + bad_bc + bad_d else 0
 
