@@ -13,6 +13,7 @@
 #include "launch.h"
 #include <unordered_map>
 #include "kernels_marginal.h"
+#include "kernels_tail.h"
 #include "kernels_joint.h"
 #include "kernels_nn.h"
 #include "kernels_bge_soft.h"
@@ -70,7 +71,7 @@ struct dibs_engine {
   float* soft_ds;  // [Mloc, S, d, d]  BGe reparam estimator: per-sample score-space gradients
   bool has_data;
   // work
-  float *scores, *probs, *w_tot, *w_lik, *acyc_part, *w_acyc, *logprobs_z, *logprobs_th, *pack, *kz, *kt, *phi_z, *phi_th;
+  float *scores, *probs, *w_lik, *acyc_part, *w_acyc, *logprobs_z, *logprobs_th, *pack, *kz, *kt, *phi_z, *phi_th;
   uint32_t* thr;
   uint64_t* masks;
   BgeQueues bq;
@@ -208,7 +209,6 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   HIP_OK(dalloc(&e->baseline2, Ml));
   HIP_OK(dalloc(&e->scores, Ml * dd));
   HIP_OK(dalloc(&e->probs, Ml * dd));
-  HIP_OK(dalloc(&e->w_tot, Ml * dd));
   HIP_OK(dalloc(&e->thr, Ml * dd));
   HIP_OK(dalloc(&e->w_lik, Ml * dd));
   HIP_OK(dalloc(&e->acyc_part, Ml * e->acyc_nblk * dd));
@@ -275,7 +275,11 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
   }
   {
     if ((size_t)2 * 4 * c.n_particles * 4 + 4096 > LDS_LIMIT) return fail("n_particles too large (kernel rows must fit in LDS)");
-    if (((size_t)c.n_vars * c.n_vars + (size_t)2 * c.n_vars * c.n_dim) * 4 > LDS_LIMIT) return fail("n_vars * n_dim too large");
+    // k_particle_grad keeps a particle's score-space gradient, its Z and (score estimator) the per-sample weights in LDS
+    const bool score_lik = c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_SCORE;
+    const int ldz = tail_ldz(c.n_vars, c.n_dim, c.n_grad_mc_samples, score_lik, LDS_LIMIT - 2048);
+    if (tail_lds_bytes(c.n_vars, ldz, c.n_grad_mc_samples, (c.n_vars + 63) / 64, score_lik, 0) > LDS_LIMIT - 2048)
+      return fail("n_vars * n_dim (or n_grad_mc_samples) too large: a particle's gradient does not fit in LDS");
   }
   // (LinearGaussian: x beyond the LDS capacity takes the Gram-matrix path; DenseNonlinearGaussian the general path)
   int ndev = 0;
@@ -302,7 +306,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (!e) return 0;
   hipSetDevice(e->cfg.device_id);
   if (e->stream) hipStreamSynchronize(e->stream);
-  void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->w_tot, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
+  void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
                   e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds};
   for (void* p : ptrs)
@@ -596,23 +600,18 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     hipLaunchKernelGGL(k_edge_scores, dim3(e->Mloc, ntile >= 16 ? 4 : (ntile >= 8 ? 2 : 1)), dim3(256), lds, e->stream, e->z, e->scores, e->thr, e->probs, alpha, e->d, e->k,
                        e->dpad, e->ldk);
   }
-  LikArgs lik{};
-  int lik_blocks = 0;
-  size_t lik_lds = 0;
-  // (not when the score estimator's blocks ride along in the acyclicity launch: see below)
-  const bool rider = c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z != DIBS_EST_REPARAM && (long)e->acyc_nblk * e->Mloc <= 512 &&
-                     !getenv("DIBS_NO_LIK_FUSE");
+  bool score_lik = false;
   // While per-kernel timing is on (set_profiling(1)) the main stream joins right away, so that every duration is a kernel alone on the
   // GPU -- but the launch still goes to the second stream: with that (high-priority) queue in existence the same kernel takes 104 us
   // on the main stream and 96 us on its own.
-  const bool fork = e->stream2 && !rider, join_now = e->profiling && !e->profiling_concurrent;
+  const bool fork = e->stream2 != nullptr, join_now = e->profiling && !e->profiling_concurrent;
   if (fork) {
     hipEventRecord(e->ev_fork, e->stream);
     hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
     KTimer tm(e, DIBS_K_ACYC, e->stream2);
-    const AcycLaunch al{e->stream2, e->scores, e->acyc_part, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
+    const AcycLaunch al{e->stream2, e->scores, e->acyc_part, e->w_acyc, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
                         e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny};
-    acyc_launch(al, lik, 0, 0);
+    acyc_launch(al);
   }
   // Single rank: the kernel matrices need only z (and theta), which are final when the step starts.  For the joint models, and for the
   // marginal model once the matrix is large against the sampling work (M D > 4 S d^2), they follow the acyclicity kernel on the second
@@ -648,7 +647,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
                     e->soft_ds, e->logprobs_z, e->w_lik, e->stream);
   } else if (c.likelihood == DIBS_LIK_BGE) {
     const BgeParams bp = e->bge.params();
-    {  // (queue counters: zero at creation, reset by k_lik_weights_score at the end of every step)
+    {  // (queue counters: zero at creation, reset by k_particle_grad at the end of every step)
       KTimer tm(e, DIBS_K_BGE_NODES);
       KmatFuse kf{nullptr, nullptr, 0, 0, 0, 0.f, 0.f};
       e->kmat_fused = false;
@@ -664,26 +663,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
       KTimer tm(e, DIBS_K_BGE_BIG);
       bge_launch_chol(e->stream, e->masks, e->node_scores, bp, e->bq, e->d, e->S, e->profiling ? e->counters : nullptr);
     }
-    {
-      const int ny = e->d < 8 ? e->d : 8;  // blocks per particle (2 / 4 / 8 / 16 measured: 26 / 19 / 17 / 19 us)
-      const size_t base = (((size_t)e->S * 36 + 15) & ~(size_t)15);
-      const size_t mbytes = (size_t)e->S * ((e->d + ny - 1) / ny) * e->W * 8;
-      const int in_lds = base + mbytes <= 64 * 1024;
-      lik_lds = base + (in_lds ? mbytes : 0);
-      lik = LikArgs{e->node_scores, e->masks, e->probs, e->logprobs_z, e->w_lik, e->baseline, e->baseline2, alpha,
-                    c.score_function_baseline, e->d, e->S, e->W, in_lds, ny, e->bq.counts};
-      // A rank with few particles leaves most block slots of the k_acyc launch empty (<= 2 of the 3 per CU): the score
-      // estimator's latency-bound blocks ride along there.  With all slots taken (one rank, 128 particles) riding along
-      // made k_acyc 21 us longer for 19 us saved, so it stays a launch of its own.
-      if ((long)e->acyc_nblk * e->Mloc <= 512 && !getenv("DIBS_NO_LIK_FUSE")) {
-        lik_blocks = ny;
-      } else {
-        KTimer tm(e, DIBS_K_LIK_WEIGHTS);
-        allow_lds(k_lik_weights_score, lik_lds);
-        hipLaunchKernelGGL(k_lik_weights_score, dim3(e->Mloc, ny), dim3(256), lik_lds, e->stream, lik);
-      }
-      std::swap(e->baseline, e->baseline2);
-    }
+    score_lik = true;  // softmax weights, W_lik and the baseline are part of k_particle_grad below
   } else if (c.likelihood == DIBS_LIK_LINGAUSS) {
     JointLaunch jl{e->stream, e->z, e->theta, e->scores, e->thr, e->w_lik, e->logprobs_z, e->logprobs_th, e->baseline,
                    e->baseline2, pack, (size_t)e->E, (size_t)(2 * e->D), (size_t)(2 * e->D + e->P), e->m0, e->M, e->Mloc, e->d,
@@ -718,27 +698,27 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     hipStreamWaitEvent(e->stream, e->ev_join, 0);  // (covers the kernel matrices: they precede the acyclicity kernel on that stream)
   } else {
     KTimer tm(e, DIBS_K_ACYC);
-    const AcycLaunch al{e->stream, e->scores, e->acyc_part, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
+    const AcycLaunch al{e->stream, e->scores, e->acyc_part, e->w_acyc, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
                         e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny};
-    acyc_launch(al, lik, lik_blocks, lik_lds);
+    acyc_launch(al);
   }
   {
-    KTimer tm(e, DIBS_K_WTOTAL);
+    // one block per particle: (score estimator: softmax weights -> W_lik,) total score-space gradient, back-projection, packed row
+    KTimer tm(e, DIBS_K_TAIL);
     float er_c = 0.f;
     if (c.graph_prior == DIBS_PRIOR_ER) {
       const double p = c.graph_prior_edges_per_node * e->d / ((e->d * (e->d - 1)) / 2.0);
       er_c = (float)(log(p) - log(1 - p));
     }
-    hipLaunchKernelGGL(k_wtotal, dim3(e->Mloc, (e->d * e->d + 255) / 256), dim3(256), 0, e->stream, e->probs, e->w_lik, e->acyc_part, e->acyc_nblk,
-                       e->w_acyc, e->w_tot, e->d, e->Sa, alpha, beta, c.graph_prior, er_c);
-  }
-  {
-    KTimer tm(e, DIBS_K_ZGRAD);
-    const size_t lds = ((size_t)e->d * e->d + (size_t)2 * e->d * e->k) * 4;
-    allow_lds(k_zgrad, lds);
-    const int zs = e->d < 8 ? e->d : 8;
-    hipLaunchKernelGGL(k_zgrad, dim3(e->Mloc, zs), dim3(256), lds, e->stream, e->z, e->w_tot, pack, (size_t)e->E, e->m0, e->d,
-                       e->k, 1.0f / (e->sigz * e->sigz));
+    const int ldz = tail_ldz(e->d, e->k, e->S, score_lik, LDS_LIMIT - 2048);
+    const int cap = score_lik ? tail_stage_cap(e->d, ldz, e->S, e->W, LDS_LIMIT - 2048) : 0;
+    const size_t lds = tail_lds_bytes(e->d, ldz, e->S, e->W, score_lik, cap);
+    const TailArgs ta{score_lik ? e->node_scores : nullptr, e->masks, e->logprobs_z, e->baseline, e->baseline2, c.score_function_baseline,
+                      score_lik ? e->bq.counts : nullptr, e->S, e->W, cap, e->probs, e->w_lik, e->w_acyc, alpha, beta, c.graph_prior, er_c,
+                      e->z, pack, (size_t)e->E, e->m0, e->d, e->k, ldz, 1.0f / (e->sigz * e->sigz), e->profiling ? e->counters : nullptr};
+    allow_lds(k_particle_grad, lds);
+    hipLaunchKernelGGL(k_particle_grad, dim3(e->Mloc), dim3(TAIL_NT), lds, e->stream, ta);
+    if (score_lik) std::swap(e->baseline, e->baseline2);
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(err));

@@ -1,12 +1,11 @@
 // acyclicity-constraint gradient on f32 MFMA (gfx950)
 #pragma once
 #include "common.h"
-#include "kernels_lik.h"
 
 // ------------------------------------------------------------------------------------------------
 // K5  acyclicity gradient: for Gumbel-soft graphs G~ = sigmoid(tau (eps + alpha s)), M = I + G~/d,
 //     dh/dG~ = (M^{d-1})^T (h = tr(M^d) - d), chained through G~.  Matrix powers on f32 MFMA, all operands
-//     resident in LDS.  Each block handles CPB chains of one particle and writes their SUM.
+//     resident in LDS.  Each block handles CPB chains of one particle and writes their SUM; k_acyc_reduce adds the partial sums.
 //     reference: graph_utils.py:8-28, dibs.py:121-140, 557-601
 // grid = (ceil(Sa / CPB), Mloc), block = 256; dynamic LDS = 3 * DP * LD * 4, DP = 16 NT, LD = DP + 2
 //
@@ -27,6 +26,38 @@
 // are contiguous: one ds_read_b128 / ds_write_b128 for NT = 4.  LD = 16 NT + 4.
 template <int NT>
 __device__ __forceinline__ int acyc_pc(int c) { return (c & 15) * NT + (c >> 4); }
+
+// Reduction of the per-block partial sums part[m][blk][d*d] over the blocks of a particle, in block order (fixed: bit-reproducible,
+// independent of the grid), scaled by 1 / Sa.  A launch of its own behind the acyclicity kernel ON ITS STREAM, i.e. beside the BGe kernels
+// and off the critical path; the consumer (k_particle_grad) then reads one value per element instead of one per block.
+// Measured alternatives inside the acyclicity launch (last block of a particle to draw a ticket reduces): with agent-scope release /
+// acquire fences around the ticket 98 -> 427 us per launch (every fence writes back / invalidates the XCD's whole L2: buffer_wbl2 /
+// buffer_inv sc1); with sc1 (agent-scope) stores and loads of the partial sums and no fence 98 -> 121 us.  The kernel boundary is cheaper.
+// grid = (Mloc, ceil(d*d / 256)), block = 256
+#ifdef DIBS_TU_ACYC
+__global__ __launch_bounds__(256) void k_acyc_reduce(const float* __restrict__ part, float* __restrict__ w_acyc, int nblk, int dd, float inv_sa) {
+  const int m = blockIdx.x, e = blockIdx.y * 256 + threadIdx.x;
+  if (e >= dd) return;
+  const float* pm = part + (size_t)m * nblk * dd + e;
+  float ac = 0.f;
+  int q = 0;
+  for (; q + 16 <= nblk; q += 16) {  // loads in flight together, additions in block order
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = pm[(size_t)(q + u) * dd];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) ac += v[u];
+  }
+  {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = q + u < nblk ? pm[(size_t)(q + u) * dd] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) ac += q + u < nblk ? v[u] : 0.f;
+  }
+  w_acyc[(size_t)m * dd + e] = ac * inv_sa;
+}
+#endif
 
 // k-steps S .. KS-1 of one tile row as a template recursion (see lds_matmul)
 template <int NT, int KS, int S>
@@ -136,13 +167,9 @@ __device__ __forceinline__ void acyc_matmul(float* __restrict__ lds, int c_off, 
 template <int NT, bool PAIRED>
 __global__ __launch_bounds__(256) void k_acyc(const float* __restrict__ scores, float* __restrict__ part, Key2 carry, int m0,
                                               int M_global, int d, int Sa, int cpb, float alpha, float tau, int layout,
-                                              int tiny, int n_acyc_blk, LikArgs lik) {
+                                              int tiny, int n_acyc_blk) {
   constexpr int DP = 16 * NT, LD = DP + 4, BUF = DP * LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if ((int)blockIdx.x >= n_acyc_blk) {  // score-estimator role (block-uniform): see lik_weights_block
-    lik_weights_block(reinterpret_cast<unsigned char*>(smem), lik, (int)blockIdx.y, (int)blockIdx.x - n_acyc_blk);
-    return;
-  }
   const int blk = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Key2 km = rng_split_row_uniform(carry, (uint32_t)M_global + 1u, (uint32_t)(m0 + m) + 1u, layout);  // dibs.py:595: key used directly
   const uint64_t dd = (uint64_t)d * d, nbits = (uint64_t)Sa * dd;

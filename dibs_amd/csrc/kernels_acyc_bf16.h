@@ -1,7 +1,7 @@
 // acyclicity-constraint gradient, 33 <= d <= 64: matrix powers on the bf16 MFMA with three-way split operands (gfx950)
 #pragma once
 #include "common.h"
-#include "kernels_lik.h"
+#include "kernels_acyc.h"
 
 // ------------------------------------------------------------------------------------------------
 // K5b  same computation as k_acyc (kernels_acyc.h; reference: graph_utils.py:8-28, dibs.py:121-140, 557-601), other arithmetic
@@ -27,7 +27,7 @@
 // from the soft graph the thread drew itself -- M needs no image after the first squaring.
 // The last power is written as float [row][68] into the free image and read back transposed for
 //   out[a][b] += (M^{d-1})[b][a] * tau * alpha * g (1 - g).
-// grid = (ceil(Sa / 2 / cpb) [+ score-estimator blocks], Mloc rounded up to 8; re-indexed XCD-aware inside), block = 256,
+// grid = (ceil(Sa / 2 / cpb), Mloc rounded up to 8; re-indexed XCD-aware inside), block = 256,
 // dynamic LDS = 2 * 24576
 //
 // Where the time goes at the headline size (2 048 blocks, 94 us; counters of scripts/probe/acyc_bf_probe.hip): 5.5 M MFMAs = 86 k cycles
@@ -169,7 +169,7 @@ __device__ __forceinline__ void abf_m0(const f32x4 (&g)[ABF_NT], f32x4 (&v)[ABF_
 template <bool FOUR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_acyc_bf(const float* __restrict__ scores, float* __restrict__ part, Key2 carry, int m0,
                                                  int M_global, int Mloc, int d, int Sa, int cpb, float alpha, float tau, int layout,
-                                                 int tiny, int n_acyc_blk, LikArgs lik) {
+                                                 int tiny, int n_acyc_blk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned char* const sb = reinterpret_cast<unsigned char*>(smem);
   // XCD-aware block order (grid = (blocks per particle, particles rounded up to 8)): workgroups go round-robin to the 8 XCDs in the
@@ -178,10 +178,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int L = blockIdx.x + gridDim.x * blockIdx.y, p_lo = L & 7, tq = L >> 3;
   const int bx = tq % (int)gridDim.x, m = (tq / (int)gridDim.x) * 8 + p_lo;
   if (m >= Mloc) return;  // (block-uniform)
-  if (bx >= n_acyc_blk) {  // score-estimator role (block-uniform): see lik_weights_block
-    lik_weights_block(sb, lik, m, bx - n_acyc_blk);
-    return;
-  }
   const int blk = bx, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g4 = lane >> 4, r = lane & 15;
   const int a = 16 * wave + r, b0 = 4 * g4;  // row; first column within a tile

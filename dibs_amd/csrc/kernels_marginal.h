@@ -4,7 +4,6 @@
 #include "common.h"
 
 #include "kernels_kmat.h"
-#include "kernels_lik.h"
 
 // ------------------------------------------------------------------------------------------------
 // particle init: z = normal(subk, (M, d, k, 2)) * std          svgd.py:145-146 / 509-510
@@ -70,83 +69,6 @@ __global__ __launch_bounds__(256) void k_edge_scores(const float* __restrict__ z
         probs[o] = row == col ? 0.f : pf;  // edge_probs (dibs.py:168-184), reused by the prior / estimator kernels
       }
     }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K7a total score-space gradient  W = W_lik - beta * mean_s(W_acyc) + W_prior   (elementwise; wide grid)
-//     reference: dibs.py:604-658 (latent prior), graph.py:93-108 / 182-196 (prior on edge probabilities)
-// grid = (Mloc, 4), block = 256
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_wtotal(const float* __restrict__ probs, const float* __restrict__ w_lik,
-                                                const float* __restrict__ acyc_part, int n_part, float* __restrict__ w_acyc,
-                                                float* __restrict__ w_tot, int d, int Sa, float alpha, float beta,
-                                                int prior_kind, float er_c) {
-  const int m = blockIdx.x, tid = threadIdx.x;
-  const size_t dd = (size_t)d * d;
-  const float inv_sa = 1.0f / (float)Sa;
-  const float* pm = probs + m * dd;
-  for (int e = blockIdx.y * 256 + tid; e < (int)dd; e += 256 * gridDim.y) {
-    const int i = e / d, j = e - i * d;
-    float ac = 0.f;
-    int q = 0;
-    for (; q + 4 <= n_part; q += 4) {  // loads in flight together, additions in fixed order
-      float v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = acyc_part[((size_t)m * n_part + q + u) * dd + e];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) ac += v[u];
-    }
-    for (; q < n_part; ++q) ac += acyc_part[((size_t)m * n_part + q) * dd + e];
-    ac *= inv_sa;
-    w_acyc[m * dd + e] = ac;
-    float pr = 0.f;
-    if (i != j && prior_kind != 2) {
-      const float p = pm[e];
-      const float dp = alpha * p * (1.0f - p);
-      if (prior_kind == 0) pr = er_c * dp;
-      else {
-        float cs = 0.f;  // soft in-degree of node j (graph.py:182-196)
-        for (int r = 0; r < d; ++r) cs += pm[r * d + j];
-        pr = (-3.0f / (1.0f + cs)) * dp;
-      }
-    }
-    w_tot[m * dd + e] = w_lik[m * dd + e] - beta * ac + pr;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K7b back-projection: grad = [W V, W^T U] - z / sigma^2, written next to a copy of z into the packed all-gather row
-//     [z | grad_z | theta | grad_theta].   (autodiff of dibs.py:179-180 in closed form)
-// grid = (Mloc, ZS), block = 256; block y handles rows i = y, y + ZS, ...; dynamic LDS = (d*d + 2*d*k) * 4
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_zgrad(const float* __restrict__ z, const float* __restrict__ w_tot,
-                                               float* __restrict__ pack, size_t pack_stride, int m0, int d, int k,
-                                               float inv_sig2) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Wm = smem;
-  float2* Zs = reinterpret_cast<float2*>(smem + (size_t)d * d);
-  const int m = blockIdx.x, tid = threadIdx.x;
-  const size_t dd = (size_t)d * d;
-  for (int e = tid; e < (int)dd; e += 256) Wm[e] = w_tot[m * dd + e];
-  const float2* zm = reinterpret_cast<const float2*>(z + (size_t)m * d * k * 2);
-  for (int e = tid; e < d * k; e += 256) Zs[e] = zm[e];
-  __syncthreads();
-  float* prow = pack + (size_t)(m0 + m) * pack_stride;
-  float2* pz = reinterpret_cast<float2*>(prow);
-  float2* pg = reinterpret_cast<float2*>(prow + (size_t)d * k * 2);
-  const int nrow = (d - blockIdx.y + gridDim.y - 1) / gridDim.y;
-  for (int e = tid; e < nrow * k; e += 256) {
-    const int i = blockIdx.y + (e / k) * gridDim.y, q = e % k;
-    float su = 0.f, sv = 0.f;
-    for (int j = 0; j < d; ++j) {
-      const float2 zj = Zs[j * k + q];
-      su = fmaf(Wm[i * d + j], zj.y, su);  // dU[i,q] = sum_j W[i,j] V[j,q]
-      sv = fmaf(Wm[j * d + i], zj.x, sv);  // dV[i,q] = sum_j W[j,i] U[j,q]
-    }
-    const float2 zi = Zs[i * k + q];
-    pz[i * k + q] = zi;
-    pg[i * k + q] = make_float2(su - zi.x * inv_sig2, sv - zi.y * inv_sig2);
   }
 }
 

@@ -1,0 +1,316 @@
+// per-particle tail of phase A (gfx950): score-estimator weights -> W_lik, total score-space gradient, back-projection onto Z.
+// One launch replaces k_lik_weights_score + k_wtotal + k_zgrad: each of those consumed only the particle's own data and
+// was latency-bound (three dependent launches of 9-15 us for ~1 GFLOP between them).
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// K4+K7  one block of 1024 threads per particle, everything staged in LDS:
+//   A  (BGe score estimator only)  l_s = sum_j node score, w = softmax(l) in double, baseline EMA        dibs.py:359-389
+//   B  W = W_lik - beta * mean_sa(W_acyc) + W_prior, W_lik = scale * alpha * (sum_s w_s G_s - P) offdiag   dibs.py:604-658,
+//      graph.py:93-108 / 182-196
+//   C  grad = [W V, W^T U] - z / sigma^2 on v_mfma_f32_16x16x4_f32 (k-ordered chains: bit-reproducible), written with a copy of z into
+//      the packed row [z | grad_z | ...]                                                                  (autodiff of dibs.py:179-180)
+// Other estimators (joint models, soft-graph BGe) hand W_lik over in global memory (node_scores == nullptr) and use B + C.
+// mean_sa(W_acyc) arrives reduced (k_acyc_reduce).  Sums run in a fixed order (samples ascending, j ascending): results do not depend
+// on the grid.  With one CU per particle the phases are latency chains, so every global input that does not depend on phase A is
+// requested before it.
+// grid = Mloc, block = 1024; dynamic LDS = tail_lds_bytes()
+// ------------------------------------------------------------------------------------------------
+#define TAIL_NT 1024
+#define TAIL_EPT 3   // elements of W per thread and pass whose inputs are prefetched
+struct TailArgs {
+  // A: score estimator
+  const double* node_scores;  // [Mloc][d][S]  (null: w_lik is an input)
+  const uint64_t* masks;      // [Mloc][d][S][W]
+  float* logprobs;            // [Mloc][S]
+  const float* baseline;
+  float* baseline_out;
+  double sf_baseline;
+  unsigned int* queue_counts;  // BGe queue counters of this step: consumed (stream order), reset here for the next step
+  int S, W, stage_cap;         // stage_cap: samples with non-zero weight whose parent sets fit in LDS (more: read through the caches)
+  // B
+  const float* probs;   // [Mloc][d][d]
+  float* w_lik;         // [Mloc][d][d]  output (A) or input
+  const float* w_acyc;  // [Mloc][d][d]  mean over the chains
+  float alpha, beta;
+  int prior_kind;
+  float er_c;
+  // C
+  const float* z;  // [Mloc][d][k][2]
+  float* pack;
+  size_t pack_stride;
+  int m0, d, k, ldz;
+  float inv_sig2;
+  unsigned long long* dbg;  // profiling: phase time stamps of block 0 (100 MHz ticks, accumulated in dbg[1..5]); null in production
+};
+
+__host__ __device__ inline int tail_nsplit(int S, int d) {
+  int n = TAIL_NT / (S > 0 ? S : 1);
+  n = n > 8 ? 8 : n;
+  n = n > d ? d : n;
+  return n < 1 ? 1 : n;
+}
+// LDS: [ W dp16 x (dp16 + 2) f32  UNION  phase-A scratch: lp S f64, lp2 nsplit*S f64, wt S f32 ] [U, V: kp4 x ldz f32 each] [colsum d f32]
+//      [nzw S f32] [nzi S i32] [staged parent sets cap*d*W u64]
+__host__ __device__ inline int tail_ldw(int d) { return ((d + 15) & ~15) + 2; }  // == 2 (mod 4): conflict-free MFMA A-operand reads
+__host__ __device__ inline size_t tail_union_bytes(int d, int S, bool lik) {
+  const size_t w = (size_t)((d + 15) & ~15) * tail_ldw(d) * 4, a = lik ? (size_t)S * 8 * (1 + tail_nsplit(S, d)) + (size_t)S * 4 : 0;
+  return ((w > a ? w : a) + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t tail_fixed_bytes(int d, int ldz, int S, bool lik) {
+  return (tail_union_bytes(d, S, lik) + ((size_t)2 * ((d + 3) & ~3) * ldz + d) * 4 + (lik ? (size_t)S * 8 : 0) + 15) & ~(size_t)15;
+}
+// row stride of the U / V images: >= k rounded up to the 16-column tiles; == 16 (mod 32) keeps the B-operand reads conflict-free
+__host__ inline int tail_ldz(int d, int k, int S, bool lik, size_t lds_limit) {
+  const int kq = (k + 15) & ~15, want = (kq & 16) ? kq : kq + 16;
+  return tail_fixed_bytes(d, want, S, lik) <= lds_limit ? want : kq;
+}
+__host__ inline int tail_stage_cap(int d, int ldz, int S, int W, size_t lds_limit) {
+  const size_t fixed = tail_fixed_bytes(d, ldz, S, true);
+  if (fixed >= lds_limit) return 0;
+  const size_t c = (lds_limit - fixed) / ((size_t)d * W * 8);
+  return (int)(c > (size_t)S ? (size_t)S : c);
+}
+__host__ inline size_t tail_lds_bytes(int d, int ldz, int S, int W, bool lik, int stage_cap) {
+  return tail_fixed_bytes(d, ldz, S, lik) + (lik ? (size_t)stage_cap * d * W * 8 : 0);
+}
+
+__global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = A.d, k = A.k, S = A.S, W = A.W, ldz = A.ldz;
+  const int dd = d * d, dp16 = (d + 15) & ~15, kp4 = (d + 3) & ~3, ldw = tail_ldw(d);
+  const bool lik = A.node_scores != nullptr;
+  const int nsplit = tail_nsplit(S, d);
+  float* Wm = reinterpret_cast<float*>(smem_raw);    // phase B / C ...
+  double* lp = reinterpret_cast<double*>(smem_raw);  // ... phase A scratch in the same bytes
+  double* lp2 = lp + S;
+  float* wt = reinterpret_cast<float*>(lp2 + (size_t)nsplit * S);
+  float* Us = reinterpret_cast<float*>(smem_raw + tail_union_bytes(d, S, lik));
+  float* Vs = Us + (size_t)kp4 * ldz;
+  float* cs = Vs + (size_t)kp4 * ldz;
+  float* nzw = cs + d;
+  int* nzi = reinterpret_cast<int*>(nzw + S);
+  uint64_t* mk = reinterpret_cast<uint64_t*>(smem_raw + tail_fixed_bytes(d, ldz, S, true));
+  __shared__ double red[2 * (TAIL_NT / 64)];
+  __shared__ int nnz_s;
+
+  // ---- requests that do not depend on phase A: Z (-> U / V images), this thread's first elements of mean(W_acyc), the edge
+  // probabilities (and W_lik of the other estimators), the soft in-degrees of the scale-free prior
+  const float* pm = A.probs + (size_t)m * dd;
+  const float* wag = A.w_acyc + (size_t)m * dd;
+  float* wlg = A.w_lik + (size_t)m * dd;
+  float pa[TAIL_EPT], pp[TAIL_EPT], pw[TAIL_EPT];
+#pragma unroll
+  for (int u = 0; u < TAIL_EPT; ++u) {
+    const int e = u * TAIL_NT + tid;
+    pa[u] = e < dd ? wag[e] : 0.f;
+    pp[u] = e < dd ? pm[e] : 0.f;
+    pw[u] = (e < dd && !lik) ? wlg[e] : 0.f;
+  }
+  const float2* zm = reinterpret_cast<const float2*>(A.z + (size_t)m * d * k * 2);
+  for (int e = tid; e < d * k; e += TAIL_NT) {
+    const int j = e / k, q = e - j * k;
+    const float2 uv = zm[e];
+    Us[j * ldz + q] = uv.x;
+    Vs[j * ldz + q] = uv.y;
+  }
+  for (int e = tid; e < (kp4 - d) * ldz; e += TAIL_NT) {  // k-step padding rows of the MFMA operands
+    Us[d * ldz + e] = 0.f;
+    Vs[d * ldz + e] = 0.f;
+  }
+  if (A.prior_kind == 1)
+    for (int j = tid; j < d; j += TAIL_NT) {
+      float c = 0.f;
+      for (int r = 0; r < d; ++r) c += pm[r * d + j];  // graph.py:182-196
+      cs[j] = c;
+    }
+
+  unsigned long long ts[6];
+  ts[0] = ts[1] = wall_clock64();
+  int nnz = 0;
+  float scale = 1.0f;
+  bool staged = false;
+  if (lik) {
+    if (A.queue_counts && m == 0 && tid < 16) A.queue_counts[tid] = 0u;  // (16 counters are allocated; BGE_NQ used)
+    // ---- A. l_s = sum_j node score: nsplit threads per sample, each a contiguous range of j, loads batched; the partial sums
+    // are combined in part order
+    const double* nsm = A.node_scores + (size_t)m * d * S;
+    const int jw = (d + nsplit - 1) / nsplit;
+    for (int idx = tid; idx < nsplit * S; idx += TAIL_NT) {
+      const int part = idx / S, s = idx - part * S;
+      const int j0 = part * jw, j1 = (j0 + jw < d) ? j0 + jw : d;
+      double t = 0.0;
+      int j = j0;
+      for (; j + 8 <= j1; j += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = nsm[(size_t)(j + u) * S + s];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+      }
+      {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (j + u < j1) ? nsm[(size_t)(j + u) * S + s] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += (j + u < j1) ? v[u] : 0.0;
+      }
+      lp2[(size_t)part * S + s] = t;
+    }
+    __syncthreads();
+    for (int s = tid; s < S; s += TAIL_NT) {
+      double t = lp2[s];
+      for (int p = 1; p < nsplit; ++p) t += lp2[(size_t)p * S + s];
+      lp[s] = t;
+      A.logprobs[(size_t)m * S + s] = (float)t;
+    }
+    __syncthreads();
+    constexpr int NW = TAIL_NT / 64;
+    double mx = -INFINITY;
+    for (int s = tid; s < S; s += TAIL_NT) mx = lp[s] > mx ? lp[s] : mx;
+    mx = wave_max_d(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+    for (int w = 1; w < NW; ++w) mx = red[w] > mx ? red[w] : mx;
+    double den = 0.0, sm = 0.0;
+    for (int s = tid; s < S; s += TAIL_NT) {
+      den += exp(lp[s] - mx);
+      sm += lp[s];
+    }
+    den = wave_sum_d(den);
+    sm = wave_sum_d(sm);
+    __syncthreads();
+    if (lane == 0) {
+      red[wave] = den;
+      red[NW + wave] = sm;
+    }
+    __syncthreads();
+    den = 0.0;
+    sm = 0.0;
+    for (int w = 0; w < NW; ++w) {
+      den += red[w];
+      sm += red[NW + w];
+    }
+    for (int s = tid; s < S; s += TAIL_NT) wt[s] = (float)(exp(lp[s] - mx) / den);
+    __syncthreads();
+    // in float most softmax weights are exactly 0 while the particles still differ (one-hot in the limit): only samples with
+    // w_s != 0 are visited, in sample order, so the sum is bit-identical to the full loop
+    if (wave == 0) {
+      int base = 0;
+      for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane;
+        const float w = s < S ? wt[s] : 0.f;
+        const unsigned long long bal = __ballot(w != 0.f);
+        if (w != 0.f) {
+          const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+          nzi[pos] = s;
+          nzw[pos] = w;
+        }
+        base += __popcll(bal);
+      }
+      if (lane == 0) nnz_s = base;
+    }
+    __syncthreads();
+    ts[1] = wall_clock64();
+    nnz = nnz_s;
+    const float bold = A.baseline[m];
+    scale = A.sf_baseline > 0.0 ? (float)exp(-(double)bold) : 1.0f;
+    if (tid == 0) A.baseline_out[m] = (float)(A.sf_baseline * (sm / S) + (1.0 - A.sf_baseline) * (double)bold);
+    // parent sets of the visited samples: [q][j][w]
+    staged = nnz <= A.stage_cap;
+    const uint64_t* mg = A.masks + (size_t)m * d * S * W;  // [j][s][w]
+    if (staged) {
+      for (int e = tid; e < nnz * d * W; e += TAIL_NT) {
+        const int q = e / (d * W), r = e - q * (d * W), j = r / W, w = r - j * W;
+        mk[e] = mg[((size_t)j * S + nzi[q]) * W + w];
+      }
+    }
+  }
+  __syncthreads();  // (phase A's scratch is dead: W takes its place)
+  ts[2] = wall_clock64();
+  for (int e = tid; e < dp16 * ldw; e += TAIL_NT) Wm[e] = 0.f;  // padding rows / columns of the MFMA operand
+  __syncthreads();
+
+  // ---- B. total score-space gradient of this particle -> LDS
+  {
+    const uint64_t* mg = A.masks + (size_t)m * d * S * W;
+    for (int e0 = 0; e0 < dd; e0 += TAIL_EPT * TAIL_NT) {
+      if (e0) {
+#pragma unroll
+        for (int u = 0; u < TAIL_EPT; ++u) {
+          const int e = e0 + u * TAIL_NT + tid;
+          pa[u] = e < dd ? wag[e] : 0.f;
+          pp[u] = e < dd ? pm[e] : 0.f;
+          pw[u] = (e < dd && !lik) ? wlg[e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TAIL_EPT; ++u) {
+        const int e = e0 + u * TAIL_NT + tid;
+        if (e >= dd) continue;
+        const int i = e / d, j = e - i * d;
+        const float p = pp[u];
+        float wl = pw[u];
+        if (lik) {
+          if (i != j) {
+            float acc = 0.f;
+            const int w = i >> 6;
+            const uint64_t bit = 1ull << (i & 63);
+            if (staged) {
+              for (int qq = 0; qq < nnz; ++qq) acc += (mk[((size_t)qq * d + j) * W + w] & bit) ? nzw[qq] : 0.f;
+            } else {
+              for (int qq = 0; qq < nnz; ++qq) acc += (mg[((size_t)j * S + nzi[qq]) * W + w] & bit) ? nzw[qq] : 0.f;
+            }
+            wl = scale * A.alpha * (acc - p);
+          }
+          wlg[e] = wl;
+        }
+        float pr = 0.f;
+        if (i != j && A.prior_kind != 2) {
+          const float dp = A.alpha * p * (1.0f - p);
+          pr = A.prior_kind == 0 ? A.er_c * dp : (-3.0f / (1.0f + cs[j])) * dp;
+        }
+        Wm[i * ldw + j] = wl - A.beta * pa[u] + pr;
+      }
+    }
+  }
+  __syncthreads();
+
+  ts[3] = wall_clock64();
+  // ---- C. back-projection: dU = W V, dV = W^T U, one 16 x 16 tile of both per wave and pass
+  // MFMA operands: A[row = lane % 16][k = lane / 16], B[k = lane / 16][col = lane % 16], D[row = 4 (lane / 16) + r][col = lane % 16]
+  float* prow = A.pack + (size_t)(A.m0 + m) * A.pack_stride;
+  float2* pz = reinterpret_cast<float2*>(prow);
+  float2* pg = reinterpret_cast<float2*>(prow + (size_t)d * k * 2);
+  const int ntj = (k + 15) >> 4, ntiles = (dp16 >> 4) * ntj, g = lane >> 4, r = lane & 15;
+  for (int t = wave; t < ntiles; t += TAIL_NT / 64) {
+    const int ti = t / ntj, tj = t - ti * ntj;
+    f32x4 du = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+    const float* wa = Wm + (ti * 16 + r) * ldw + g;   // W[i = ti*16 + r][j = k0 + g]
+    const float* wtr = Wm + g * ldw + ti * 16 + r;    // W[j = k0 + g][i = ti*16 + r]
+    const float* vb = Vs + g * ldz + tj * 16 + r;     // V[j = k0 + g][q = tj*16 + r]
+    const float* ub = Us + g * ldz + tj * 16 + r;
+    for (int k0 = 0; k0 < kp4; k0 += 4) {
+      du = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k0], vb[k0 * ldz], du, 0, 0, 0);
+      dv = __builtin_amdgcn_mfma_f32_16x16x4f32(wtr[k0 * ldw], ub[k0 * ldz], dv, 0, 0, 0);
+    }
+    const int q = tj * 16 + r;
+    if (q < k) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int i = ti * 16 + 4 * g + rr;
+        if (i < d) {
+          const float2 zi = make_float2(Us[i * ldz + q], Vs[i * ldz + q]);
+          pz[i * k + q] = zi;
+          pg[i * k + q] = make_float2(du[rr] - zi.x * A.inv_sig2, dv[rr] - zi.y * A.inv_sig2);
+        }
+      }
+    }
+  }
+  ts[4] = wall_clock64();
+  if (A.dbg && m == 0 && tid == 0)
+    for (int u = 1; u < 5; ++u) atomicAdd(A.dbg + u, ts[u] - ts[u - 1]);
+}

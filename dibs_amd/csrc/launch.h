@@ -3,7 +3,6 @@
 #pragma once
 #include "common.h"
 #include "kernels_kmat.h"
-#include "kernels_lik.h"
 #include "kernels_bge.h"
 
 // ---- tu_bge.hip --------------------------------------------------------------------------------------
@@ -19,10 +18,11 @@ void bge_launch_sum_nodes(hipStream_t stream, const double* node_scores, float* 
 struct AcycLaunch {
   hipStream_t stream;
   const float* scores;
-  float* part;
+  float* part;            // [Mloc][nblk][d*d] partial sums of the blocks
+  float* w_acyc;          // [Mloc][d*d] mean over the chains (k_acyc_reduce, same stream)
   Key2 carry;
   int m0, M, Mloc, d, Sa, cpb, units, nblk;  // units != Sa: chains are taken in Threefry pairs
   float alpha, tau;
   int layout, tiny;
 };
-void acyc_launch(const AcycLaunch& a, const LikArgs& lik, int lik_blocks, size_t lik_lds);
+void acyc_launch(const AcycLaunch& a);

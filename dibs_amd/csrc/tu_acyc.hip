@@ -6,20 +6,19 @@
 #include <stdlib.h>
 
 template <int NT>
-static void launch_nt(const AcycLaunch& a, const LikArgs& lik, int lik_blocks, size_t lik_lds) {
+static void launch_nt(const AcycLaunch& a) {
   constexpr int DP = 16 * NT, LD = DP + 4;
   size_t lds = (size_t)(3 * DP + 1) * LD * 4;  // + one slack row (the k pipeline may load one step past the end)
-  if (lik_blocks && lik_lds > lds) lds = lik_lds;
   const bool paired = a.units != a.Sa;
-  const dim3 grid(a.nblk + lik_blocks, a.Mloc);  // blockIdx.x >= nblk: score-estimator blocks riding along
+  const dim3 grid(a.nblk, a.Mloc);
   if (paired) {
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_acyc<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_acyc<NT, true>), grid, dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.d, a.Sa, a.cpb, a.alpha,
-                       a.tau, a.layout, a.tiny, a.nblk, lik);
+                       a.tau, a.layout, a.tiny, a.nblk);
   } else {
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_acyc<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_acyc<NT, false>), grid, dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.d, a.Sa, a.cpb, a.alpha,
-                       a.tau, a.layout, a.tiny, a.nblk, lik);
+                       a.tau, a.layout, a.tiny, a.nblk);
   }
 }
 
@@ -29,11 +28,16 @@ static bool acyc_use_bf16(const AcycLaunch& a) {
   return !off && a.units != a.Sa && a.d > 32 && a.d <= 64;
 }
 
-void acyc_launch(const AcycLaunch& a, const LikArgs& lik, int lik_blocks, size_t lik_lds) {
+static void acyc_launch_power(const AcycLaunch& a);
+void acyc_launch(const AcycLaunch& a) {
+  acyc_launch_power(a);
+  const int dd = a.d * a.d;
+  hipLaunchKernelGGL(k_acyc_reduce, dim3(a.Mloc, (dd + 255) / 256), dim3(256), 0, a.stream, a.part, a.w_acyc, a.nblk, dd, 1.0f / (float)a.Sa);
+}
+static void acyc_launch_power(const AcycLaunch& a) {
   if (acyc_use_bf16(a)) {
     size_t lds = 2 * ABF_IMG_BYTES;
-    if (lik_blocks && lik_lds > lds) lds = lik_lds;
-    const dim3 grid(a.nblk + lik_blocks, (a.Mloc + 7) & ~7);
+      const dim3 grid(a.nblk, (a.Mloc + 7) & ~7);
     if (a.d > 48) {
       static size_t lds_set = 0;
       if (lds > lds_set) {
@@ -41,7 +45,7 @@ void acyc_launch(const AcycLaunch& a, const LikArgs& lik, int lik_blocks, size_t
         lds_set = lds;
       }
       hipLaunchKernelGGL(k_acyc_bf<true>, grid, dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.Mloc, a.d, a.Sa, a.cpb, a.alpha,
-                         a.tau, a.layout, a.tiny, a.nblk, lik);
+                         a.tau, a.layout, a.tiny, a.nblk);
     } else {
       static size_t lds_set = 0;
       if (lds > lds_set) {
@@ -49,17 +53,17 @@ void acyc_launch(const AcycLaunch& a, const LikArgs& lik, int lik_blocks, size_t
         lds_set = lds;
       }
       hipLaunchKernelGGL(k_acyc_bf<false>, grid, dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.Mloc, a.d, a.Sa, a.cpb, a.alpha,
-                         a.tau, a.layout, a.tiny, a.nblk, lik);
+                         a.tau, a.layout, a.tiny, a.nblk);
     }
     return;
   }
   switch ((a.d + 15) / 16) {
-    case 1: launch_nt<1>(a, lik, lik_blocks, lik_lds); break;
-    case 2: launch_nt<2>(a, lik, lik_blocks, lik_lds); break;
-    case 3: launch_nt<3>(a, lik, lik_blocks, lik_lds); break;
-    case 4: launch_nt<4>(a, lik, lik_blocks, lik_lds); break;
-    case 5: launch_nt<5>(a, lik, lik_blocks, lik_lds); break;
-    case 6: launch_nt<6>(a, lik, lik_blocks, lik_lds); break;
-    default: launch_nt<7>(a, lik, lik_blocks, lik_lds); break;
+    case 1: launch_nt<1>(a); break;
+    case 2: launch_nt<2>(a); break;
+    case 3: launch_nt<3>(a); break;
+    case 4: launch_nt<4>(a); break;
+    case 5: launch_nt<5>(a); break;
+    case 6: launch_nt<6>(a); break;
+    default: launch_nt<7>(a); break;
   }
 }
