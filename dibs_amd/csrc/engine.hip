@@ -11,7 +11,8 @@
 #define DIBS_TU_ENGINE
 #include "../../include/dibs_hip.h"
 #include "launch.h"
-#include <unordered_map>
+#include <map>
+#include <mutex>
 #include "kernels_marginal.h"
 #include "kernels_tail.h"
 #include "kernels_joint.h"
@@ -261,6 +262,9 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
     if (c.n_vars > 64 || bge_soft_waves(c.n_vars, false) < 1)
       return fail("BGe + reparam estimator: n_vars must be <= 64 on the device");
   }
+  if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_SCORE &&
+      bge_sample_lds_bytes(c.n_vars, c.n_grad_mc_samples, (c.n_vars + 63) / 64) > LDS_LIMIT - 2048)
+    return fail("BGe: n_grad_mc_samples too large (the parent sets of one node's samples are staged in LDS)");
   if (c.likelihood == DIBS_LIK_DENSENN) {
     // one hidden layer of <= 64 units with <= 128 observations runs on the MFMA kernels of kernels_nn.h, every other stack on the
     // general path of kernels_nn_generic.h
@@ -435,9 +439,12 @@ extern "C" int dibs_engine_set_data(dibs_engine* e, const float* x, const int32_
   if (!e || !x) return fail("null argument");
   HIP_OK(hipSetDevice(e->cfg.device_id));
   HIP_OK(hipStreamSynchronize(e->stream));
+  e->has_data = false;  // (a failure below leaves the engine without data: the next step reports it instead of reading freed statistics)
   const size_t n = (size_t)e->N * e->d;
   if (e->x) hipFree(e->x);
   if (e->mask) hipFree(e->mask);
+  e->x = nullptr;
+  e->mask = nullptr;
   HIP_OK(dalloc(&e->x, n));
   HIP_OK(dalloc(&e->mask, n));
   HIP_OK(hipMemcpy(e->x, x, n * 4, hipMemcpyHostToDevice));
@@ -522,19 +529,24 @@ extern "C" int dibs_engine_get_state(dibs_engine* e, float* z, float* v_z, float
   return 0;
 }
 
-// kernels that may need more than the default 64 KiB of dynamic LDS
-template <typename K>
-static void allow_lds(K kernel, size_t bytes) {
-  // (one attribute call per kernel instantiation and size increase, not one per launch: K is a distinct function type only per
-  //  signature, so the high-water mark is kept per function pointer)
-  static std::unordered_map<const void*, size_t> granted;
+// kernels that may need more than the default 64 KiB of dynamic LDS (see launch.h).  One attribute call per (device, kernel) and size
+// increase, not one per launch; the table is shared by every engine of the process, so it is keyed by device and guarded by a mutex
+// (ctypes releases the GIL: two engines may be stepped from two host threads).
+void dibs_allow_lds(const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> granted;
   if (bytes <= 48 * 1024) return;
-  size_t& g = granted[(const void*)kernel];
+  int dev = 0;
+  hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& g = granted[{dev, kernel}];
   if (bytes > g) {
-    hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     g = bytes;
   }
 }
+template <typename K>
+static void allow_lds(K kernel, size_t bytes) { dibs_allow_lds((const void*)kernel, bytes); }
 
 // ---- profiling helpers -----------------------------------------------------------------------
 struct KTimer {
@@ -604,7 +616,9 @@ static int step_local(dibs_engine* e, int t, float* pack) {
   // While per-kernel timing is on (set_profiling(1)) the main stream joins right away, so that every duration is a kernel alone on the
   // GPU -- but the launch still goes to the second stream: with that (high-priority) queue in existence the same kernel takes 104 us
   // on the main stream and 96 us on its own.
-  const bool fork = e->stream2 != nullptr, join_now = e->profiling && !e->profiling_concurrent;
+  // (a small acyclicity launch -- <= 512 blocks: config 2, or a rank of a sharded headline run -- stays on the main stream: the fork / join
+  //  events cost 6 + 6 us of the critical path, more than such a launch can hide; measured at config 2: 16 100 -> see DESIGN.md)
+  const bool fork = e->stream2 != nullptr && (long)e->acyc_nblk * e->Mloc > 512, join_now = e->profiling && !e->profiling_concurrent;
   if (fork) {
     hipEventRecord(e->ev_fork, e->stream);
     hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
@@ -686,11 +700,12 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     const NNParams np_ = nn_params(c);
     {
       KTimer tm(e, DIBS_K_NN_THETA);
-      joint_nn_dispatch(&e->jw, jl, carry_theta, LIN_MODE_THETA, np_, (size_t)e->P);
+      if (joint_nn_dispatch(&e->jw, jl, carry_theta, LIN_MODE_THETA, np_, (size_t)e->P)) return fail("DenseNonlinearGaussian: scratch area: hipMalloc failed");
     }
     {
       KTimer tm(e, DIBS_K_NN_Z);
-      joint_nn_dispatch(&e->jw, jl, carry_lik, c.grad_estimator_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM, np_, (size_t)e->P);
+      if (joint_nn_dispatch(&e->jw, jl, carry_lik, c.grad_estimator_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM, np_, (size_t)e->P))
+        return fail("DenseNonlinearGaussian: scratch area: hipMalloc failed");
       std::swap(e->baseline, e->baseline2);
     }
   }
@@ -980,7 +995,7 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
     HIP_OK(hipMemcpy(d_g.p, g, (size_t)n * dd * 4, hipMemcpyHostToDevice));
     if (nn) {
       const NNParams np_ = nn_params(c);
-      joint_nn_score_given(jg.jw, d_th.p, d_g.p, d_out.p, n, d, n_ho, np_, P, e->stream);
+      if (joint_nn_score_given(jg.jw, d_th.p, d_g.p, d_out.p, n, d, n_ho, np_, P, e->stream)) return fail("DenseNonlinearGaussian: scratch area: hipMalloc failed");
     } else {
       joint_lin_score_given(jg.jw, d_th.p, d_g.p, d_out.p, n, d, n_ho, (float)c.lin_obs_noise, (float)c.lin_mean_edge,
                             (float)c.lin_sig_edge, e->stream);

@@ -487,8 +487,9 @@ __global__ void k_init_theta_nn(float* __restrict__ theta, size_t P, Key2 key, i
 // ---- host side (defined in tu_nn.hip) ---------------------------------------------------------------
 // true: the tuned one-hidden-layer kernels of this file apply; false: the general path of kernels_nn_generic.h runs
 bool joint_nn_fast_path(int d, int N, const NNParams& np_);
-void joint_nn_dispatch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P);
-void joint_nn_score_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N, const NNParams& np_,
+// (both return non-zero when the scratch area of the general path cannot be allocated)
+int joint_nn_dispatch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P);
+int joint_nn_score_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N, const NNParams& np_,
                           size_t P, hipStream_t stream);
 // theta = stax initialisation stream of sample_parameters (nonlinearGaussian.py:155-186)
 void joint_nn_init_theta(float* theta, size_t P, Key2 key, int m0, int Mloc, int M, int d, const NNParams& np_, int layout, hipStream_t stream);
@@ -540,31 +541,35 @@ static float* nng_scratch(JointWork* w, size_t floats) {
   return w->nng_scratch;
 }
 
-static void joint_nng_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_) {
+// blocks of the persistent log-prob kernel (each owns 256 * hsum floats of activation records)
+static int nng_blocks(long work) { return (int)(work < 2048 ? work : 2048); }
+
+static int joint_nng_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_) {
   const NNNet net = nn_net(jl.d, np_);
   const size_t lds = (((size_t)jl.d * jl.d + 3) & ~(size_t)3) * 4 + 128;
-  const size_t need1 = (size_t)jl.S * jl.Mloc * 256 * net.hsum, need2 = (size_t)jl.Mloc * 2 * net.hsum * jl.d * jl.N;
+  const int nb = nng_blocks((long)jl.S * jl.Mloc);
+  const size_t need1 = (size_t)nb * 256 * net.hsum, need2 = (size_t)jl.Mloc * 2 * net.hsum * jl.d * jl.N;
   float* scr = nng_scratch(w, need1 > need2 ? need1 : need2);
-  if (!scr) return;  // (the next hipGetLastError / sync reports the failed allocation)
+  if (!scr) return 1;
   float* lp = mode == LIN_MODE_THETA ? jl.logprobs_th : jl.logprobs_z;
   if (lds > 48 * 1024) {
     hipFuncSetAttribute((const void*)k_nng_logprobs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)k_nng_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  hipLaunchKernelGGL(k_nng_logprobs, dim3(jl.S, jl.Mloc), dim3(256), lds, jl.stream, w->x, w->mask, jl.theta, jl.scores, jl.thr, lp, carry, mode,
-                     jl.m0, jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, w->any_mask, scr);
+  hipLaunchKernelGGL(k_nng_logprobs, dim3(nb), dim3(256), lds, jl.stream, w->x, w->mask, jl.theta, jl.scores, jl.thr, lp, carry, mode,
+                     jl.m0, jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, w->any_mask, scr, jl.Mloc);
   float* out = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off : jl.w_lik;
   const size_t ostride = mode == LIN_MODE_THETA ? jl.pack_stride : (size_t)jl.d * jl.d;
   float* tcopy = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr;
   hipLaunchKernelGGL(k_nng_grad, dim3(jl.Mloc), dim3(256), lds, jl.stream, w->x, w->mask, jl.theta, jl.scores, jl.thr, lp, out, ostride, tcopy,
                      jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S,
                      jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask, scr);
+  return 0;
 }
 
-void joint_nn_dispatch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P) {
+int joint_nn_dispatch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P) {
   if (!joint_nn_fast_path(jl.d, jl.N, np_)) {
-    joint_nng_launch(w, jl, carry, mode, np_);
-    return;
+    return joint_nng_launch(w, jl, carry, mode, np_);
   }
   switch ((jl.d + 15) / 16) {
     case 1: joint_nn_launch<1>(w, jl, carry, mode, np_, P); break;
@@ -575,6 +580,7 @@ void joint_nn_dispatch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode
     case 6: joint_nn_launch<6>(w, jl, carry, mode, np_, P); break;
     default: joint_nn_launch<7>(w, jl, carry, mode, np_, P); break;
   }
+  return 0;
 }
 
 template <int NT>
@@ -586,17 +592,18 @@ static void launch_nn_given(const JointWork& jw, const float* theta, const int32
                      reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, N, 1, 1, 0.f, 1.f, 0, 0, np_,
                      jw.any_mask, (const float*)nullptr);
 }
-void joint_nn_score_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N, const NNParams& np_,
-                          size_t P, hipStream_t stream) {
+int joint_nn_score_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N, const NNParams& np_,
+                         size_t P, hipStream_t stream) {
   if (!joint_nn_fast_path(d, N, np_)) {
     const NNNet net = nn_net(d, np_);
     const size_t lds = (((size_t)d * d + 3) & ~(size_t)3) * 4 + 128;
-    float* scr = nng_scratch(const_cast<JointWork*>(&jw), (size_t)n * 256 * net.hsum);
-    if (!scr) return;
+    const int nb = nng_blocks(n);
+    float* scr = nng_scratch(const_cast<JointWork*>(&jw), (size_t)nb * 256 * net.hsum);
+    if (!scr) return 1;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_nng_logprobs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_nng_logprobs, dim3(1, n), dim3(256), lds, stream, jw.x, jw.mask, theta, (const float*)nullptr,
-                       reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, N, 1, 0.f, 1.f, 0, 0, np_, jw.any_mask, scr);
-    return;
+    hipLaunchKernelGGL(k_nng_logprobs, dim3(nb), dim3(256), lds, stream, jw.x, jw.mask, theta, (const float*)nullptr,
+                       reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, N, 1, 0.f, 1.f, 0, 0, np_, jw.any_mask, scr, n);
+    return 0;
   }
   switch ((d + 15) / 16) {
     case 1: launch_nn_given<1>(jw, theta, g, out, n, d, N, np_, P, stream); break;
@@ -607,6 +614,7 @@ void joint_nn_score_given(const JointWork& jw, const float* theta, const int32_t
     case 6: launch_nn_given<6>(jw, theta, g, out, n, d, N, np_, P, stream); break;
     default: launch_nn_given<7>(jw, theta, g, out, n, d, N, np_, P, stream); break;
   }
+  return 0;
 }
 void joint_nn_init_theta(float* theta, size_t P, Key2 key, int m0, int Mloc, int M, int d, const NNParams& np_, int layout, hipStream_t stream) {
   const int nt = Mloc * d;

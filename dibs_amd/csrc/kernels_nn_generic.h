@@ -86,55 +86,60 @@ __global__ __launch_bounds__(256) void k_nng_logprobs(const float* __restrict__ 
                                                       const float* __restrict__ theta, const float* __restrict__ scores,
                                                       const uint32_t* __restrict__ thr, float* __restrict__ logprobs, Key2 carry, int mode,
                                                       int m0, int M_global, int d, int N, int S, float alpha, float tau, int layout,
-                                                      int tiny, NNParams np_, int any_mask, float* __restrict__ scratch) {
+                                                      int tiny, NNParams np_, int any_mask, float* __restrict__ scratch, int n_m) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* GS = smem;
   double* red = reinterpret_cast<double*>(smem + (((size_t)d * d + 3) & ~(size_t)3));
   const NNNet net = nn_net(d, np_);
-  const int m = blockIdx.y, s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t dd = (size_t)d * d;
-  const float* th_m = theta + (size_t)m * net.P;
-  const Key2 key = (mode == LIN_MODE_GIVEN) ? Key2{0, 0} : lin_mode_key(mode, carry, M_global, m0 + m, layout);
   const uint64_t nbits = (uint64_t)S * dd;
-  const uint32_t* thr_m = thr + (size_t)m * dd;
-  const float* sc_m = scores ? scores + (size_t)m * dd : nullptr;
-  for (int e = tid; e < (int)dd; e += 256) {
-    const int a = e / d, j = e - a * d;
-    GS[e] = lin_sample_g(mode, key, nbits, dd, s, a, j, d, thr_m, sc_m, alpha, tau, layout, tiny);
-  }
-  __syncthreads();
-  // prior: every leaf N(0, sig_param); first-layer weights weighted by g[a][j]   (nonlinearGaussian.py:260-272)
-  float part = 0.f;
-  for (int l = 0; l < net.nl; ++l) {
-    const int in = net.sizes[l], out = net.sizes[l + 1];
-    const long nw = (long)d * in * out;
-    for (long e = tid; e < nw; e += 256) {
-      const float lw = lin_logn(th_m[net.woff[l] + e], 0.f, np_.sig_param);
-      if (l == 0) {
-        const int a = (int)((e / out) % in), j = (int)(e / ((long)in * out));
-        part = fmaf(GS[a * d + j], lw, part);
-      } else {
-        part += lw;
-      }
+  // persistent blocks: the activation records (256 * hsum floats per block) are sized by the grid, not by S * n_m
+  float* rec = scratch + (size_t)blockIdx.x * 256 * (size_t)net.hsum + tid;
+  for (long wi = blockIdx.x; wi < (long)S * n_m; wi += gridDim.x) {
+    const int m = (int)(wi / S), s = (int)(wi - (long)m * S);
+    const float* th_m = theta + (size_t)m * net.P;
+    const Key2 key = (mode == LIN_MODE_GIVEN) ? Key2{0, 0} : lin_mode_key(mode, carry, M_global, m0 + m, layout);
+    const uint32_t* thr_m = thr + (size_t)m * dd;
+    const float* sc_m = scores ? scores + (size_t)m * dd : nullptr;
+    for (int e = tid; e < (int)dd; e += 256) {
+      const int a = e / d, j = e - a * d;
+      GS[e] = lin_sample_g(mode, key, nbits, dd, s, a, j, d, thr_m, sc_m, alpha, tau, layout, tiny);
     }
-    if (np_.bias)
-      for (long e = tid; e < (long)d * out; e += 256) part += lin_logn(th_m[net.boff[l] + e], 0.f, np_.sig_param);
+    __syncthreads();
+    // prior: every leaf N(0, sig_param); first-layer weights weighted by g[a][j]   (nonlinearGaussian.py:260-272)
+    float part = 0.f;
+    for (int l = 0; l < net.nl; ++l) {
+      const int in = net.sizes[l], out = net.sizes[l + 1];
+      const long nw = (long)d * in * out;
+      for (long e = tid; e < nw; e += 256) {
+        const float lw = lin_logn(th_m[net.woff[l] + e], 0.f, np_.sig_param);
+        if (l == 0) {
+          const int a = (int)((e / out) % in), j = (int)(e / ((long)in * out));
+          part = fmaf(GS[a * d + j], lw, part);
+        } else {
+          part += lw;
+        }
+      }
+      if (np_.bias)
+        for (long e = tid; e < (long)d * out; e += 256) part += lin_logn(th_m[net.boff[l] + e], 0.f, np_.sig_param);
+    }
+    // likelihood
+    const float inv2 = 0.5f / np_.obs_noise;
+    const float lognorm_x = -0.5f * logf(np_.obs_noise) - 0.918938533204672742f;
+    for (int it = tid; it < d * N; it += 256) {
+      const int j = it / N, n = it - j * N;
+      if (any_mask && mask[(size_t)n * d + j]) continue;
+      const float mean = nng_forward(net, np_, th_m, x, GS, d, j, n, rec, 256);
+      const float e = x[(size_t)n * d + j] - mean;
+      part += lognorm_x - inv2 * e * e;
+    }
+    const double tot = wave_sum_d((double)part);
+    if (lane == 0) red[wave] = tot;
+    __syncthreads();
+    if (tid == 0) logprobs[(size_t)m * S + s] = (float)(red[0] + red[1] + red[2] + red[3]);
+    __syncthreads();  // GS / red are rewritten by the next work item
   }
-  // likelihood
-  const float inv2 = 0.5f / np_.obs_noise;
-  const float lognorm_x = -0.5f * logf(np_.obs_noise) - 0.918938533204672742f;
-  float* rec = scratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 * (size_t)net.hsum + tid;
-  for (int it = tid; it < d * N; it += 256) {
-    const int j = it / N, n = it - j * N;
-    if (any_mask && mask[(size_t)n * d + j]) continue;
-    const float mean = nng_forward(net, np_, th_m, x, GS, d, j, n, rec, 256);
-    const float e = x[(size_t)n * d + j] - mean;
-    part += lognorm_x - inv2 * e * e;
-  }
-  const double tot = wave_sum_d((double)part);
-  if (lane == 0) red[wave] = tot;
-  __syncthreads();
-  if (tid == 0) logprobs[(size_t)m * S + s] = (float)(red[0] + red[1] + red[2] + red[3]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -5,6 +5,10 @@
 #include "kernels_kmat.h"
 #include "kernels_bge.h"
 
+// kernels that may need more than the default 64 KiB of dynamic LDS: raises hipFuncAttributeMaxDynamicSharedMemorySize once per
+// (device, kernel) and size increase (engine.hip; thread-safe -- engines on several devices / host threads share the table)
+void dibs_allow_lds(const void* kernel, size_t bytes);
+
 // ---- tu_bge.hip --------------------------------------------------------------------------------------
 // sampling + queueing (sample = false: parent sets given in `masks`); kf.z != null appends the kernel-matrix blocks
 void bge_launch_sample(bool sample, hipStream_t stream, const uint32_t* thr, uint64_t* masks, double* node_scores, const BgeParams& bp,

@@ -12,11 +12,11 @@ static void launch_nt(const AcycLaunch& a) {
   const bool paired = a.units != a.Sa;
   const dim3 grid(a.nblk, a.Mloc);
   if (paired) {
-    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_acyc<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dibs_allow_lds((const void*)k_acyc<NT, true>, lds);
     hipLaunchKernelGGL((k_acyc<NT, true>), grid, dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.d, a.Sa, a.cpb, a.alpha,
                        a.tau, a.layout, a.tiny, a.nblk);
   } else {
-    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_acyc<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dibs_allow_lds((const void*)k_acyc<NT, false>, lds);
     hipLaunchKernelGGL((k_acyc<NT, false>), grid, dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.d, a.Sa, a.cpb, a.alpha,
                        a.tau, a.layout, a.tiny, a.nblk);
   }
@@ -39,19 +39,11 @@ static void acyc_launch_power(const AcycLaunch& a) {
     size_t lds = 2 * ABF_IMG_BYTES;
       const dim3 grid(a.nblk, (a.Mloc + 7) & ~7);
     if (a.d > 48) {
-      static size_t lds_set = 0;
-      if (lds > lds_set) {
-        hipFuncSetAttribute((const void*)k_acyc_bf<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set = lds;
-      }
+      dibs_allow_lds((const void*)k_acyc_bf<true>, lds);
       hipLaunchKernelGGL(k_acyc_bf<true>, grid, dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.Mloc, a.d, a.Sa, a.cpb, a.alpha,
                          a.tau, a.layout, a.tiny, a.nblk);
     } else {
-      static size_t lds_set = 0;
-      if (lds > lds_set) {
-        hipFuncSetAttribute((const void*)k_acyc_bf<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set = lds;
-      }
+      dibs_allow_lds((const void*)k_acyc_bf<false>, lds);
       hipLaunchKernelGGL(k_acyc_bf<false>, grid, dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.Mloc, a.d, a.Sa, a.cpb, a.alpha,
                          a.tau, a.layout, a.tiny, a.nblk);
     }

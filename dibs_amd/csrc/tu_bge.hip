@@ -1,20 +1,9 @@
 // translation unit: BGe sampling / factorisation kernels and their launchers (kernels_bge.h)
 #define DIBS_TU_BGE
 #include "launch.h"
-#include <unordered_map>
 
 template <typename K>
-static void allow_lds(K kernel, size_t bytes) {
-  // (one attribute call per kernel instantiation and size increase, not one per launch: K is a distinct function type only per
-  //  signature, so the high-water mark is kept per function pointer)
-  static std::unordered_map<const void*, size_t> granted;
-  if (bytes <= 48 * 1024) return;
-  size_t& g = granted[(const void*)kernel];
-  if (bytes > g) {
-    hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    g = bytes;
-  }
-}
+static void allow_lds(K kernel, size_t bytes) { dibs_allow_lds((const void*)kernel, bytes); }
 
 size_t bge_sample_lds_bytes(int d, int S, int W) { return 4 * bge_sample_wave_bytes(d, S, W); }
 
