@@ -258,9 +258,9 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
   if (c.joint && c.likelihood == DIBS_LIK_BGE)
     return fail("JointDiBS + BGe is not constructible (BGe has no parameters; linearGaussian.py:53-54)");
   if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_REPARAM) {
-    // soft-graph BGe (kernels_bge_soft.h): one matrix row per lane, d x d factor and solution block per wave in LDS
-    if (c.n_vars > 64 || bge_soft_waves(c.n_vars, false) < 1)
-      return fail("BGe + reparam estimator: n_vars must be <= 64 on the device");
+    // soft-graph BGe (kernels_bge_soft.h): one or two matrix rows per lane, packed factor + inverse columns per wave in LDS
+    if (c.n_vars > 128 || bge_soft_waves(c.n_vars, false) < 1)
+      return fail("BGe + reparam estimator: n_vars too large for the device kernel");
   }
   if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_SCORE &&
       bge_sample_lds_bytes(c.n_vars, c.n_grad_mc_samples, (c.n_vars + 63) / 64) > LDS_LIMIT - 2048)

@@ -11,13 +11,19 @@
 //   dl_j/dp_i = gamma'(l) - 1/2 log s - h_i - (2 c2 / s) y_i ( (R~ (p o y))_i - R_ji )        (i != j)
 //   gamma'(l) = 1/2 psi((N + alpha_lambd - d + l + 1)/2) - 1/2 psi((alpha_lambd - d + l + 1)/2) + log t
 // (autograd of the reference formula; checked against torch.autograd in tests/test_oracle.py and on the device in
-//  tests/test_gpu_parity.py).  h needs the diagonal of M_pa^-1 Q with Q_bi = R~_ib p_b: lane i solves L L^T w = Q[:, i] by
-// forward / backward substitution (L is read as LDS broadcasts) and keeps w_i; lane j solves for y instead.
-// One wave per node, one block per (particle, sample); d <= 64 (one matrix row per lane).
+//  tests/test_gpu_parity.py).
+// h only needs the DIAGONAL of M_pa^-1: on the rows with p_i > 0, M_pa = D (R + Lam) D with Lam = D^-2 - I, so with B = (R + Lam)^-1
+//   h_i = (1 / p_i) sum_b B_ib R~_ib = (1 / p_i) ((B R)_ii - B_ii) = (1 / p_i) (1 - B_ii (Lam_ii + 1)) = (1 - (M_pa^-1)_ii) / p_i
+// (h_i = 0 where p_i = 0), and (M_pa^-1)_ii = |column i of L^-1|^2.  Lane i therefore solves L u = e_i (its column of L^-1; forward
+// substitution only), lane j solves L w = b in the same pass, and y_i = u_i . w.  1 - (M_pa^-1)_ii is assembled from L_ii^2 - 1 (kept
+// from the factorisation without the 1) and the off-diagonal part of the column: no cancellation for small p_i.
+// One wave per node (lane = matrix row; two rows per lane for d > 64), one block per (particle, sample).  L (column-major) and the
+// columns of L^-1 are packed triangles in LDS: 2 * d (d + 1) / 2 floats per wave.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels_joint.h"
+#include <stdlib.h>
 
 struct BgeSoftParams {
   const float* R;     // [n_mats, d, d]
@@ -38,15 +44,17 @@ __device__ __forceinline__ double digamma_d(double x) {
   return acc + log(x) - 0.5 / x - ser;
 }
 
+__host__ __device__ inline int bge_soft_tri(int d) { return d * (d + 1) / 2; }
 __host__ __device__ inline size_t bge_soft_wave_bytes(int d) {
-  // L [d][d|1] | U [d][64] | p[64] | y[64] | dinv[64]
-  return ((size_t)d * (d | 1) + (size_t)d * 64 + 3 * 64) * 4;
+  // L tri | U tri | p[128] | y[128] | w[128] | dinv[128]
+  return (((size_t)2 * bge_soft_tri(d) + 4 * 128) * 4 + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t bge_soft_shared_bytes(int d, bool r_in_lds) {
-  return ((((size_t)d * d * (r_in_lds ? 2 : 1)) * 4 + 15) & ~(size_t)15) + 256;  // Gs | Rs | red[4] (+ pad)
+  return ((((size_t)d * d * (r_in_lds ? 1 : 0)) * 4 + 15) & ~(size_t)15) + 256;  // Rs | red[4] (+ pad)
 }
 __host__ __device__ inline int bge_soft_waves(int d, bool r_in_lds) {
   const size_t shared = bge_soft_shared_bytes(d, r_in_lds);
+  if (shared + bge_soft_wave_bytes(d) > (size_t)160 * 1024 - 1024) return 0;
   const int nw = (int)(((size_t)160 * 1024 - 1024 - shared) / bge_soft_wave_bytes(d));
   return nw > 4 ? 4 : nw;
 }
@@ -54,33 +62,30 @@ __host__ __device__ inline size_t bge_soft_lds_bytes(int d, bool r_in_lds) {
   return bge_soft_shared_bytes(d, r_in_lds) + (size_t)bge_soft_waves(d, r_in_lds) * bge_soft_wave_bytes(d);
 }
 
-// grid = (S, Mloc), block = 256
-template <bool R_LDS>
+// grid = (S, Mloc), block = 256.  RPL: matrix rows per lane (1: d <= 64, 2: d <= 128)
+template <bool R_LDS, int RPL>
 __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scores, BgeSoftParams bp, Key2 carry, int m0, int M_global,
                                                   int d, int S, float alpha, float tau, int layout, int tiny,
                                                   float* __restrict__ ds_out, float* __restrict__ logprobs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int s = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int dd = d * d, ldl = d | 1;
-  float* Gs = reinterpret_cast<float*>(smem_raw);             // soft graph of this sample, [i][j]
-  float* Rs = Gs + dd;                                        // R (one matrix for all nodes)
+  const int dd = d * d, ntri = bge_soft_tri(d);
+  float* Rs = reinterpret_cast<float*>(smem_raw);             // R (one matrix for all nodes)
   double* red = reinterpret_cast<double*>(smem_raw + bge_soft_shared_bytes(d, R_LDS) - 256);  // [4] partial log-probs (+ pad)
   const int nw = bge_soft_waves(d, R_LDS);
   unsigned char* wbase = smem_raw + bge_soft_shared_bytes(d, R_LDS) + (size_t)wave * bge_soft_wave_bytes(d);
-  float* L = reinterpret_cast<float*>(wbase);
-  float* U = L + (size_t)d * ldl;
-  float* pv = U + (size_t)d * 64;
-  float* yv = pv + 64;
-  float* dinv = yv + 64;
+  float* Lc = reinterpret_cast<float*>(wbase);  // L, column-major packed: (r, q), r >= q, at q d - q (q - 1) / 2 + r - q
+  float* Ut = Lc + ntri;                        // columns of L^-1, row-major packed: (k, c), c <= k, at k (k + 1) / 2 + c
+  float* pv = Ut + ntri;
+  float* yv = pv + 128;
+  float* wv = yv + 128;
+  float* dinv = wv + 128;
 
   const float* sc_m = scores + (size_t)m * dd;
   const Key2 key = lin_mode_key(LIN_MODE_Z_REPARAM, carry, M_global, m0 + m, layout);  // dibs.py:430-431
   const uint64_t nbits = (uint64_t)S * dd;
-  for (int e = tid; e < dd; e += 256) {
-    const int i = e / d, j = e - i * d;
-    Gs[e] = lin_sample_g(LIN_MODE_Z_REPARAM, key, nbits, (uint64_t)dd, s, i, j, d, nullptr, sc_m, alpha, tau, layout, tiny);
-    if (R_LDS) Rs[e] = bp.R[e];
-  }
+  if (R_LDS)
+    for (int e = tid; e < dd; e += 256) Rs[e] = bp.R[e];
   if (tid < 4) red[tid] = 0.0;
   __syncthreads();
 
@@ -89,86 +94,299 @@ __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scor
   if (wave < nw) {
     for (int j = wave; j < d; j += nw) {
       const float* R = R_LDS ? Rs : bp.R + (bp.n_mats > 1 ? (size_t)j * dd : 0);
-      const int r = lane;
-      const bool act = r < d;
-      const float p_r = (act && r != j) ? Gs[r * d + j] : 0.f;
-      pv[lane] = p_r;
-      const double l = wave_sum_d((double)p_r);
+      // column j of the soft graph of this sample (dibs.py:121-140), drawn by the lanes that own its rows
+      float p[RPL], g[RPL];
+      bool act[RPL];
+      double lsum = 0.0;
+#pragma unroll
+      for (int h = 0; h < RPL; ++h) {
+        const int r = lane + 64 * h;
+        act[h] = r < d;
+        g[h] = act[h] ? lin_sample_g(LIN_MODE_Z_REPARAM, key, nbits, (uint64_t)dd, s, r, j, d, nullptr, sc_m, alpha, tau, layout, tiny) : 0.f;
+        p[h] = g[h];  // (0 on the diagonal)
+        pv[r] = p[h];
+        lsum += (double)p[h];
+      }
+      const double l = wave_sum_d(lsum);
       wave_lds_fence();
-      // ---- Cholesky of M_pa (lane = row) --------------------------------------------------------
-      float mypiv = 1.f;
+      // ---- Cholesky of M_pa, column by column (lane = row) -------------------------------------------------
+      float dm1[RPL];  // L_rr^2 - 1 of this lane's rows
+      double ldp = 0.0;
+#pragma unroll
+      for (int h = 0; h < RPL; ++h) dm1[h] = 0.f;
       for (int kk = 0; kk < d; ++kk) {
-        float acc = 0.f;
-        if (act && r >= kk) {
-          const float dlt = r == kk ? 1.f : 0.f;
-          acc = dlt + p_r * pv[kk] * (R[r * d + kk] - dlt);
-          const float* lr = L + (size_t)r * ldl;
-          const float* lk = L + (size_t)kk * ldl;
+        const float pk = pv[kk];
+        float acc[RPL];
+#pragma unroll
+        for (int h = 0; h < RPL; ++h) {
+          const int r = lane + 64 * h;
+          acc[h] = 0.f;
+          if (act[h] && r >= kk) {
+            acc[h] = p[h] * pk * (R[r * d + kk] - (r == kk ? 1.f : 0.f));   // M_pa[r][kk] - delta
+            int ir = r, ik = kk;                                            // (r, q) and (kk, q) of column q = 0
 #pragma unroll 8
-          for (int q = 0; q < kk; ++q) acc = fmaf(-lr[q], lk[q], acc);  // (unrolled: the LDS reads of several terms in flight)
+            for (int q = 0; q < kk; ++q) {  // (unrolled: the LDS reads of several terms in flight)
+              acc[h] = fmaf(-Lc[ir], Lc[ik], acc[h]);
+              ir += d - q - 1;
+              ik += d - q - 1;
+            }
+          }
         }
-        const float piv = __shfl(acc, kk, 64);
+        const float accp = RPL == 1 ? acc[0] : (kk < 64 ? acc[0] : acc[RPL - 1]);
+        const float pivm1 = __shfl(accp, kk & 63, 64);
+        const float piv = 1.0f + pivm1;
         const float inv = rsqrtf(piv);
-        if (r == kk) {
-          mypiv = piv;
-          dinv[kk] = inv;
+        const int ck = kk * d - kk * (kk - 1) / 2 - kk;  // (r, kk) at ck + r
+#pragma unroll
+        for (int h = 0; h < RPL; ++h) {
+          const int r = lane + 64 * h;
+          if (r == kk) {
+            dm1[h] = pivm1;
+            dinv[kk] = inv;
+            Lc[ck + r] = piv * inv;
+            ldp += log((double)piv);
+          } else if (act[h] && r > kk) {
+            Lc[ck + r] = acc[h] * inv;
+          }
         }
-        if (act && r > kk) L[(size_t)r * ldl + kk] = acc * inv;
         wave_lds_fence();
       }
-      const double ld_pa = wave_sum_d(act ? log((double)mypiv) : 0.0);
-      // ---- forward substitution  L u = rhs(lane):  rhs_b = p_b (R[lane][b] - [b == lane != j]) ------------------
-      if (act) {
-        for (int k = 0; k < d; ++k) {
-          const float dlt = (k == r && r != j) ? 1.f : 0.f;
-          float v = pv[k] * (R[r * d + k] - dlt);
-          const float* lk = L + (size_t)k * ldl;
-#pragma unroll 8
-          for (int q = 0; q < k; ++q) v = fmaf(-lk[q], U[q * 64 + lane], v);
-          U[k * 64 + lane] = v * dinv[k];
-        }
-        // ---- backward substitution  L^T w = u, down to row `stop` (lane j needs all of y, the others only w_lane) -----
-        const int stop = r == j ? 0 : r;
-        for (int k = d - 1; k >= stop; --k) {
-          float v = U[k * 64 + lane];
-#pragma unroll 8
-          for (int q = k + 1; q < d; ++q) v = fmaf(-L[(size_t)q * ldl + k], U[q * 64 + lane], v);
-          U[k * 64 + lane] = v * dinv[k];
-        }
+      const double ld_pa = wave_sum_d(ldp);
+      // ---- forward substitutions: lane c solves L u = e_c (column c of L^-1), the lane that owns row j solves L w = b instead ----
+      float b_own[RPL];
+#pragma unroll
+      for (int h = 0; h < RPL; ++h) {
+        const int r = lane + 64 * h;
+        b_own[h] = act[h] ? p[h] * R[j * d + r] : 0.f;
+        wv[r] = b_own[h];  // (rhs, overwritten by the solution row by row)
       }
       wave_lds_fence();
-      const float h_r = act ? U[r * 64 + r] : 0.f;   // w_r of this lane's own system
-      const float y_r = act ? U[r * 64 + j] : 0.f;   // y = M_pa^-1 b (lane j's system), row r
-      yv[lane] = y_r;
-      const double bty = wave_sum_d(act ? (double)(p_r * R[j * d + r]) * (double)y_r : 0.0);
+      for (int k = 0; k < d; ++k) {
+        const int tk = k * (k + 1) / 2;
+        float vs[RPL];
+        float vw = wv[k];  // rhs b_k (every lane computes w_k: one broadcast chain, no lane divergence)
+        int ik = k;        // (k, q) of column q = 0
+#pragma unroll
+        for (int h = 0; h < RPL; ++h) vs[h] = (lane + 64 * h == k) ? 1.f : 0.f;
+#pragma unroll 8
+        for (int q = 0; q < k; ++q) {
+          const float lkq = Lc[ik];
+          ik += d - q - 1;
+          vw = fmaf(-lkq, wv[q], vw);
+#pragma unroll
+          for (int h = 0; h < RPL; ++h) {
+            const int c = lane + 64 * h;
+            if (c <= q) vs[h] = fmaf(-lkq, Ut[q * (q + 1) / 2 + c], vs[h]);
+          }
+        }
+        const float di = dinv[k];
+#pragma unroll
+        for (int h = 0; h < RPL; ++h) {
+          const int c = lane + 64 * h;
+          if (c <= k) Ut[tk + c] = vs[h] * di;
+        }
+        if (lane == 0) wv[k] = vw * di;
+        wave_lds_fence();
+      }
+      // ---- (M_pa^-1)_cc and y_c = (L^-T w)_c from this lane's column of L^-1 ------------------------------------
+      float offd[RPL], y[RPL];
+#pragma unroll
+      for (int h = 0; h < RPL; ++h) {
+        const int c = lane + 64 * h;
+        offd[h] = 0.f;
+        y[h] = 0.f;
+        if (act[h]) {
+          for (int k = c; k < d; ++k) {
+            const float u = Ut[k * (k + 1) / 2 + c];
+            if (k > c) offd[h] = fmaf(u, u, offd[h]);
+            y[h] = fmaf(u, wv[k], y[h]);
+          }
+          if (c == j) y[h] = 0.f;  // row j of M_pa is the identity and b_j = 0
+        }
+        yv[c] = y[h];
+      }
+      double btyp = 0.0;
+#pragma unroll
+      for (int h = 0; h < RPL; ++h) btyp += (double)b_own[h] * (double)y[h];
+      const double bty = wave_sum_d(btyp);
       const double sch = (double)R[j * d + j] - bty;
       wave_lds_fence();
-      float t_r = 0.f;
-      if (act) {
-#pragma unroll 8
-        for (int b = 0; b < d; ++b) t_r = fmaf(R[r * d + b] - (b == r ? 1.f : 0.f), pv[b] * yv[b], t_r);
-        t_r -= R[j * d + r];
-      }
       const double Nn = bp.Nj[j], al = bp.alpha_lambd;
-      double lj = 0.0, dl = 0.0;
+      double lj = 0.0, gprime = 0.0, ls = 0.0, c2 = 0.0;
       if (Nn > 0.0) {  // linearGaussian.py:118: a node without observations scores 0
-        const double a1 = 0.5 * (Nn + al - d + l + 1.0), a2 = 0.5 * (al - d + l + 1.0), c2 = a1;
+        const double a1 = 0.5 * (Nn + al - d + l + 1.0), a2 = 0.5 * (al - d + l + 1.0);
+        c2 = a1;
         const double gam = 0.5 * (log(bp.alpha_mu) - log(Nn + bp.alpha_mu)) + lgamma(a1) - lgamma(a2) - 0.5 * Nn * log(M_PI) +
                            0.5 * (al - d + 2.0 * l + 1.0) * bp.log_t;
-        const double gprime = 0.5 * digamma_d(a1) - 0.5 * digamma_d(a2) + bp.log_t;
-        const double ls = log(sch);
+        gprime = 0.5 * digamma_d(a1) - 0.5 * digamma_d(a2) + bp.log_t;
+        ls = log(sch);
         lj = gam - 0.5 * ld_pa - c2 * ls;
-        dl = gprime - 0.5 * ls - (double)h_r - (2.0 * c2 / sch) * (double)y_r * (double)t_r;
       }
       lp_wave += lj;
-      if (act) {
-        const float g = Gs[r * d + j];
-        out[r * d + j] = (r == j) ? 0.f : (float)dl * tau * alpha * g * (1.0f - g);
+#pragma unroll
+      for (int h = 0; h < RPL; ++h) {
+        const int r = lane + 64 * h;
+        if (!act[h]) continue;
+        float t_r = 0.f;
+#pragma unroll 8
+        for (int bb = 0; bb < d; ++bb) t_r = fmaf(R[r * d + bb] - (bb == r ? 1.f : 0.f), pv[bb] * yv[bb], t_r);
+        t_r -= R[j * d + r];
+        // 1 - (M_pa^-1)_rr = (L_rr^2 - 1) / L_rr^2 - |off-diagonal part of column r of L^-1|^2, each term O(p_r^2)
+        const float h_r = p[h] > 0.f ? (dm1[h] / (1.0f + dm1[h]) - offd[h]) / p[h] : 0.f;
+        const double dl = Nn > 0.0 ? gprime - 0.5 * ls - (double)h_r - (2.0 * c2 / sch) * (double)y[h] * (double)t_r : 0.0;
+        out[r * d + j] = (r == j) ? 0.f : (float)dl * tau * alpha * g[h] * (1.0f - g[h]);
       }
       wave_lds_fence();
     }
     if (lane == 0) red[wave] = lp_wave;
   }
+  __syncthreads();
+  if (tid == 0) logprobs[(size_t)m * S + s] = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// d <= 64: the same computation with this lane's matrix row in REGISTERS.  The generic kernel above reads both operands of every FMA
+// from LDS (own row + broadcast row): 256 B of LDS traffic per wave-FMA against 128 B per clock and CU -- LDS-bound at a quarter of the
+// vector rate, at one or two waves per SIMD.  Here lane r keeps L[r][0..kk) (factorisation) and then its column of L^-1 (forward
+// substitution) in registers; only the broadcast operand -- row kk of L, four values per ds_read_b128 -- comes from LDS.  Register
+// arrays need compile-time indices: the kernel is instantiated for DP = d rounded up to 8 and every loop is unrolled (rows / columns
+// d .. DP-1 are identity padding, p = 0).
+// LDS per wave: L row-major [DP][DP + 4] | b, w, p, y, dinv [DP] each
+// ------------------------------------------------------------------------------------------------
+template <int DP>
+__host__ __device__ inline size_t bge_softr_wave_bytes() { return ((size_t)DP * (DP + 4) + 5 * DP) * 4; }
+template <int DP>
+__host__ __device__ inline size_t bge_softr_lds_bytes(int d, bool r_in_lds) { return bge_soft_shared_bytes(d, r_in_lds) + 4 * bge_softr_wave_bytes<DP>(); }
+
+template <int DP, bool R_LDS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bge_soft_reg(const float* __restrict__ scores, BgeSoftParams bp, Key2 carry, int m0, int M_global,
+                                                      int d, int S, float alpha, float tau, int layout, int tiny,
+                                                      float* __restrict__ ds_out, float* __restrict__ logprobs) {
+  constexpr int LDL = DP + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int s = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int dd = d * d;
+  float* Rs = reinterpret_cast<float*>(smem_raw);
+  double* red = reinterpret_cast<double*>(smem_raw + bge_soft_shared_bytes(d, R_LDS) - 256);
+  float* Lr = reinterpret_cast<float*>(smem_raw + bge_soft_shared_bytes(d, R_LDS) + (size_t)wave * bge_softr_wave_bytes<DP>());
+  float* bv = Lr + DP * LDL;
+  float* wv = bv + DP;
+  float* pv = wv + DP;
+  float* yv = pv + DP;
+  float* dinv = yv + DP;
+  const float* sc_m = scores + (size_t)m * dd;
+  const Key2 key = lin_mode_key(LIN_MODE_Z_REPARAM, carry, M_global, m0 + m, layout);  // dibs.py:430-431
+  const uint64_t nbits = (uint64_t)S * dd;
+  if (R_LDS)
+    for (int e = tid; e < dd; e += 256) Rs[e] = bp.R[e];
+  if (tid < 4) red[tid] = 0.0;
+  __syncthreads();
+  float* out = ds_out + ((size_t)m * S + s) * dd;
+  double lp_wave = 0.0;
+  const bool act = lane < d, inrow = lane < DP;
+  for (int j = wave; j < d; j += 4) {
+    const float* R = R_LDS ? Rs : bp.R + (bp.n_mats > 1 ? (size_t)j * dd : 0);
+    const float* Rrow = R + (act ? lane : 0) * d;
+    const float g = act ? lin_sample_g(LIN_MODE_Z_REPARAM, key, nbits, (uint64_t)dd, s, lane, j, d, nullptr, sc_m, alpha, tau, layout, tiny) : 0.f;
+    const float p = g;  // column j of the soft graph (dibs.py:121-140); 0 on the diagonal and on the padding rows
+    const double l = wave_sum_d((double)p);
+    if (inrow) {
+      pv[lane] = p;
+      bv[lane] = act ? p * R[j * d + lane] : 0.f;
+    }
+    wave_lds_fence();
+    // ---- Cholesky of M_pa = I + D R~ D, column by column; lane = row, row in registers ------------------------------------
+    float row[DP];
+    float dm1 = 0.f;  // L_rr^2 - 1 of this lane's row (kept without the 1: no cancellation for small p)
+#pragma unroll
+    for (int kk = 0; kk < DP; ++kk) {
+      const float rk = (act && kk < d) ? Rrow[kk < d ? kk : 0] : 0.f;
+      // (four independent partial sums: at one or two waves per SIMD a single dependent FMA chain would issue every ~8 cycles)
+      float acc = p * pv[kk] * (rk - (lane == kk ? 1.f : 0.f)), acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+#pragma unroll
+      for (int q0 = 0; q0 < kk; q0 += 4) {
+        const float4 lk = *reinterpret_cast<const float4*>(Lr + kk * LDL + q0);  // row kk of L: broadcast
+        acc = fmaf(-row[q0], lk.x, acc);
+        if (q0 + 1 < kk) acc1 = fmaf(-row[q0 + 1], lk.y, acc1);
+        if (q0 + 2 < kk) acc2 = fmaf(-row[q0 + 2], lk.z, acc2);
+        if (q0 + 3 < kk) acc3 = fmaf(-row[q0 + 3], lk.w, acc3);
+      }
+      acc = (acc + acc1) + (acc2 + acc3);
+      const float pivm1 = __shfl(acc, kk, 64);
+      const float piv = 1.0f + pivm1;
+      const float inv = rsqrtf(piv);
+      const float lv = lane == kk ? piv * inv : (lane > kk ? acc * inv : 0.f);
+      row[kk] = lv;
+      if (lane == kk) {
+        dm1 = pivm1;
+        dinv[kk] = inv;
+      }
+      if (inrow) Lr[lane * LDL + kk] = lv;
+      wave_lds_fence();
+    }
+    const double ld_pa = wave_sum_d(inrow ? log((double)(1.0f + dm1)) : 0.0);
+    // ---- forward substitution: lane c solves L u = e_c (column c of L^-1), lane j solves L w = b -----------------------------
+    float u[DP];
+    const bool isj = lane == j;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      float v = isj ? bv[k] : (lane == k ? 1.f : 0.f), v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll
+      for (int q0 = 0; q0 < k; q0 += 4) {
+        const float4 lk = *reinterpret_cast<const float4*>(Lr + k * LDL + q0);
+        v = fmaf(-lk.x, u[q0], v);
+        if (q0 + 1 < k) v1 = fmaf(-lk.y, u[q0 + 1], v1);
+        if (q0 + 2 < k) v2 = fmaf(-lk.z, u[q0 + 2], v2);
+        if (q0 + 3 < k) v3 = fmaf(-lk.w, u[q0 + 3], v3);
+      }
+      v = (v + v1) + (v2 + v3);
+      u[k] = v * dinv[k];
+      if (isj) wv[k] = u[k];
+    }
+    wave_lds_fence();
+    // (M_pa^-1)_cc = |column c of L^-1|^2 (its off-diagonal part here), y_c = column c . w, |w|^2 for the Schur complement
+    float offd = 0.f, y = 0.f, w2 = 0.f;
+#pragma unroll
+    for (int k0 = 0; k0 < DP; k0 += 4) {
+      const float4 w4 = *reinterpret_cast<const float4*>(wv + k0);
+      const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float uk = u[k0 + i];
+        offd = fmaf(k0 + i > lane ? uk : 0.f, uk, offd);
+        y = fmaf(uk, ws[i], y);
+        w2 = fmaf(ws[i], ws[i], w2);
+      }
+    }
+    if (isj) y = 0.f;  // row j of M_pa is the identity and b_j = 0
+    if (inrow) yv[lane] = y;
+    const double sch = (double)R[j * d + j] - (double)w2;  // s = R_jj - b^T M_pa^-1 b = R_jj - |L^-1 b|^2
+    wave_lds_fence();
+    const double Nn = bp.Nj[j], al = bp.alpha_lambd;
+    double lj = 0.0, gprime = 0.0, ls = 0.0, c2 = 0.0;
+    if (Nn > 0.0) {  // linearGaussian.py:118: a node without observations scores 0
+      const double a1 = 0.5 * (Nn + al - d + l + 1.0), a2 = 0.5 * (al - d + l + 1.0);
+      c2 = a1;
+      const double gam = 0.5 * (log(bp.alpha_mu) - log(Nn + bp.alpha_mu)) + lgamma(a1) - lgamma(a2) - 0.5 * Nn * log(M_PI) +
+                         0.5 * (al - d + 2.0 * l + 1.0) * bp.log_t;
+      gprime = 0.5 * digamma_d(a1) - 0.5 * digamma_d(a2) + bp.log_t;
+      ls = log(sch);
+      lj = gam - 0.5 * ld_pa - c2 * ls;
+    }
+    lp_wave += lj;
+    if (act) {
+      float t_r = 0.f;
+#pragma unroll 8
+      for (int bb = 0; bb < d; ++bb) t_r = fmaf(Rrow[bb] - (bb == lane ? 1.f : 0.f), pv[bb] * yv[bb], t_r);
+      t_r -= R[j * d + lane];
+      // 1 - (M_pa^-1)_rr = (L_rr^2 - 1) / L_rr^2 - |off-diagonal part of column r of L^-1|^2, each term O(p_r^2)
+      const float h_r = p > 0.f ? (dm1 / (1.0f + dm1) - offd) / p : 0.f;
+      const double dl = Nn > 0.0 ? gprime - 0.5 * ls - (double)h_r - (2.0 * c2 / sch) * (double)y * (double)t_r : 0.0;
+      out[lane * d + j] = isj ? 0.f : (float)dl * tau * alpha * g * (1.0f - g);
+    }
+    wave_lds_fence();
+  }
+  if (lane == 0) red[wave] = lp_wave;
   __syncthreads();
   if (tid == 0) logprobs[(size_t)m * S + s] = (float)(red[0] + red[1] + red[2] + red[3]);
 }
@@ -212,17 +430,46 @@ __global__ __launch_bounds__(256) void k_soft_combine(const float* __restrict__ 
 // both launches of the estimator: per-sample soft-graph scores + gradients, then the softmax-weighted combination
 void bge_soft_launch(const BgeSoftParams& sp, const float* scores, Key2 carry, int m0, int M, int Mloc, int d, int S, float alpha,
                      float tau, int layout, int tiny, float* soft_ds, float* logprobs, float* w_lik, hipStream_t stream) {
-  const bool rl = sp.n_mats == 1 && bge_soft_waves(d, true) >= 1;
+  const bool rl = sp.n_mats == 1 && bge_soft_waves(d, true) >= (bge_soft_waves(d, false) < 4 ? bge_soft_waves(d, false) : 4);
   const size_t lds = bge_soft_lds_bytes(d, rl);
-  if (rl) {
-    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_bge_soft<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_bge_soft<true>, dim3(S, Mloc), dim3(256), lds, stream, scores, sp, carry, m0, M, d, S, alpha, tau, layout, tiny,
-                       soft_ds, logprobs);
-  } else {
-    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_bge_soft<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_bge_soft<false>, dim3(S, Mloc), dim3(256), lds, stream, scores, sp, carry, m0, M, d, S, alpha, tau, layout, tiny,
-                       soft_ds, logprobs);
+#define SOFT_LAUNCH(RL_, RPL_)                                                                                                          \
+  {                                                                                                                                     \
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_bge_soft<RL_, RPL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((k_bge_soft<RL_, RPL_>), dim3(S, Mloc), dim3(256), lds, stream, scores, sp, carry, m0, M, d, S, alpha, tau, layout, \
+                       tiny, soft_ds, logprobs);                                                                                        \
   }
+  if (d <= 64 && !getenv("DIBS_SOFT_GENERIC")) {
+    const bool rr = sp.n_mats == 1;
+#define SOFTR(DP_)                                                                                                                     \
+  {                                                                                                                                     \
+    const size_t l2 = bge_softr_lds_bytes<DP_>(d, rr);                                                                                  \
+    if (rr) {                                                                                                                           \
+      if (l2 > 48 * 1024) hipFuncSetAttribute((const void*)k_bge_soft_reg<DP_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2); \
+      hipLaunchKernelGGL((k_bge_soft_reg<DP_, true>), dim3(S, Mloc), dim3(256), l2, stream, scores, sp, carry, m0, M, d, S, alpha, tau, layout, \
+                         tiny, soft_ds, logprobs);                                                                                      \
+    } else {                                                                                                                            \
+      if (l2 > 48 * 1024) hipFuncSetAttribute((const void*)k_bge_soft_reg<DP_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2); \
+      hipLaunchKernelGGL((k_bge_soft_reg<DP_, false>), dim3(S, Mloc), dim3(256), l2, stream, scores, sp, carry, m0, M, d, S, alpha, tau, layout, \
+                         tiny, soft_ds, logprobs);                                                                                      \
+    }                                                                                                                                   \
+  }
+    switch ((d + 7) / 8) {
+      case 1: SOFTR(8) break;
+      case 2: SOFTR(16) break;
+      case 3: SOFTR(24) break;
+      case 4: SOFTR(32) break;
+      case 5: SOFTR(40) break;
+      case 6: SOFTR(48) break;
+      case 7: SOFTR(56) break;
+      default: SOFTR(64) break;
+    }
+#undef SOFTR
+  } else if (d <= 64) {
+    if (rl) SOFT_LAUNCH(true, 1) else SOFT_LAUNCH(false, 1)
+  } else {
+    if (rl) SOFT_LAUNCH(true, 2) else SOFT_LAUNCH(false, 2)
+  }
+#undef SOFT_LAUNCH
   hipLaunchKernelGGL(k_soft_combine, dim3(Mloc), dim3(256), (size_t)S * 4 + 16, stream, soft_ds, logprobs, w_lik, d, S);
 }
 #else

