@@ -226,7 +226,7 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
     HIP_OK(dalloc(&e->masks, Ml * e->S * e->d * e->W));
     HIP_OK(dalloc(&e->node_scores, Ml * e->S * e->d));
     e->bq.cap = (uint32_t)(Ml * e->S * e->d);
-    HIP_OK(dalloc(&e->bq.list, (size_t)BGE_NQ * e->bq.cap));
+    HIP_OK(dalloc(&e->bq.list, (size_t)BGE_NQ * e->bq.cap * e->W));  // (one list per size tier, each sized for every problem)
     HIP_OK(dalloc(&e->bq.counts, (size_t)16));
     if (c.grad_estimator_z == DIBS_EST_REPARAM) HIP_OK(dalloc(&e->soft_ds, Ml * e->S * dd));
   }
@@ -675,7 +675,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     }
     {
       KTimer tm(e, DIBS_K_BGE_BIG);
-      bge_launch_chol(e->stream, e->masks, e->node_scores, bp, e->bq, e->d, e->S, e->profiling ? e->counters : nullptr);
+      bge_launch_chol(e->stream, e->node_scores, bp, e->bq, e->d, e->S, e->profiling ? e->counters : nullptr);
     }
     score_lik = true;  // softmax weights, W_lik and the baseline are part of k_particle_grad below
   } else if (c.likelihood == DIBS_LIK_LINGAUSS) {
@@ -956,11 +956,11 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
     const int W = e->W, CH = 512;
     DevBuf<uint64_t> d_masks;
     DevBuf<double> d_ns;
-    DevBuf<uint32_t> q_list;
+    DevBuf<uint4> q_list;
     DevBuf<unsigned int> q_counts;
     HIP_OK(d_masks.alloc((size_t)d * CH * W));
     HIP_OK(d_ns.alloc((size_t)d * CH));
-    HIP_OK(q_list.alloc((size_t)BGE_NQ * d * CH));
+    HIP_OK(q_list.alloc((size_t)BGE_NQ * d * CH * W));
     HIP_OK(q_counts.alloc((size_t)BGE_NQ));
     const BgeQueues sq{q_list.p, q_counts.p, (uint32_t)(d * CH)};  // scratch queues for this call
     const BgeParams bp = st.params();
@@ -976,7 +976,7 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
       HIP_OK(hipMemsetAsync(sq.counts, 0, BGE_NQ * sizeof(unsigned int), e->stream));
       bge_launch_sample(false, e->stream, nullptr, d_masks.p, d_ns.p, bp, Key2{0, 0}, 0, 1, 1, d, S, W, 0, sq,
                         KmatFuse{nullptr, nullptr, 0, 0, 0, 0.f, 0.f});
-      bge_launch_chol(e->stream, d_masks.p, d_ns.p, bp, sq, d, S, nullptr);
+      bge_launch_chol(e->stream, d_ns.p, bp, sq, d, S, nullptr);
       bge_launch_sum_nodes(e->stream, d_ns.p, d_out.p + q0, d, S);
       HIP_OK(hipStreamSynchronize(e->stream));
     }

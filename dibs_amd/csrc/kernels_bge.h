@@ -41,8 +41,10 @@ struct BgeParams {
   int n_mats;
 };
 
+// A queue entry carries everything the factorisation needs -- {code = (m * d + j) * S + s, j, parent-set words} -- so that the consumer
+// issues ONE independent 16-byte load per problem (d > 64: two) instead of the chain list -> code -> masks[code] -> (code / S) % d.
 struct BgeQueues {
-  uint32_t* list;        // [BGE_NQ][cap] problem codes (m * d + j) * S + s
+  uint4* list;           // [BGE_NQ][cap][W]  {code, j, w0.lo, w0.hi} (, {w1.lo, w1.hi, 0, 0})
   unsigned int* counts;  // [BGE_NQ]: zero at creation, reset by the consumer of the node scores after every use
   uint32_t cap;
 };
@@ -72,6 +74,14 @@ __device__ __forceinline__ double bge_score(const BgeParams& bp, int j, int l, i
   const double c = Nn + bp.alpha_lambd - d + l;
   const double g = bp.gam[(size_t)j * (d + 1) + l], ld = 0.6931471805599453 * (double)ld2, ll = bge_log(last);
   return comp ? g - 0.5 * (bp.ldR[bp.n_mats > 1 ? j : 0] + ld) + 0.5 * c * ll : g - 0.5 * ld - 0.5 * (c + 1.0) * ll;
+}
+
+// the same with the table entries already in registers (k_bge_chol requests them before the factorisation)
+__device__ __forceinline__ double bge_score_pre(double Nn, double g, double ldRv, double alpha_lambd, int l, int d, bool comp, float ld2, float last) {
+  if (!(Nn > 0.0)) return 0.0;  // linearGaussian.py:118
+  const double c = Nn + alpha_lambd - d + l;
+  const double ld = 0.6931471805599453 * (double)ld2, ll = bge_log(last);
+  return comp ? g - 0.5 * (ldRv + ld) + 0.5 * c * ll : g - 0.5 * ld - 0.5 * (c + 1.0) * ll;
 }
 
 // index set of a problem: the parents (or, complement form, the non-parents other than j) as a bit mask over the d variables
@@ -256,7 +266,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_sample(const uint32_t* __res
       const uint32_t v = loc[s];
       if (v != 0xFFFFFFFFu) {
         const uint32_t tq = v >> 28;
-        qs.list[(size_t)tq * qs.cap + blk_base[tq] + (v & 0x0FFFFFFFu)] = (uint32_t)(((size_t)m * d + j) * S + s);
+        uint4* dst = qs.list + ((size_t)tq * qs.cap + blk_base[tq] + (v & 0x0FFFFFFFu)) * W;
+        const uint64_t w0 = mk[s * W];
+        dst[0] = make_uint4((uint32_t)(((size_t)m * d + j) * S + s), (uint32_t)j, (uint32_t)w0, (uint32_t)(w0 >> 32));
+        if (W > 1) {
+          const uint64_t w1 = mk[s * W + 1];
+          dst[1] = make_uint4((uint32_t)w1, (uint32_t)(w1 >> 32), 0u, 0u);
+        }
       }
     }
 }
@@ -524,9 +540,12 @@ __host__ __device__ inline size_t bge_chol_lds_bytes(int d, bool r_in_lds) {
 
 // grid = any (persistent: work units are dealt round-robin, largest tier first), block = 256; dynamic LDS = bge_chol_lds_bytes()
 // R_LDS: one matrix pair (no interventions) resident in LDS; otherwise R_j / Q_j are read through the caches.
+// The walk over the work units is software-pipelined: the queue entries of a block's NEXT unit are requested before the current unit is
+// factorised, and a problem's table entries (log-gamma term, N_j, logdet R) as soon as its parent count is known -- at two waves per SIMD
+// (215 registers) nothing else hides those round trips (39 % of the wave cycles were s_waitcnt before: profiles/round2_pmc_lds_window.txt).
 template <bool R_LDS, bool W2>
-__global__ __launch_bounds__(256) void k_bge_chol(const uint64_t* __restrict__ masks, double* __restrict__ node_scores, BgeParams bp,
-                                                  BgeQueues qs, int d, int S, unsigned long long* __restrict__ counters) {
+__global__ __launch_bounds__(256) void k_bge_chol(double* __restrict__ node_scores, BgeParams bp, BgeQueues qs, int d, int S,
+                                                  unsigned long long* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ unsigned int cnt_s[BGE_NQ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -542,6 +561,44 @@ __global__ __launch_bounds__(256) void k_bge_chol(const uint64_t* __restrict__ m
     total += units[qi];
   }
   if (blockIdx.x >= total) return;  // (block-uniform)
+  const int W = W2 ? 2 : 1;
+  // work unit u -> (tier, index inside the tier), largest tier first
+  auto unit_of = [&](unsigned int u, int& qi, unsigned int& local) {
+    qi = BGE_NQ - 1;
+    unsigned int base = 0;
+#pragma unroll
+    for (int t = BGE_NQ - 1; t > 0; --t)
+      if (qi == t && u >= base + units[t]) { base += units[t]; qi = t - 1; }
+    local = u - base;
+  };
+  // queue entries of this thread's problems of a unit (up to BGE_NPL0 per thread; a quad / a wave shares one entry); j = ~0: no problem
+  auto fetch = [&](int qi, unsigned int local, uint4 (&ea)[BGE_NPL0], uint4 (&eb)[BGE_NPL0]) {
+    const unsigned int n_q = cnt_s[qi];
+    const int npl = qi == 0 ? BGE_NPL0 : (qi == 1 ? BGE_NPL1 : (qi == 2 ? BGE_NPL2 : 1));
+    const unsigned int usz = qi < 4 ? 256u * (unsigned int)npl : (qi < 8 ? 64u : (unsigned int)nwg);
+    const unsigned int idx = qi < 4 ? (unsigned int)tid : (qi < 8 ? (unsigned int)(tid >> 2) : (unsigned int)wave);
+    const bool lane_ok = qi < 8 || wave < nwg;
+    const uint4* lst = qs.list + (size_t)qi * qs.cap * W;
+#pragma unroll
+    for (int v = 0; v < BGE_NPL0; ++v) {
+      const unsigned int pi = local * usz + 256u * (unsigned int)v + idx;
+      const bool has = v < npl && pi < n_q && lane_ok;
+      ea[v] = make_uint4(0u, 0xFFFFFFFFu, 0u, 0u);
+      eb[v] = make_uint4(0u, 0u, 0u, 0u);
+      if (has) {
+        ea[v] = lst[(size_t)pi * W];
+        if (W2) eb[v] = lst[(size_t)pi * W + 1];
+      }
+    }
+  };
+  // (d > 64 with R resident: the second mask word of the entries in flight would cost the second wave per SIMD -- fetched at use there)
+  constexpr bool PRE = !(R_LDS && W2);
+  uint4 na[BGE_NPL0], nb[BGE_NPL0];
+  int nqi;
+  unsigned int nlocal;
+  unit_of(blockIdx.x, nqi, nlocal);
+  if (PRE) fetch(nqi, nlocal, na, nb);  // (in flight while R / Q are staged)
+
   const int ldr = d + 1, msz = ldr * ldr;
   const float* Rg = bp.Rp;
   float* Rs = reinterpret_cast<float*>(smem_raw);
@@ -555,30 +612,38 @@ __global__ __launch_bounds__(256) void k_bge_chol(const uint64_t* __restrict__ m
   }
   int* const qbase = reinterpret_cast<int*>(smem_raw + r_bytes + (size_t)wave * bge_quad_bytes());
   unsigned char* const gbase = smem_raw + r_bytes + 4 * bge_quad_bytes() + (size_t)(wave < nwg ? wave : 0) * bge_generic_wave_bytes(d);
-  const int W = W2 ? 2 : 1;
   // matrix offset of a problem relative to `Rm`: LDS holds [R | Q]; global memory holds Rp and Qp as separate arrays
   const float* Rm = R_LDS ? Rs : Rg;
   const long qoff = R_LDS ? (long)msz : (long)(bp.Qp - bp.Rp);
 
   float flops = 0.f;
-  // one problem: decode, index mask (parents or complement), matrix offset
-  auto load = [&](bool has, uint32_t code, int& jj, int& l, int& li, int& mat, bool& comp, uint64_t& w0, uint64_t& w1) {
-    w0 = 0ull;
-    w1 = 0ull;
-    jj = d;  // (no problem: every index is the padding index)
-    if (has) {
-      jj = (int)(code / (uint32_t)S) % d;
-      w0 = masks[(size_t)code * W];
-      if (W2) w1 = masks[(size_t)code * W + 1];
-    }
+  // one problem: decode its entry, index mask (parents or complement), matrix offset; table entries requested here
+  struct Tab {
+    double Nn, g, ldRv;
+  };
+  auto load = [&](const uint4& ea, const uint4& eb, bool& has, uint32_t& code, int& jj, int& l, int& li, int& mat, bool& comp, uint64_t& w0,
+                  uint64_t& w1, Tab& tb) {
+    has = ea.y != 0xFFFFFFFFu;
+    code = ea.x;
+    jj = has ? (int)ea.y : d;  // (no problem: every index is the padding index)
+    w0 = ((uint64_t)ea.w << 32) | ea.z;
+    w1 = W2 ? (((uint64_t)eb.y << 32) | eb.x) : 0ull;
     l = __popcll(w0) + __popcll(w1);
+    if (PRE) {
+      tb.Nn = has ? bp.Nj[jj] : 0.0;
+      tb.g = has ? bp.gam[(size_t)jj * (d + 1) + l] : 0.0;
+      tb.ldRv = has ? bp.ldR[bp.n_mats > 1 ? jj : 0] : 0.0;
+    }
     comp = has && (l + 1 > d - l);
     bge_index_mask(w0, w1, jj, d, comp);
     li = has ? (comp ? d - 1 - l : l) : 0;  // rows before j
     mat = (int)((comp ? qoff : 0) + ((has && bp.n_mats > 1) ? (long)jj * msz : 0));
   };
-  auto store = [&](bool writer, uint32_t code, int jj, int l, int li, bool comp, float ld2, float last) {
-    if (writer) node_scores[code] = bge_score(bp, jj, l, d, comp, ld2, last);
+  auto store = [&](bool writer, uint32_t code, int jj, const Tab& tb, int l, int li, bool comp, float ld2, float last) {
+    if (writer) {
+      if (PRE) node_scores[code] = bge_score_pre(tb.Nn, tb.g, tb.ldRv, bp.alpha_lambd, l, d, comp, ld2, last);
+      else node_scores[code] = bge_score(bp, jj, l, d, comp, ld2, last);
+    }
     if (counters) {  // profiling: executed Cholesky flops, n^3 / 3 per problem
       const float n = (float)(li + 1);
       flops += writer ? n * n * n * (1.0f / 3.0f) : 0.f;
@@ -591,38 +656,39 @@ __global__ __launch_bounds__(256) void k_bge_chol(const uint64_t* __restrict__ m
     uint32_t code[NPL_];                                                                                       \
     uint64_t w0[NPL_], w1[NPL_];                                                                               \
     float ld2[NPL_], last[NPL_];                                                                               \
-    _Pragma("unroll") for (int v = 0; v < NPL_; ++v) {                                                         \
-      const unsigned int pi = local * (256u * NPL_) + 256u * v + tid;                                          \
-      has[v] = pi < n_q;                                                                                       \
-      code[v] = has[v] ? list[pi] : 0u;                                                                        \
-    }                                                                                                          \
-    _Pragma("unroll") for (int v = 0; v < NPL_; ++v) load(has[v], code[v], jj[v], l[v], li[v], mat[v], comp[v], w0[v], w1[v]); \
+    Tab tb[NPL_];                                                                                              \
+    _Pragma("unroll") for (int v = 0; v < NPL_; ++v) load(ca[v], cb[v], has[v], code[v], jj[v], l[v], li[v], mat[v], comp[v], w0[v], w1[v], tb[v]); \
     bge_chol_lane<NMAX_, W2, NPL_>(Rm, mat, ldr, d, w0, w1, jj, li, ld2, last);                                \
-    _Pragma("unroll") for (int v = 0; v < NPL_; ++v) store(has[v], code[v], jj[v], l[v], li[v], comp[v], ld2[v], last[v]); \
+    _Pragma("unroll") for (int v = 0; v < NPL_; ++v) store(has[v], code[v], jj[v], tb[v], l[v], li[v], comp[v], ld2[v], last[v]); \
   }
 #define BGE_QUAD_TIER(NB_)                                                                                     \
   {                                                                                                            \
-    const unsigned int pi = local * 64u + (tid >> 2);                                                          \
-    const bool has = pi < n_q;                                                                                 \
-    const uint32_t code = has ? list[pi] : 0u;                                                                 \
+    bool has, comp;                                                                                            \
+    uint32_t code;                                                                                             \
     int jj, l, li, mat;                                                                                        \
-    bool comp;                                                                                                 \
     uint64_t w0, w1;                                                                                           \
     float ld2, last;                                                                                           \
-    load(has, code, jj, l, li, mat, comp, w0, w1);                                                             \
-    bge_chol_quad<NB_, W2>(Rm, mat, ldr, d, qbase + (lane >> 2) * BGE_QS, w0, w1, jj, li, ld2, last); \
-    store(has && (tid & 3) == 0, code, jj, l, li, comp, ld2, last);                                            \
+    Tab tb;                                                                                                    \
+    load(ca[0], cb[0], has, code, jj, l, li, mat, comp, w0, w1, tb);                                           \
+    bge_chol_quad<NB_, W2>(Rm, mat, ldr, d, qbase + (lane >> 2) * BGE_QS, w0, w1, jj, li, ld2, last);          \
+    store(has && (tid & 3) == 0, code, jj, tb, l, li, comp, ld2, last);                                            \
   }
   for (unsigned int u = blockIdx.x; u < total; u += gridDim.x) {
-    int qi = BGE_NQ - 1;
-    unsigned int base = 0;
+    const int qi = nqi;
+    uint4 ca[BGE_NPL0], cb[BGE_NPL0];
+    if (PRE) {
 #pragma unroll
-    for (int t = BGE_NQ - 1; t > 0; --t)
-      if (qi == t && u >= base + units[t]) { base += units[t]; qi = t - 1; }
-    const unsigned int local = u - base;
-    const uint32_t* list = qs.list + (size_t)qi * qs.cap;
-    const unsigned int n_q = cnt[0] * (qi == 0) + cnt[1] * (qi == 1) + cnt[2] * (qi == 2) + cnt[3] * (qi == 3) + cnt[4] * (qi == 4) +
-                             cnt[5] * (qi == 5) + cnt[6] * (qi == 6) + cnt[7] * (qi == 7) + cnt[8] * (qi == 8);
+      for (int v = 0; v < BGE_NPL0; ++v) {
+        ca[v] = na[v];
+        cb[v] = nb[v];
+      }
+    } else {
+      fetch(nqi, nlocal, ca, cb);
+    }
+    if (u + gridDim.x < total) {  // (block-uniform)
+      unit_of(u + gridDim.x, nqi, nlocal);
+      if (PRE) fetch(nqi, nlocal, na, nb);
+    }
     switch (qi) {
       case 0: BGE_LANE_TIER(4, BGE_NPL0) break;
       case 1: BGE_LANE_TIER(8, BGE_NPL1) break;
@@ -634,16 +700,15 @@ __global__ __launch_bounds__(256) void k_bge_chol(const uint64_t* __restrict__ m
       case 7: BGE_QUAD_TIER(8) break;
       default:
         if (W2) {
-          const unsigned int pi = local * (unsigned int)nwg + wave;
-          const bool has = pi < n_q && wave < nwg;
-          const uint32_t code = has ? list[pi] : 0u;
+          bool has, comp;
+          uint32_t code;
           int jj, l, li, mat;
-          bool comp;
           uint64_t w0, w1;
           float ld2 = 0.f, last = 1.f;
-          load(has, code, jj, l, li, mat, comp, w0, w1);
+          Tab tb;
+          load(ca[0], cb[0], has, code, jj, l, li, mat, comp, w0, w1, tb);
           if (has) bge_chol_wave(Rm, mat, ldr, d, gbase, w0, w1, jj, li, ld2, last);
-          store(has && lane == 0, code, jj, l, li, comp, ld2, last);
+          store(has && lane == 0, code, jj, tb, l, li, comp, ld2, last);
         }
         break;
     }

@@ -14,8 +14,8 @@ void dibs_allow_lds(const void* kernel, size_t bytes);
 void bge_launch_sample(bool sample, hipStream_t stream, const uint32_t* thr, uint64_t* masks, double* node_scores, const BgeParams& bp,
                        Key2 carry, int m0, int M, int Mloc, int d, int S, int W, int layout, const BgeQueues& qs, const KmatFuse& kf);
 size_t bge_sample_lds_bytes(int d, int S, int W);
-void bge_launch_chol(hipStream_t stream, const uint64_t* masks, double* node_scores, const BgeParams& bp, const BgeQueues& qs, int d,
-                     int S, unsigned long long* counters);
+void bge_launch_chol(hipStream_t stream, double* node_scores, const BgeParams& bp, const BgeQueues& qs, int d, int S,
+                     unsigned long long* counters);
 void bge_launch_sum_nodes(hipStream_t stream, const double* node_scores, float* out, int d, int S);
 
 // ---- tu_acyc.hip -------------------------------------------------------------------------------------

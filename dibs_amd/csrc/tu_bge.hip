@@ -27,8 +27,8 @@ void bge_launch_sample(bool sample, hipStream_t stream, const uint32_t* thr, uin
   }
 }
 
-void bge_launch_chol(hipStream_t stream, const uint64_t* masks, double* node_scores, const BgeParams& bp, const BgeQueues& qs, int d,
-                     int S, unsigned long long* counters) {
+void bge_launch_chol(hipStream_t stream, double* node_scores, const BgeParams& bp, const BgeQueues& qs, int d, int S,
+                     unsigned long long* counters) {
   const bool w2 = d > 64;
   bool rl = bp.n_mats == 1;
   if (rl && bge_chol_lds_bytes(d, true) > (size_t)150 * 1024) rl = false;
@@ -37,7 +37,7 @@ void bge_launch_chol(hipStream_t stream, const uint64_t* masks, double* node_sco
 #define CHOL(RL_, W2_)                                                                                                  \
   {                                                                                                                     \
     allow_lds(k_bge_chol<RL_, W2_>, lds);                                                                               \
-    hipLaunchKernelGGL((k_bge_chol<RL_, W2_>), grid, block, lds, stream, masks, node_scores, bp, qs, d, S, counters);             \
+    hipLaunchKernelGGL((k_bge_chol<RL_, W2_>), grid, block, lds, stream, node_scores, bp, qs, d, S, counters);                    \
   }
   if (rl && !w2) CHOL(true, false)
   else if (rl) CHOL(true, true)

@@ -55,16 +55,52 @@ def _rms(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)))
 
 
-def _within_f32_noise(name, dev, dbg64, dbg32, floor, factor=3.0):
-    """At these sizes the deviations from the f64 oracle are float32 arithmetic itself, not the kernels: R rounded to f32 and
-    n ~ 25 pivots per factorisation give node-score errors up to ~1 for a few ill-conditioned parent sets (out of 10^6), and the
-    softmax over the S log-scores turns near-ties into O(1e-2) differences of single weights.  The oracle's own f32 build shows
-    the same numbers (tests/tools/gpu_bge_accuracy.py).  Such buffers are therefore compared in RMS against what the f32 oracle
-    loses on the same state: rms(device - f64) <= max(floor * max|ref|, factor * rms(f32 oracle - f64))."""
+# Fixed bounds on rms(device - f64 oracle) of the estimator buffers at the benchmarked sizes, taken from round 3's measurements (about
+# 2-3x the largest value seen over t = 0, 1, 5, 20 of the headline trajectory and config 4's step 2; the run is bit-reproducible).  At
+# these sizes the deviation from the f64 oracle is float32 arithmetic itself: R rounded to f32 and n ~ 25 pivots per factorisation give
+# node-score errors up to ~1 for a few ill-conditioned parent sets out of 10^6, and the softmax over the S log-scores turns near-ties into
+# O(1e-2) differences of single weights.  The oracle's own f32 build on the same state is printed beside the device as a DIAGNOSTIC (it
+# shows the same numbers: device / f32 oracle at t = 1: node scores 1.04e-3 / 1.58e-3, log p(D|G) 8.2e-3 / 1.1e-2); it no longer moves
+# the bound.      name: (absolute rms bound, or None) , (rms bound relative to max |ref|, or None)
+# config 3 free run, checkpoint: (Z, theta) relative to max |.| of the f64 oracle.  Measured: Z 2.40e-4 / 2.38e-4 / 2.36e-4 at steps 25 / 50 / 100
+# (the oracle's f32 build: 1.9e-4 -- the offset appears in the first steps and does not grow), theta 8.8e-6 (f32 build: 2e-3)
+CONFIG3_BOUNDS = {25: (5e-4, 3e-5), 50: (5e-4, 3e-5), 100: (5e-4, 3e-5)}
+# one SVGD step on Z from the device's own state, relative to max |Z|, per step index.  Measured 2.8e-8 / 3.2e-4 / 6.2e-8 / 4.3e-8 at
+# t = 0 / 1 / 5 / 20 (f32 build of the oracle: 2.8e-8 / 7.9e-4 / 4.5e-8 / 4.3e-8) and 1.7e-6 for config 4's step 2: north_star's 1e-4 holds
+# with four orders of magnitude to spare except at t = 1, the first step with a likelihood term, where RMSprop's second-moment estimate
+# is still ~0 and a coordinate whose phi is float32 noise moves by a full step of either sign.
+Z_STEP_BOUNDS = {0: 1e-6, 1: 1e-3, 5: 1e-6, 20: 1e-6, "config4": 1e-5}
+STAGE_BOUNDS = {
+    "node_scores": (3e-3, None),    # measured <= 1.33e-3 (values ~ 4e2)
+    "logprobs_z": (2.5e-2, None),   # measured <= 1.01e-2 (values ~ 4e3 .. 7e3)
+    "w_lik": (2e-3, None),          # measured <= 6.9e-4 (values up to 20)
+    "grad_z": (None, 3e-6),         # measured 6.0e-7 .. 9.8e-7 of max |grad| (up to 5e6: float32 rounding of the sum)
+    "phi_z": (None, 3e-6),          # measured 6.0e-7 .. 9.8e-7 of max |phi|
+}
+
+
+def _stage_check(name, dev, dbg64, dbg32):
     ref = np.asarray(dbg64[name], np.float64)
     e_dev, e_32 = _rms(dev, ref), _rms(dbg32[name], ref)
-    ok = e_dev <= max(floor * np.abs(ref).max(), factor * e_32)
-    return ok, f"{name}: rms device-f64 {e_dev:.2e}, rms f32oracle-f64 {e_32:.2e}, max|ref| {np.abs(ref).max():.2e}"
+    b_abs, b_rel = STAGE_BOUNDS[name]
+    bound = b_abs if b_abs is not None else b_rel * np.abs(ref).max()
+    return e_dev <= bound, f"{name}: rms device-f64 {e_dev:.2e} (bound {bound:.1e}; f32 oracle-f64 {e_32:.2e}, max|ref| {np.abs(ref).max():.2e})"
+
+
+def _update_check(cfg, x_prev, v_prev, phi_dev, phi_ref, x_dev, x_ref):
+    """The optimizer step on one segment.  RMSprop maps phi to a step of ~stepsize / sqrt(0.1) whatever its size while the second-moment
+    estimate is still small: a coordinate whose phi lies below the float32 noise of the largest one takes that step in a direction
+    decided by rounding (in the reference's float32 arithmetic as well; measured here: 6e-2 of max |Z| on < 1 % of the coordinates with
+    every stage buffer, phi included, equal to 1e-6).  So the new value is compared with the oracle on the coordinates that carry signal
+    (|phi| > 1e-3 max |phi|), and on ALL coordinates with the optimizer applied to the device's own phi."""
+    phi_ref = np.asarray(phi_ref, np.float64).ravel()
+    phi_dev = np.asarray(phi_dev, np.float64).ravel()[:phi_ref.size]
+    x_prev, v_prev = np.asarray(x_prev, np.float64).ravel(), np.asarray(v_prev, np.float64).ravel()
+    x_dev, x_ref = np.asarray(x_dev, np.float64).ravel(), np.asarray(x_ref, np.float64).ravel()
+    big = np.abs(phi_ref) > 1e-3 * np.abs(phi_ref).max()
+    x_upd = x_prev - cfg.stepsize * phi_dev / np.sqrt(0.9 * v_prev + 0.1 * phi_dev ** 2 + 1e-8)
+    return dict(all=float(np.abs(x_dev - x_ref).max() / np.abs(x_ref).max()), signal=float(np.abs(x_dev - x_ref)[big].max() / np.abs(x_ref).max()),
+                vs_own_phi=rel_err(x_dev, x_upd), signal_share=float(big.mean()))
 
 
 def test_headline_stage_parity(c_oracle64, c_oracle32):
@@ -97,16 +133,17 @@ def test_headline_stage_parity(c_oracle64, c_oracle32):
         assert (g["key"] == st["key"]).all()
         assert rel_err(eng.read("SCORES"), dbg["scores"]) < 2e-6
         ns = eng.read("NODE_SCORES").reshape(M, d, S).transpose(0, 2, 1)
-        checks = [_within_f32_noise("node_scores", ns, dbg, dbg32, 1e-5), _within_f32_noise("logprobs_z", eng.read("LOGPROBS_Z"), dbg, dbg32, 2e-6),
-                  _within_f32_noise("w_lik", eng.read("W_LIK"), dbg, dbg32, 2e-4), _within_f32_noise("grad_z", eng.read("GRAD_Z"), dbg, dbg32, 1e-5),
-                  _within_f32_noise("phi_z", eng.read("PHI_Z"), dbg, dbg32, 1e-5)]
+        checks = [_stage_check("node_scores", ns, dbg, dbg32), _stage_check("logprobs_z", eng.read("LOGPROBS_Z"), dbg, dbg32),
+                  _stage_check("w_lik", eng.read("W_LIK"), dbg, dbg32), _stage_check("grad_z", eng.read("GRAD_Z"), dbg, dbg32),
+                  _stage_check("phi_z", eng.read("PHI_Z"), dbg, dbg32)]
         print(f"t={t}: " + "; ".join(msg for _, msg in checks))
         assert all(ok for ok, _ in checks), f"t={t}: {checks}"
         assert rel_err(eng.read("W_ACYC"), dbg["w_acyc"]) < 1e-5, f"t={t}"
         assert rel_err(eng.read("KXX"), dbg["kxx"]) < 1e-5, f"t={t}"
-        # one step on Z: north_star's 1e-4 wherever float32 itself holds it (the f32 oracle's deviation is the yardstick)
-        z_noise = rel_err(st32["z"], st["z"])
-        assert rel_err(g["z"], st["z"]) < max(1e-4, 3 * z_noise), f"t={t}: f32 oracle deviates {z_noise:.1e}"
+        # one step on Z from the device's state (fixed bound; the f32 oracle's own deviation is printed as a diagnostic)
+        z_dev, z_noise = rel_err(g["z"], st["z"]), rel_err(st32["z"], st["z"])
+        print(f"t={t}: one step on Z: device-f64 {z_dev:.2e}, f32 oracle-f64 {z_noise:.2e}")
+        assert z_dev < Z_STEP_BOUNDS[t], f"t={t}: {z_dev:.2e} (f32 oracle deviates {z_noise:.1e})"
     eng.close()
 
 
@@ -140,6 +177,50 @@ def test_config3_fullsize_step(c_oracle64):
     eng.close()
 
 
+def test_config3_free_running_100_steps(c_oracle64, c_oracle32):
+    """BASELINE config 3 at its stated size (JointDiBS + LinearGaussian, d=50, 128 particles, reparam estimator, defaults), free-running
+    for 100 steps from PRNGKey(1) on the factory's data (dibs/target.py:122-187) against the oracle's f64 build, with its f32 build
+    beside it as a printed diagnostic.  Asserted with fixed bounds (CONFIG3_BOUNDS, measured values beside them): theta within north_star's
+    1e-4, identical posterior graphs and E-SHD at every checkpoint, Z within the bound float32 arithmetic holds at this size (the Z
+    gradient is a softmax-weighted sum over 128 soft graphs whose log-joints differ by hundreds: near-ties move single weights)."""
+    from dibs_amd import random
+    from dibs_amd.inference import JointDiBS
+    from dibs_amd.metrics import expected_shd
+    from dibs_amd.target import make_linear_gaussian_model
+    d, M = 50, 128
+    data, gm, lm = make_linear_gaussian_model(key=random.PRNGKey(0), n_vars=d, graph_prior_str="er")
+    dibs = JointDiBS(x=data.x, graph_model=gm, likelihood_model=lm)
+    cfg = dibs._make_config(M, d)
+    eng = _engine(cfg, data.x)
+    eng.init_particles(prng.PRNGKey(1))
+    st = c_oracle64.new_state(cfg, prng.PRNGKey(1))
+    st32 = c_oracle32.new_state(cfg, prng.PRNGKey(1))
+    half = max(NT // 2, 1)
+    t = 0
+    for cp in (25, 50, 100):
+        th = [threading.Thread(target=c_oracle64.run, args=(cfg, data.x, None, st, t, cp - t), kwargs=dict(n_threads=half)),
+              threading.Thread(target=c_oracle32.run, args=(cfg, data.x, None, st32, t, cp - t), kwargs=dict(n_threads=half))]
+        for x_ in th:
+            x_.start()
+        eng.run(t, cp - t)
+        for x_ in th:
+            x_.join()
+        t = cp
+        g = eng.get_state()
+        ez, et = rel_err(g["z"], st["z"]), rel_err(g["theta"], st["theta"])
+        gd, go = dibs.particle_to_g_lim(g["z"]), dibs.particle_to_g_lim(np.asarray(st["z"], np.float32))
+        same = float((gd == go).all(axis=(1, 2)).mean())
+        e_d = expected_shd(dist=dibs.get_empirical(gd, g["theta"].reshape(M, d, d)), g=data.g)
+        e_o = expected_shd(dist=dibs.get_empirical(go, np.asarray(st["theta"], np.float32).reshape(M, d, d)), g=data.g)
+        print(f"config 3 step {cp}: rel err z {ez:.2e} theta {et:.2e} (f32 oracle: z {rel_err(st32['z'], st['z']):.2e} theta "
+              f"{rel_err(st32['theta'], st['theta']):.2e}); identical graphs {same:.3f}; E-SHD gpu {e_d:.4f} oracle {e_o:.4f}")
+        assert (g["key"] == st["key"]).all()
+        bz, bt = CONFIG3_BOUNDS[cp]
+        assert ez < bz and et < bt, (cp, ez, et)
+        assert same == 1.0 and abs(e_d - e_o) < 1e-3, (cp, same, e_d, e_o)
+    eng.close()
+
+
 def test_config4_sharded_fullsize(c_oracle64, c_oracle32):
     """BASELINE config 4: BGe, d=50, 1024 particles sharded over 8 ranks.  (JointDiBS + BGe is not constructible in the
     reference -- BGe has no parameters, linearGaussian.py:53-54 -- so the config runs as MarginalDiBS)
@@ -161,13 +242,15 @@ def test_config4_sharded_fullsize(c_oracle64, c_oracle32):
     sref = ref.get_state()
     assert (sref["key"] == st["key"]).all()
     ns = ref.read("NODE_SCORES").reshape(M, d, 128).transpose(0, 2, 1)
-    checks = [_within_f32_noise("node_scores", ns, dbg, dbg32, 1e-5), _within_f32_noise("w_lik", ref.read("W_LIK"), dbg, dbg32, 2e-4),
-              _within_f32_noise("phi_z", ref.read("PHI_Z"), dbg, dbg32, 1e-5)]
+    checks = [_stage_check("node_scores", ns, dbg, dbg32), _stage_check("w_lik", ref.read("W_LIK"), dbg, dbg32),
+              _stage_check("phi_z", ref.read("PHI_Z"), dbg, dbg32)]
     print("config 4: " + "; ".join(msg for _, msg in checks))
     assert all(ok for ok, _ in checks), checks
     assert rel_err(ref.read("W_ACYC"), dbg["w_acyc"]) < 1e-5
     assert rel_err(ref.read("KXX"), dbg["kxx"]) < 1e-5
-    assert rel_err(sref["z"], st["z"]) < max(1e-4, 3 * rel_err(st32["z"], st["z"]))
+    z_dev, z_noise = rel_err(sref["z"], st["z"]), rel_err(st32["z"], st["z"])
+    print(f"config 4: one step on Z: device-f64 {z_dev:.2e}, f32 oracle-f64 {z_noise:.2e}")
+    assert z_dev < Z_STEP_BOUNDS["config4"], (z_dev, z_noise)
     ref.close()
     del dbg, dbg32
     tstream = torch.cuda.Stream()
@@ -222,6 +305,46 @@ def test_config5_fullsize_step(c_oracle64):
     assert rel_err(eng.read("PHI_THETA"), dbg["phi_theta"]) < 2e-3
     assert rel_err(g["theta"], st["theta"]) < 1e-4
     assert rel_err(g["z"], st["z"]) < 5e-4   # relu' flips at pre-activations within fp32 rounding of 0 (see test_gpu_parity.py)
+    eng.close()
+
+
+def test_config5_factory_data_steps(c_oracle64):
+    """BASELINE config 5 on the data the benchmark uses: make_nonlinear_gaussian_model (MLP ancestral sampling, dibs/target.py:190-260,
+    models/nonlinearGaussian.py:189-242) with a scale-free ground truth, 10 intervention sets of ceil(0.1 d) clamped nodes
+    (target.py:97-105 geometry); d=100, 256 particles.  Two consecutive steps t = 1, 2 from the initial particles, every stage buffer."""
+    from dibs_amd import random
+    from dibs_amd.target import make_nonlinear_gaussian_model
+    d, M, N = 100, 256, 100
+    data, _, _ = make_nonlinear_gaussian_model(key=random.PRNGKey(0), n_vars=d, graph_prior_str="sf", n_observations=N)
+    rng = np.random.default_rng(0)
+    mask = np.zeros((N, d), np.int32)
+    for r in range(0, N, 10):
+        mask[r:r + 10, rng.choice(d, int(np.ceil(0.1 * d)), replace=False)] = 1
+    x = np.where(mask == 1, 0.0, data.x).astype(np.float32)
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=N, joint=True, likelihood="densenn", graph_prior="sf",
+                      nn_hidden=(5,), has_interventions=True)
+    eng = _engine(cfg, x, mask)
+    eng.init_particles(prng.PRNGKey(1))
+    eng.run(0, 1)
+    for t in (1, 2):
+        st = _oracle_state_from_engine(eng)
+        prev = eng.get_state()
+        dbg = c_oracle64.step(cfg, x, mask, st, t, debug=True, n_threads=NT)
+        eng.run(t, 1)
+        g = eng.get_state()
+        assert (g["key"] == st["key"]).all()
+        errs = dict(lp_th=rel_err(eng.read("LOGPROBS_THETA"), dbg["logprobs_th"]), lp_z=rel_err(eng.read("LOGPROBS_Z"), dbg["logprobs_z"]),
+                    g_th=rel_err(eng.read("GRAD_THETA"), dbg["grad_theta"]), w_lik=rel_err(eng.read("W_LIK"), dbg["w_lik"]),
+                    w_acyc=rel_err(eng.read("W_ACYC"), dbg["w_acyc"]), g_z=rel_err(eng.read("GRAD_Z"), dbg["grad_z"]),
+                    phi_th=rel_err(eng.read("PHI_THETA"), dbg["phi_theta"]), phi_z=rel_err(eng.read("PHI_Z"), dbg["phi_z"]))
+        upd_z = _update_check(cfg, prev["z"], prev["v_z"], eng.read("PHI_Z"), dbg["phi_z"], g["z"], st["z"])
+        upd_t = _update_check(cfg, prev["theta"], prev["v_theta"], eng.read("PHI_THETA"), dbg["phi_theta"], g["theta"], st["theta"])
+        print(f"config 5 (factory data) t={t}: " + ", ".join(f"{k_} {v:.1e}" for k_, v in errs.items()) + f"; z {upd_z}; theta {upd_t}")
+        assert errs["lp_th"] < 2e-5 and errs["lp_z"] < 2e-5 and errs["w_acyc"] < 1e-5
+        assert max(errs["g_th"], errs["w_lik"], errs["g_z"], errs["phi_th"], errs["phi_z"]) < 2e-3
+        for u in (upd_z, upd_t):   # north_star's 1e-4 on the coordinates with signal (measured for Z: 2e-8 .. 4e-7; own-phi 2e-8 .. 3e-8)
+            assert u["signal"] < 1e-4 and u["vs_own_phi"] < 1e-6, u
+        assert upd_z["signal_share"] > 0.9, upd_z   # (measured > 0.99)
     eng.close()
 
 

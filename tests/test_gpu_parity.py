@@ -721,8 +721,20 @@ def test_marginal_bge_reparam_estimator(d, M, S, Sa, interv):
         assert rel_err(eng.read("LOGPROBS_Z"), lp_o) < (5e-5 if d < 50 else 3e-4)
         dz = (aux["dz_lik"] + aux["dz_prior"]).numpy()
         assert rel_err(eng.read("GRAD_Z"), dz) < 2e-3
-        assert rel_err(eng.read("PHI_Z"), aux["phi_z"].numpy()) < 2e-3
-        assert rel_err(g["z"], st2.z.numpy()) < 1e-4
+        phi_o = aux["phi_z"].numpy()
+        phi_dev = eng.read("PHI_Z").reshape(phi_o.shape)
+        assert rel_err(phi_dev, phi_o) < 2e-3
+        # RMSprop from v = 0 maps phi to a step of +-stepsize / sqrt(0.1) whatever its size: a coordinate whose phi lies below the float32
+        # noise of the largest one (d = 100, one particle, two soft graphs: most of them) may take that step with the other sign.  Those
+        # coordinates are checked against the optimizer applied to the DEVICE's phi, all others against the oracle's z.
+        z0, v0, z_o = st.z.numpy(), st.v_z.numpy(), st2.z.numpy()
+        big = np.abs(phi_o) > 1e-2 * np.abs(phi_o).max()
+        assert big.any() and np.abs(g["z"] - z_o)[big].max() / np.abs(z_o).max() < 1e-4
+        v1 = 0.9 * v0 + 0.1 * phi_dev.astype(np.float64) ** 2
+        z_upd = z0 - cfg.stepsize * phi_dev / np.sqrt(v1 + 1e-8)
+        assert rel_err(g["z"], z_upd) < 1e-5
+        if d < 65:
+            assert rel_err(g["z"], z_o) < 1e-4
         st = st2
     eng.close()
 

@@ -151,18 +151,34 @@ def main():
             if np.abs(dbg["scores"]).max() * cfg.alpha_linear * max(step, 1) > 15.0:
                 # soft graphs within float rounding of 0 / 1: g (1 - g) is rounding noise times matrix-power entries, for the reference's
                 # float32 arithmetic as for the device's (plain gradient descent with a one-dimensional latent space gets there in 2 steps)
-                e, note = min(e, 0.0), note + " (saturated: not compared)"
+                e, note = min(e, 0.0), note + " (saturated: Z not compared)"
             if not np.isfinite(g["z"]).all():
                 e, note = float("inf"), note + " non-finite"
+            # stage buffers are compared in EVERY trial, also where Z is not (saturation, Bernoulli boundary flips, phi-only comparisons):
+            # the deterministic stages always, the estimator stages wherever their inputs are the oracle's
+            stage = {"SCORES": (rel(eng.read("SCORES"), dbg["scores"]), 5e-6), "KXX": (rel(eng.read("KXX"), dbg["kxx"]), 2e-5)}
+            same_s = None   # [M, S]: sampled graph identical to the oracle's (BGe; the other families draw no Bernoulli graphs for Z)
             if fam == "bge":
                 # a Bernoulli draw flips where the uniform falls between the float32 and the float64 value of sigmoid(alpha s): a handful of
                 # the M S d^2 bits at the larger sizes (for the reference's float32 arithmetic against the f64 oracle as well)
                 gg = graphs_from_masks(eng.read("PARENT_MASKS"), kw["n_particles"], kw["n_grad_mc_samples"], kw["n_vars"])
                 nflip = int((gg != dbg["g_samples"]).sum())
+                same_s = (gg == dbg["g_samples"]).all(axis=(2, 3))
                 if nflip > max(2, 1e-5 * gg.size):
                     note += f" graphs-differ({nflip} of {gg.size})"
                 elif nflip:
-                    e, note = min(e, 0.0), note + f" ({nflip} Bernoulli boundary flips of {gg.size}: not compared)"
+                    e, note = min(e, 0.0), note + f" ({nflip} Bernoulli boundary flips of {gg.size}: Z not compared)"
+            lp_d, lp_o = eng.read("LOGPROBS_Z").reshape(M, S), np.asarray(dbg["logprobs_z"], np.float64).reshape(M, S)
+            sel = np.ones((M, S), bool) if same_s is None else same_s
+            if sel.any() and np.isfinite(lp_o[sel]).all():
+                stage["LOGPROBS_Z"] = (float(np.abs(lp_d - lp_o)[sel].max() / max(np.abs(lp_o[sel]).max(), 1e-300)), 2e-4 if os.environ.get("FUZZ_SCALE") else 5e-5)
+            if (same_s is None or same_s.all()) and np.isfinite(dbg["w_lik"]).all() and np.abs(dbg["w_lik"]).max() > 0:
+                # (softmax-weighted: a near-tie of two log-scores moves single entries by O(alpha); the RMS over the matrix catches a wrong kernel)
+                wd, wo = eng.read("W_LIK").astype(np.float64).ravel(), np.asarray(dbg["w_lik"], np.float64).ravel()
+                stage["W_LIK"] = (float(np.sqrt(np.mean((wd - wo) ** 2)) / max(np.sqrt(np.mean(wo ** 2)), 1e-300)), 5e-2)
+            for name, (err, lim) in stage.items():
+                if not err <= lim:
+                    e, note = max(e, 1.0), note + f" stage-differs({name} {err:.1e} > {lim:.0e})"
             if not (g["key"] == st["key"]).all():
                 note += " key-differs"
             worst = max(worst, e)
