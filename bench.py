@@ -10,7 +10,8 @@ before the timed region.  W untimed steps t = 0..W-1 of the trajectory from PRNG
 between barrier + synchronize fences (max over ranks).  The cost of a step depends on t (sampled parent sets shrink as the particles
 sharpen), so the timed window is restored from a snapshot and measured repeatedly -- at least `--reps` times and until the timed
 regions add up to `--min-seconds` of GPU time: `value` comes from the MEDIAN repetition, `rep_ms_per_step` summarises all of them.
-N > 1 shards the particles over the ranks (strong scaling: total work fixed) with one RCCL all-gather of the packed rows per step.
+N > 1 shards the particles over the ranks (strong scaling: total work fixed); per step one RCCL all-gather of the gradient rows between the
+phases and one of the new values beside the next phase A (dibs_amd/distributed.py).
 Rank 0 prints ONE JSON line (DESIGN.md "Measurement" explains every field).
 
 --config selects the workload: `headline` (default) is BASELINE.json's metric config; 2 .. 5 are BASELINE.json configs[1..4] at their
@@ -178,25 +179,36 @@ def main():
         eng.set_data(x, mask)
         eng.init_particles(random.PRNGKey(1))
         if N > 1:
-            from dibs_amd.distributed import make_buffers, run_sharded
+            from dibs_amd.distributed import OverlapBuffers, refresh_values, run_sharded_overlapped
             with torch.cuda.stream(tstream):
-                send, recv = make_buffers(eng, N, torch.device("cuda", local_rank), torch.float32)
+                buf = OverlapBuffers(eng, N, torch.device("cuda", local_rank), torch.float32)
+            send, recv = buf.gsend, buf.grads
 
             def run(t0, n):
                 with torch.cuda.stream(tstream):
-                    run_sharded(eng, t0, n, send, recv)   # phase A -> one all-gather (RCCL) -> phase B, per step
+                    # per step: phase A (+ kernel-matrix slab from the values gathered on the side stream) -> all-gather of the gradient
+                    # rows (RCCL) -> phase B -> export + all-gather of the new values on the side stream, beside the next phase A
+                    run_sharded_overlapped(eng, t0, n, buf)
+
+            def restore(snap_):
+                eng.set_state(**snap_)
+                with torch.cuda.stream(tstream):
+                    refresh_values(eng, buf)   # untimed: the values of the restored state (in a run they were gathered during the step before)
         else:
             send = recv = None
 
             def run(t0, n):
                 eng.run(t0, n)
+
+            def restore(snap_):
+                eng.set_state(**snap_)
         run(0, W)                       # untimed warm-up: steps 0 .. W-1 of the trajectory
         fence()
         snap = {k_: v for k_, v in eng.get_state().items() if v is not None}   # state at t = W (this rank's particles)
         rep_s, total = [], 0.0
         while len(rep_s) < max(reps_min, 1) or (total < min_seconds and len(rep_s) < 2000):
             if rep_s:
-                eng.set_state(**snap)   # untimed: back to t = W
+                restore(snap)           # untimed: back to t = W
             fence()
             t_begin = time.perf_counter()
             run(W, K)                   # timed: steps W .. W+K-1
@@ -208,9 +220,9 @@ def main():
                 el = float(tt.item())
             rep_s.append(el)
             total += el
-        return eng, run, snap, rep_s, (cfg, x, mask), (tstream, send, recv)
+        return eng, run, snap, rep_s, (cfg, x, mask), (tstream, send, recv, restore)
 
-    eng, run, snap, rep_s, (cfg, x, mask), (tstream, send, recv) = measure(args.config, M, args.reps, args.min_seconds)
+    eng, run, snap, rep_s, (cfg, x, mask), (tstream, send, recv, restore) = measure(args.config, M, args.reps, args.min_seconds)
     elapsed = float(np.median(rep_s))
     steps_per_s = K / elapsed
     c = CONFIGS[args.config]
@@ -223,7 +235,7 @@ def main():
         "config": {"workload": c["label"], "name": args.config, "n_vars": d, "n_particles": M, "n_observations": N_OBS,
                    "n_grad_mc_samples": S_MC, "n_acyclicity_mc_samples": SA_MC,
                    "timed_steps": f"t={W}..{W + K - 1} of one trajectory from PRNGKey(1)",
-                   "parallelism": f"particles sharded over {N} rank(s), 1 all-gather/step" if N > 1 else "single GPU"},
+                   "parallelism": f"particles sharded over {N} rank(s); gradients all-gathered between the phases, values beside phase A" if N > 1 else "single GPU"},
         "reps": len(rep_s), "timed_seconds_total": float(np.sum(rep_s)),
         "rep_ms_per_step": {"median": 1e3 * elapsed / K, "min": 1e3 * min(rep_s) / K, "max": 1e3 * max(rep_s) / K,
                             "first5": [1e3 * r / K for r in rep_s[:5]]},
@@ -232,7 +244,7 @@ def main():
 
     if N > 1:
         # ---- diagnosis of a sharded run: per-rank kernel timers, the collective alone, config 4 beside the strong-scaling headline ----
-        eng.set_state(**snap)
+        restore(snap)
         eng.set_profiling(True)
         eng.reset_timers()
         run(W, K)
@@ -253,7 +265,9 @@ def main():
         ag_us = e0.elapsed_time(e1) / 50 * 1e3
         out["sharded"] = {
             "kernel_us_per_step_by_rank": allk, "allgather_us": ag_us, "allgather_bytes_per_rank": int(send.numel() * 4),
-            "exchange": "phase A -> ONE all_gather_into_tensor of [z | grad_z | theta | grad_theta] -> phase B, on one stream (not overlapped)",
+            "exchange": "overlapped: the values [z | theta] are all-gathered on a side stream right after the optimizer step (beside the next "
+                        "phase A, where the kernel-matrix slab is computed from them on the engine's second stream); between phase A and phase B "
+                        "only the gradient rows travel (allgather_us / allgather_bytes_per_rank are THAT collective)",
             "strong_scaling_bound": "128 particles: a rank's step is 6-7 dependent launches of 6-20 us that do not shrink with the shard "
                                     "(profiles/round2_shard_scaling.txt: 212 / 159 / 107 / 96 us per rank-step at 1/2/4/8 ranks on one GPU, "
                                     "before the collective) => <= 2.2x at 8 GPUs; the >= 6x of north_star needs per-rank work >> launch "

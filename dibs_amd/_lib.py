@@ -18,6 +18,8 @@ EXPORTS = [
     "dibs_engine_step_local", "dibs_engine_step_update", "dibs_engine_gather_elems_per_rank", "dibs_engine_sync",
     "dibs_engine_read_buffer", "dibs_engine_buffer_bytes", "dibs_engine_theta_size", "dibs_engine_set_profiling",
     "dibs_engine_get_timers", "dibs_engine_reset_timers", "dibs_engine_get_counters", "dibs_score_graphs",
+    "dibs_engine_plane_elems_per_rank", "dibs_engine_export_values", "dibs_engine_step_local_grads", "dibs_engine_step_update_planes",
+    "dibs_engine_kmat_values",
 ]
 
 
@@ -65,6 +67,12 @@ def load():
     lib.dibs_engine_step_update.argtypes = [vp, i32, vp]
     lib.dibs_engine_gather_elems_per_rank.argtypes = [vp]
     lib.dibs_engine_gather_elems_per_rank.restype = i64
+    lib.dibs_engine_plane_elems_per_rank.argtypes = [vp]
+    lib.dibs_engine_plane_elems_per_rank.restype = i64
+    lib.dibs_engine_export_values.argtypes = [vp, vp]
+    lib.dibs_engine_step_local_grads.argtypes = [vp, i32, vp]
+    lib.dibs_engine_kmat_values.argtypes = [vp, vp, vp]
+    lib.dibs_engine_step_update_planes.argtypes = [vp, i32, vp, vp]
     lib.dibs_engine_sync.argtypes = [vp]
     lib.dibs_engine_read_buffer.argtypes = [vp, i32, vp, i64]
     lib.dibs_engine_buffer_bytes.argtypes = [vp, i32]
@@ -77,7 +85,7 @@ def load():
     lib.dibs_engine_get_counters.argtypes = [vp, vp, i32]
     lib.dibs_score_graphs.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp]
     for name in EXPORTS:
-        if name not in ("dibs_last_error", "dibs_abi_version", "dibs_engine_gather_elems_per_rank",
+        if name not in ("dibs_last_error", "dibs_abi_version", "dibs_engine_gather_elems_per_rank", "dibs_engine_plane_elems_per_rank",
                         "dibs_engine_buffer_bytes", "dibs_engine_theta_size"):
             getattr(lib, name).restype = i32
     _lib = lib

@@ -56,7 +56,7 @@ struct BgeStats {
 struct dibs_engine {
   dibs_config cfg;
   int d, k, M, Mloc, m0, N, S, Sa, W;
-  int64_t D, P, E;  // z elems / theta elems per particle, packed row stride (floats)
+  int64_t D, P, E, Ev;  // z elems / theta elems per particle, packed row stride [z | grad_z | theta | grad_theta], plane row stride [z | theta] (floats)
   int dpad, ldk, acyc_nt, acyc_cpb, acyc_nblk, acyc_units;
   float sigz;
   hipStream_t stream;
@@ -87,6 +87,7 @@ struct dibs_engine {
                             // overlap with their vector work.  Same arithmetic, same results; DIBS_NO_ACYC_STREAM2 keeps one stream.
   hipEvent_t ev_fork, ev_join, ev_k0, ev_k1;
   bool kmat_early;  // this step's kernel matrices were launched on the second stream (behind the acyclicity kernel)
+  bool kmat_ext;    // ... or by dibs_engine_kmat_values on a stream of the caller (overlapped exchange)
   double t_ms[DIBS_K_COUNT];
   int64_t t_n[DIBS_K_COUNT];
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
@@ -145,6 +146,7 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   e->D = (int64_t)e->d * e->k * 2;
   e->P = theta_size(c);
   e->E = ((2 * e->D + 2 * e->P) + 3) & ~(int64_t)3;
+  e->Ev = ((e->D + e->P) + 3) & ~(int64_t)3;
   e->dpad = (e->d + 15) & ~15;
   {
     const int kp = (e->k + 3) & ~3;
@@ -587,7 +589,20 @@ static void drain_timers(dibs_engine* e) {
 // the host walks the chain (row 0), kernels derive row 1 + m.
 static Key2 next_carry(const dibs_engine* e, Key2 k) { return rng_split_row(k, (uint32_t)e->M + 1u, 0u, e->cfg.rng_layout); }
 
-static int step_local(dibs_engine* e, int t, float* pack) {
+// where phase A writes its per-particle rows (indexed by GLOBAL particle id): packed rows [z | grad_z | theta | grad_theta] (stride E, the
+// single-rank buffer and the one-collective protocol) or gradient rows [grad_z | grad_theta] (stride Ev, the overlapped protocol, where
+// the values travel separately).
+struct RowTarget {
+  float* base;
+  size_t stride, gz_off, th_off, gth_off;
+  int copy_vals;
+};
+static RowTarget packed_rows(const dibs_engine* e, float* pack) {
+  return RowTarget{pack, (size_t)e->E, (size_t)e->D, (size_t)(2 * e->D), (size_t)(2 * e->D + e->P), 1};
+}
+
+static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
+  float* const pack = rt.base;
   const dibs_config& c = e->cfg;
   const float alpha = (float)(c.alpha_linear * t), beta = (float)(c.beta_linear * t);
   const int L = c.rng_layout;
@@ -680,7 +695,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     score_lik = true;  // softmax weights, W_lik and the baseline are part of k_particle_grad below
   } else if (c.likelihood == DIBS_LIK_LINGAUSS) {
     JointLaunch jl{e->stream, e->z, e->theta, e->scores, e->thr, e->w_lik, e->logprobs_z, e->logprobs_th, e->baseline,
-                   e->baseline2, pack, (size_t)e->E, (size_t)(2 * e->D), (size_t)(2 * e->D + e->P), e->m0, e->M, e->Mloc, e->d,
+                   e->baseline2, pack, rt.stride, rt.th_off, rt.gth_off, rt.copy_vals, e->m0, e->M, e->Mloc, e->d,
                    e->N, e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny, c.grad_estimator_z, c.score_function_baseline,
                    (float)c.lin_obs_noise, (float)c.lin_mean_edge, (float)c.lin_sig_edge};
     {
@@ -694,7 +709,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     }
   } else if (c.likelihood == DIBS_LIK_DENSENN) {
     JointLaunch jl{e->stream, e->z, e->theta, e->scores, e->thr, e->w_lik, e->logprobs_z, e->logprobs_th, e->baseline,
-                   e->baseline2, pack, (size_t)e->E, (size_t)(2 * e->D), (size_t)(2 * e->D + e->P), e->m0, e->M, e->Mloc, e->d,
+                   e->baseline2, pack, rt.stride, rt.th_off, rt.gth_off, rt.copy_vals, e->m0, e->M, e->Mloc, e->d,
                    e->N, e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny, c.grad_estimator_z, c.score_function_baseline,
                    0.f, 0.f, 0.f};
     const NNParams np_ = nn_params(c);
@@ -730,7 +745,7 @@ static int step_local(dibs_engine* e, int t, float* pack) {
     const size_t lds = tail_lds_bytes(e->d, ldz, e->S, e->W, score_lik, cap);
     const TailArgs ta{score_lik ? e->node_scores : nullptr, e->masks, e->logprobs_z, e->baseline, e->baseline2, c.score_function_baseline,
                       score_lik ? e->bq.counts : nullptr, e->S, e->W, cap, e->probs, e->w_lik, e->w_acyc, alpha, beta, c.graph_prior, er_c,
-                      e->z, pack, (size_t)e->E, e->m0, e->d, e->k, ldz, 1.0f / (e->sigz * e->sigz), e->profiling ? e->counters : nullptr};
+                      e->z, pack, rt.stride, rt.copy_vals, e->m0, e->d, e->k, ldz, 1.0f / (e->sigz * e->sigz), e->profiling ? e->counters : nullptr};
     allow_lds(k_particle_grad, lds);
     hipLaunchKernelGGL(k_particle_grad, dim3(e->Mloc), dim3(TAIL_NT), lds, e->stream, ta);
     if (score_lik) std::swap(e->baseline, e->baseline2);
@@ -740,21 +755,38 @@ static int step_local(dibs_engine* e, int t, float* pack) {
   return 0;
 }
 
-static int step_update(dibs_engine* e, int t, const float* pack) {
+// where phase B reads the rows of ALL particles: packed rows (stride E) or the two planes [values | gradients] of the overlapped protocol
+// (one allocation, [2][M][Ev]: both planes share the row stride, the gradient plane starts M * Ev floats later)
+struct RowSource {
+  const float* base;
+  size_t stride, z_off, gz_off, th_off, gth_off;
+};
+static RowSource packed_source(const dibs_engine* e, const float* pack) {
+  return RowSource{pack, (size_t)e->E, 0, (size_t)e->D, (size_t)(2 * e->D), (size_t)(2 * e->D + e->P)};
+}
+static RowSource plane_source(const dibs_engine* e, const float* planes) {
+  const size_t g = (size_t)e->M * e->Ev;
+  return RowSource{planes, (size_t)e->Ev, 0, g, (size_t)e->D, g + (size_t)e->D};
+}
+
+static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_send = nullptr) {
   (void)t;
+  const float* const pack = rs.base;
   const dibs_config& c = e->cfg;
-  if (!e->kmat_early && (!e->kmat_fused || c.joint)) {
+  const bool kmat_ext = e->kmat_ext;  // computed from the gathered values on the caller's side stream (dibs_engine_kmat_values)
+  e->kmat_ext = false;
+  if (!kmat_ext && !e->kmat_early && (!e->kmat_fused || c.joint)) {
     KTimer tm(e, DIBS_K_KMAT);
     const int ksym = e->Mloc == e->M;  // single rank: the slab is the whole (symmetric) matrix
     auto kmat_lds = [](size_t len) { return (size_t)(((len < KMAT_CH ? len : (size_t)KMAT_CH) + 3) & ~(size_t)3) * 4; };
     allow_lds(k_kmat, kmat_lds(e->D > e->P ? e->D : e->P));
     const dim3 kg(e->Mloc, (e->M + KMAT_BT - 1) / KMAT_BT);
     if (!e->kmat_fused)
-      hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->D), e->stream, pack, (size_t)e->E, (size_t)0,
+      hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->D), e->stream, pack, rs.stride, rs.z_off,
                          (int)e->D, e->kz, e->m0, e->M, (float)c.scale_latent, (float)c.h_latent, ksym);
     if (c.joint)
-      hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->P), e->stream, pack, (size_t)e->E,
-                         (size_t)(2 * e->D), (int)e->P, e->kt, e->m0, e->M, (float)c.scale_theta, (float)c.h_theta, ksym);
+      hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->P), e->stream, pack, rs.stride,
+                         rs.th_off, (int)e->P, e->kt, e->m0, e->M, (float)c.scale_theta, (float)c.h_theta, ksym);
   }
   {
     KTimer tm(e, DIBS_K_PHI_UPDATE);
@@ -769,14 +801,14 @@ static int step_update(dibs_engine* e, int t, const float* pack) {
       const dim3 g((unsigned)(8 * ngroups * ((cols + 7) / 8)));
 #define PHI_LAUNCH(TA_)                                                                                                        \
       allow_lds(k_phi_update<TA_>, lds);                                                                                         \
-      hipLaunchKernelGGL(k_phi_update<TA_>, g, dim3(256), lds, e->stream, pack, (size_t)e->E, val_off, grad_off, (int)len, e->kz, \
+      hipLaunchKernelGGL(k_phi_update<TA_>, g, dim3(256), lds, e->stream, pack, rs.stride, val_off, grad_off, (int)len, e->kz, \
                          e->kt, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize, c.optimizer == DIBS_OPT_RMSPROP, \
-                         (int)cols, ngroups);
+                         (int)cols, ngroups, vals_send, (size_t)e->Ev, is_theta ? (size_t)e->D : (size_t)0);
       if (ta == 16) { PHI_LAUNCH(16) } else if (ta == 8) { PHI_LAUNCH(8) } else { PHI_LAUNCH(4) }
 #undef PHI_LAUNCH
     };
-    phi((size_t)0, (size_t)e->D, (size_t)e->D, 0, e->z, e->vz, e->phi_z, (float)c.h_latent);
-    if (c.joint) phi((size_t)(2 * e->D), (size_t)(2 * e->D + e->P), (size_t)e->P, 1, e->theta, e->vtheta, e->phi_th, (float)c.h_theta);
+    phi(rs.z_off, rs.gz_off, (size_t)e->D, 0, e->z, e->vz, e->phi_z, (float)c.h_latent);
+    if (c.joint) phi(rs.th_off, rs.gth_off, (size_t)e->P, 1, e->theta, e->vtheta, e->phi_th, (float)c.h_theta);
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(err));
@@ -789,8 +821,8 @@ extern "C" int dibs_engine_run(dibs_engine* e, int32_t t_start, int32_t n_steps)
   if (e->cfg.n_ranks != 1) return fail("dibs_engine_run is single-rank; use step_local / step_update");
   HIP_OK(hipSetDevice(e->cfg.device_id));
   for (int t = t_start; t < t_start + n_steps; ++t) {
-    if (step_local(e, t, e->pack)) return 1;
-    if (step_update(e, t, e->pack)) return 1;
+    if (step_local(e, t, packed_rows(e, e->pack))) return 1;
+    if (step_update(e, t, packed_source(e, e->pack))) return 1;
     if (e->profiling && e->pending.size() > 4096) drain_timers(e);
   }
   HIP_OK(hipStreamSynchronize(e->stream));
@@ -805,13 +837,65 @@ extern "C" int dibs_engine_step_local(dibs_engine* e, int32_t t, void* send_dev)
   HIP_OK(hipSetDevice(e->cfg.device_id));
   // send_dev holds only this rank's rows: [Mloc, E]; kernels index rows by global particle id
   float* base = (float*)send_dev - (size_t)e->m0 * e->E;
-  return step_local(e, t, base);
+  return step_local(e, t, packed_rows(e, base));
+}
+
+// ---- overlapped exchange (see include/dibs_hip.h): values travel right after the optimizer step, gradients between the phases ----
+extern "C" int64_t dibs_engine_plane_elems_per_rank(const dibs_engine* e) { return e ? (int64_t)e->Mloc * e->Ev : 0; }
+
+extern "C" int dibs_engine_export_values(dibs_engine* e, void* vals_send_dev) {
+  if (!e || !vals_send_dev) return fail("null argument");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  float* dst = (float*)vals_send_dev;
+  HIP_OK(hipMemcpy2DAsync(dst, (size_t)e->Ev * 4, e->z, (size_t)e->D * 4, (size_t)e->D * 4, (size_t)e->Mloc, hipMemcpyDeviceToDevice, e->stream));
+  if (e->P)
+    HIP_OK(hipMemcpy2DAsync(dst + e->D, (size_t)e->Ev * 4, e->theta, (size_t)e->P * 4, (size_t)e->P * 4, (size_t)e->Mloc, hipMemcpyDeviceToDevice,
+                            e->stream));
+  return 0;
+}
+
+extern "C" int dibs_engine_step_local_grads(dibs_engine* e, int32_t t, void* grads_send_dev) {
+  if (!e || !grads_send_dev) return fail("null argument");
+  if (!e->has_data) return fail("dibs_engine_set_data has not been called");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  // rows [grad_z | grad_theta] of this rank's particles, stride Ev; kernels index rows by global particle id
+  float* base = (float*)grads_send_dev - (size_t)e->m0 * e->Ev;
+  return step_local(e, t, RowTarget{base, (size_t)e->Ev, 0, 0, (size_t)e->D, 0});
+}
+
+// kernel-matrix slab(s) of the NEXT phase B from the values of all particles (plane 0), launched on `stream` -- the caller's side stream,
+// behind its all-gather of the values, i.e. beside phase A and without any synchronisation of its own.  The caller orders phase B behind it
+// (one event it needs anyway: phase B reads plane 0 as well).
+extern "C" int dibs_engine_kmat_values(dibs_engine* e, const void* vals_all_dev, void* stream) {
+  if (!e || !vals_all_dev || !stream) return fail("null argument");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  const dibs_config& c = e->cfg;
+  hipStream_t st = (hipStream_t)stream;
+  auto kmat_lds = [](size_t len) { return (size_t)(((len < KMAT_CH ? len : (size_t)KMAT_CH) + 3) & ~(size_t)3) * 4; };
+  dibs_allow_lds((const void*)k_kmat, kmat_lds(e->D > e->P ? e->D : e->P));
+  const dim3 kg(e->Mloc, (e->M + KMAT_BT - 1) / KMAT_BT);
+  const int ksym = e->Mloc == e->M;
+  const float* vals = (const float*)vals_all_dev;
+  hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->D), st, vals, (size_t)e->Ev, (size_t)0, (int)e->D, e->kz, e->m0, e->M, (float)c.scale_latent,
+                     (float)c.h_latent, ksym);
+  if (c.joint)
+    hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->P), st, vals, (size_t)e->Ev, (size_t)e->D, (int)e->P, e->kt, e->m0, e->M, (float)c.scale_theta,
+                       (float)c.h_theta, ksym);
+  HIP_OK(hipGetLastError());
+  e->kmat_ext = true;
+  return 0;
+}
+
+extern "C" int dibs_engine_step_update_planes(dibs_engine* e, int32_t t, const void* planes_dev, void* vals_send_dev) {
+  if (!e || !planes_dev) return fail("null argument");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  return step_update(e, t, plane_source(e, (const float*)planes_dev), (float*)vals_send_dev);
 }
 
 extern "C" int dibs_engine_step_update(dibs_engine* e, int32_t t, const void* recv_dev) {
   if (!e || !recv_dev) return fail("null argument");
   HIP_OK(hipSetDevice(e->cfg.device_id));
-  return step_update(e, t, (const float*)recv_dev);
+  return step_update(e, t, packed_source(e, (const float*)recv_dev));
 }
 
 extern "C" int64_t dibs_engine_gather_elems_per_rank(const dibs_engine* e) { return e ? (int64_t)e->Mloc * e->E : 0; }

@@ -39,6 +39,7 @@ struct JointLaunch {
   float* baseline_out;
   float* pack;
   size_t pack_stride, theta_off, gtheta_off;
+  int copy_theta;  // 1: packed rows carry a copy of theta at theta_off; 0: gradient rows only
   int m0, M, Mloc, d, N, S;
   float alpha, tau;
   int layout, tiny, est_z;
@@ -682,7 +683,7 @@ static void joint_lin_grads(JointWork* w, const JointLaunch& jl, Key2 carry_thet
   const size_t lds2 = lin_lds_bytes(jl.d, jl.N, NT, true);
   if (lds2 > 48 * 1024) hipFuncSetAttribute((const void*)k_lin_grad<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
   const LinGradJob jt{jl.logprobs_th, jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off, jl.pack_stride,
-                      jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off, nullptr, carry_theta, LIN_MODE_THETA};
+                      jl.copy_theta ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr, nullptr, carry_theta, LIN_MODE_THETA};
   const LinGradJob jz{jl.logprobs_z, jl.w_lik, (size_t)jl.d * jl.d, nullptr, jl.baseline_out, carry_z,
                       jl.est_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM};
   hipLaunchKernelGGL(k_lin_grad<NT>, dim3(jl.Mloc, 2), dim3(256), lds2, jl.stream, w->x, w->mask, jl.theta, jl.scores, jl.thr, jt, jz,
@@ -726,7 +727,7 @@ void joint_lin_all_grads(JointWork* w, const JointLaunch& jl, Key2 carry_theta, 
     const size_t lds = ling_lds(jl.d, ng, true);
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_ling_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const LinGradJob jt{jl.logprobs_th, jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off, jl.pack_stride,
-                        jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off, nullptr, carry_theta, LIN_MODE_THETA};
+                        jl.copy_theta ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr, nullptr, carry_theta, LIN_MODE_THETA};
     const LinGradJob jz{jl.logprobs_z, jl.w_lik, (size_t)jl.d * jl.d, nullptr, jl.baseline_out, carry_z,
                         jl.est_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM};
     hipLaunchKernelGGL(k_ling_grad, dim3(jl.Mloc, 2), dim3(256), lds, jl.stream, w->gram, ng, jl.theta, jl.scores, jl.thr, jt, jz, jl.baseline,

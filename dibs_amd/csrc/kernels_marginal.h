@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, si
 //     phi_a = -(1/M) sum_b [ (kz+kt)[a,b] grad_b - (2/h) kseg[a,b] (x_b - x_a) ]   (column kxx[:,a], symmetric kernel)
 //     rmsprop: v = 0.9 v + 0.1 phi^2 ; x -= step * phi / sqrt(v + 1e-8)      |  gd: x -= step * phi
 //     reference: svgd.py:194-224, 591-670, 265, 718-719; jax.example_libraries.optimizers.rmsprop
-// grid = (ceil(len / 256), ceil(Mloc / TA)), block = 256
+// grid = (ceil(len / 256), ceil(Mloc / TA)), block = 256;  vout != null: the updated segment is also written to vout[a][vout_off + i]
 // ------------------------------------------------------------------------------------------------
 // block = 64 consecutive elements x TA local particles; wave w sums over the quarter b in [w Mq, (w+1) Mq) of the particles and
 // the four partial sums are added in wave order (the order is a function of M only: results do not depend on TA or the rank
@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
                                                     size_t grad_off, int len, const float* __restrict__ kz,
                                                     const float* __restrict__ kt, int seg_is_theta, float* __restrict__ x,
                                                     float* __restrict__ v, float* __restrict__ phi_out, int m0, int Mloc,
-                                                    int M, float h, float stepsize, int rmsprop, int ncols, int ngroups) {
+                                                    int M, float h, float stepsize, int rmsprop, int ncols, int ngroups,
+                                                    float* __restrict__ vout, size_t vout_stride, size_t vout_off) {
   // 1-D grid, XCD-aware: workgroups go round-robin to the 8 XCDs, each with its own L2.  Linear id L = 8 (ngroups c_hi + g) + c_lo runs
   // the `ngroups` particle groups of column slab c = 8 c_hi + c_lo on XCD c_lo, back to back: the slab's [z_b | grad_b] rows (64 KiB) are
   // fetched into that L2 once instead of once per group (a (cols, groups) grid spread every slab over 4 XCDs and re-read the 5 MB of
@@ -189,13 +190,17 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
     const float xv = pack[(size_t)(m0 + a) * pack_stride + val_off + i];
     const size_t o = (size_t)a * len + i;
     if (phi_out) phi_out[o] = phi;
+    float xn;
     if (rmsprop) {
       const float vv = v[o] * 0.9f + phi * phi * 0.1f;
       v[o] = vv;
-      x[o] = xv - stepsize * phi / sqrtf(vv + 1e-8f);
+      xn = xv - stepsize * phi / sqrtf(vv + 1e-8f);
     } else {
-      x[o] = xv - stepsize * phi;
+      xn = xv - stepsize * phi;
     }
+    x[o] = xn;
+    // overlapped exchange: the new value also goes straight into this rank's send rows [Mloc][Ev] (no separate export pass)
+    if (vout) vout[(size_t)a * vout_stride + vout_off + i] = xn;
   }
 }
 

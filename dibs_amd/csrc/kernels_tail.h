@@ -38,8 +38,9 @@ struct TailArgs {
   float er_c;
   // C
   const float* z;  // [Mloc][d][k][2]
-  float* pack;
+  float* pack;          // row of particle m0 + m: [z | grad_z | ...] (copy_z) or [grad_z | ...] (gradient rows only)
   size_t pack_stride;
+  int copy_z;           // 1: packed rows [z | grad_z | ...]; 0: the row starts with grad_z and z is not copied
   int m0, d, k, ldz;
   float inv_sig2;
   unsigned long long* dbg;  // profiling: phase time stamps of block 0 (100 MHz ticks, accumulated in dbg[1..5]); null in production
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
   // MFMA operands: A[row = lane % 16][k = lane / 16], B[k = lane / 16][col = lane % 16], D[row = 4 (lane / 16) + r][col = lane % 16]
   float* prow = A.pack + (size_t)(A.m0 + m) * A.pack_stride;
   float2* pz = reinterpret_cast<float2*>(prow);
-  float2* pg = reinterpret_cast<float2*>(prow + (size_t)d * k * 2);
+  float2* pg = reinterpret_cast<float2*>(prow + (A.copy_z ? (size_t)d * k * 2 : (size_t)0));
   const int ntj = (k + 15) >> 4, ntiles = (dp16 >> 4) * ntj, g = lane >> 4, r = lane & 15;
   for (int t = wave; t < ntiles; t += TAIL_NT / 64) {
     const int ti = t / ntj, tj = t - ti * ntj;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
         const int i = ti * 16 + 4 * g + rr;
         if (i < d) {
           const float2 zi = make_float2(Us[i * ldz + q], Vs[i * ldz + q]);
-          pz[i * k + q] = zi;
+          if (A.copy_z) pz[i * k + q] = zi;
           pg[i * k + q] = make_float2(du[rr] - zi.x * A.inv_sig2, dv[rr] - zi.y * A.inv_sig2);
         }
       }

@@ -1,16 +1,28 @@
 """Particle-sharded SVGD over several ranks (one process per GPU, torch.distributed).
 
 The reference has no multi-device code.  Every estimator of a step is per particle; only the
-kernel matrix / phi couple particles, so a step is
+kernel matrix / phi couple particles.  Two protocols over the same arithmetic (bit-identical results):
+
+``run_sharded`` -- one collective per step
     phase A  engine.step_local(t, send)      estimators for this rank's M/G particles, packed rows
                                              [z | grad_z | theta | grad_theta]
     exchange ONE all_gather_into_tensor(recv, send)     (RCCL over xGMI with backend "nccl")
     phase B  engine.step_update(t, recv)     kernel slab, phi and optimizer step for the local particles
-PRNG rows are indexed by the global particle id and phi sums over b in global order, so the result does not depend
-on the number of ranks (tests/test_distributed_gloo.py checks bit-equality against the single-rank run).
 
-``engine`` is anything exposing step_local / step_update / gather_elems_per_rank with tensors' data_ptr()s: the HIP
-Engine (dibs_amd.engine) in production, the oracle adapter in the CPU gloo test."""
+``run_sharded_overlapped`` -- the default of ``sample_sharded`` and ``bench.py``
+    The kernel matrix and the repulsive term need the VALUES [z | theta] of all particles, and those are final as soon as the previous
+    optimizer step is done; only the GRADIENTS depend on phase A.  So after phase B every rank exports its new values and they are
+    all-gathered on a SIDE stream while phase A of the next step runs; the kernel-matrix slab is computed from them on that same stream,
+    behind the gather.  Between the phases only the gradient rows travel (half the bytes), and phase B is phi + optimizer.
+        side stream:   all_gather(values(t)) -> kernel-matrix slab(t) ----.
+        main stream:   phase A(t) ------------> all_gather(gradients(t)) -> phase B(t), which also writes values(t+1) into the send rows
+    Both collectives are issued on the same process group in the same order on every rank (values(t), then gradients(t)).
+
+PRNG rows are indexed by the global particle id and phi sums over b in global order, so the result does not depend
+on the number of ranks (tests/test_distributed_gloo.py checks bit-equality against the single-rank run for both protocols).
+
+``engine`` is anything exposing the calls used below with tensors' data_ptr()s: the HIP Engine (dibs_amd.engine) in production, the
+oracle adapter in the CPU gloo test."""
 import numpy as np
 
 
@@ -42,22 +54,89 @@ def run_sharded(engine, t_start, n_steps, send, recv, group=None):
         engine.step_update(t, recv.data_ptr())
 
 
-def _gather_particles(eng, n_particles, group):
-    """z (and theta) of all ranks' particles as numpy arrays, on every rank"""
+class OverlapBuffers:
+    """Buffers of the overlapped protocol: per-rank send rows for values and gradients, and ONE allocation `planes` = [2][M][Ev]
+    (plane 0: values [z | theta] of all particles, plane 1: their gradients) that phase B reads.  On a GPU the values travel on `side`
+    (a second torch stream); `vals_ready` is recorded there after each gather of the values."""
+
+    def __init__(self, engine, world_size, device, dtype):
+        import torch
+        n = engine.plane_elems_per_rank()
+        self.n, self.world = n, world_size
+        self.vsend = torch.zeros(n, dtype=dtype, device=device)
+        self.gsend = torch.zeros(n, dtype=dtype, device=device)
+        self.planes = torch.zeros(2 * n * world_size, dtype=dtype, device=device)
+        self.vals, self.grads = self.planes[:n * world_size], self.planes[n * world_size:]
+        self.cuda = torch.device(device).type == "cuda"
+        self.side = torch.cuda.Stream(device=device) if self.cuda else None
+        self.vals_ready = torch.cuda.Event() if self.cuda else None
+        self.exported = torch.cuda.Event() if self.cuda else None
+        self.fresh = False   # plane 0 holds the values of the engine's current state
+
+
+def _gather(dst, src, group, single):
+    import torch.distributed as dist
+    if single:
+        dst.copy_(src)
+    else:
+        dist.all_gather_into_tensor(dst, src, group=group)
+
+
+def _exchange_values(engine, buf, group, single, exported=False):
+    """this rank's [z | theta] (exported here on the current = engine stream unless phase B already wrote them into the send rows) are
+    gathered into plane 0 on the side stream"""
+    import torch
+    if not exported:
+        engine.export_values(buf.vsend.data_ptr())
+    if buf.cuda:
+        buf.exported.record(torch.cuda.current_stream())
+        with torch.cuda.stream(buf.side):
+            buf.side.wait_event(buf.exported)
+            _gather(buf.vals, buf.vsend, group, single)
+            engine.kmat_values(buf.vals.data_ptr(), buf.side.cuda_stream)   # kernel-matrix slab of the next phase B, behind the gather
+            buf.vals_ready.record(buf.side)
+    else:
+        _gather(buf.vals, buf.vsend, group, single)
+    buf.fresh = True
+
+
+def refresh_values(engine, buf, group=None):
+    """(re-)gather the values after the engine's state was set from outside (init_particles / set_state); run_sharded_overlapped does it
+    on demand, callers that time a run do it beforehand"""
+    import torch.distributed as dist
+    _exchange_values(engine, buf, group, (not dist.is_initialized()) or dist.get_world_size(group) == 1)
+
+
+def run_sharded_overlapped(engine, t_start, n_steps, buf, group=None):
+    """steps t_start .. t_start + n_steps - 1 with the values exchanged off the critical path (see the module docstring).  Call it inside
+    ``torch.cuda.stream(<the engine's stream>)`` on a GPU.  `buf.fresh` must be False whenever the engine's state was set from outside
+    (init_particles, set_state) since the last call."""
     import torch
     import torch.distributed as dist
-    eng.sync()
-    st = eng.get_state()
-    z = torch.from_numpy(st["z"]).cuda()
-    zs = torch.empty((n_particles,) + tuple(z.shape[1:]), dtype=z.dtype, device=z.device)
-    dist.all_gather_into_tensor(zs, z, group=group)
-    ths = None
-    if st["theta"] is not None:
-        th = torch.from_numpy(st["theta"]).cuda()
-        ths = torch.empty((n_particles, th.shape[1]), dtype=th.dtype, device=th.device)
-        dist.all_gather_into_tensor(ths, th, group=group)
-        ths = ths.cpu().numpy()
-    return zs.cpu().numpy(), ths
+    single = (not dist.is_initialized()) or dist.get_world_size(group) == 1
+    if not buf.fresh:
+        _exchange_values(engine, buf, group, single)
+    for t in range(t_start, t_start + n_steps):
+        engine.step_local_grads(t, buf.gsend.data_ptr())                                # phase A
+        _gather(buf.grads, buf.gsend, group, single)                                    # the exchange on the critical path: gradients only
+        if buf.cuda:
+            torch.cuda.current_stream().wait_event(buf.vals_ready)                      # values + kernel matrix (done long ago)
+        engine.step_update_planes(t, buf.planes.data_ptr(), buf.vsend.data_ptr())       # phase B: phi + optimizer (+ new values -> send rows)
+        _exchange_values(engine, buf, group, single, exported=True)                     # values of step t + 1, beside its phase A
+
+
+def _all_particles(eng, buf, n_particles, group):
+    """z (and theta) of ALL ranks' particles as numpy arrays, on every rank: plane 0 of the overlapped protocol already holds them on
+    the device after every step (no extra collective, one device-to-host copy)."""
+    import torch
+    import torch.distributed as dist
+    if not buf.fresh:
+        _exchange_values(eng, buf, group, (not dist.is_initialized()) or dist.get_world_size(group) == 1)
+    if buf.cuda:
+        buf.vals_ready.synchronize()
+    D, P = eng.d * eng.k * 2, eng.P
+    v = buf.vals.view(n_particles, -1).cpu().numpy()
+    return np.ascontiguousarray(v[:, :D]).reshape(n_particles, eng.d, eng.k, 2), (np.ascontiguousarray(v[:, D:D + P]) if P else None)
 
 
 def sample_sharded(dibs, *, key, n_particles, steps, n_dim_particles=None, callback_every=None, callback=None, group=None):
@@ -79,19 +158,19 @@ def sample_sharded(dibs, *, key, n_particles, steps, n_dim_particles=None, callb
             dibs.latent_prior_std = float(np.float32(1.0) / np.sqrt(np.float32(n_dim)))
         callback_every = callback_every or steps
         with torch.cuda.stream(stream):
-            send, recv = make_buffers(eng, world, torch.device("cuda", dev), torch.float32)
+            buf = OverlapBuffers(eng, world, torch.device("cuda", dev), torch.float32)
             for t in (range(0, steps, callback_every) if steps else range(0)):
-                run_sharded(eng, t, callback_every, send, recv, group)
+                run_sharded_overlapped(eng, t, callback_every, buf, group)
                 if callback:
-                    # same keyword arguments as MarginalDiBS.sample / JointDiBS.sample (svgd.py:318-324, :783-789): ALL particles
-                    stream.synchronize()
-                    zs_all, th_all = _gather_particles(eng, n_particles, group)
+                    # same keyword arguments as MarginalDiBS.sample / JointDiBS.sample (svgd.py:318-324, :783-789): ALL particles,
+                    # on every rank (the callback runs on every rank)
+                    zs_all, th_all = _all_particles(eng, buf, n_particles, group)
                     kw = dict(dibs=dibs, t=t + callback_every, zs=zs_all)
                     if dibs._joint:
                         kw["thetas"] = dibs._theta_out(th_all)
                     callback(**kw)
+            out_z, th_all = _all_particles(eng, buf, n_particles, group)
         stream.synchronize()
-        out_z, th_all = _gather_particles(eng, n_particles, group)
         if dibs._joint:
             return dibs.particle_to_g_lim(out_z), dibs._theta_out(th_all)
         return dibs.particle_to_g_lim(out_z)

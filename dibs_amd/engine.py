@@ -78,6 +78,25 @@ class Engine:
     def gather_elems_per_rank(self):
         return int(self.lib.dibs_engine_gather_elems_per_rank(self._h))
 
+    # overlapped exchange (include/dibs_hip.h): values right after the optimizer step, gradients between the phases
+    def plane_elems_per_rank(self):
+        return int(self.lib.dibs_engine_plane_elems_per_rank(self._h))
+
+    def export_values(self, vals_send_ptr):
+        _lib.check(self.lib.dibs_engine_export_values(self._h, C.c_void_p(vals_send_ptr)))
+
+    def step_local_grads(self, t, grads_send_ptr):
+        _lib.check(self.lib.dibs_engine_step_local_grads(self._h, int(t), C.c_void_p(grads_send_ptr)))
+
+    def kmat_values(self, vals_all_ptr, stream):
+        if not stream:
+            raise ValueError("kmat_values needs the handle of the (non-default) stream the values were gathered on")
+        _lib.check(self.lib.dibs_engine_kmat_values(self._h, C.c_void_p(vals_all_ptr), C.c_void_p(stream)))
+
+    def step_update_planes(self, t, planes_ptr, vals_send_ptr=None):
+        _lib.check(self.lib.dibs_engine_step_update_planes(self._h, int(t), C.c_void_p(planes_ptr),
+                                                           C.c_void_p(vals_send_ptr) if vals_send_ptr else None))
+
     def sync(self):
         _lib.check(self.lib.dibs_engine_sync(self._h))
 

@@ -152,6 +152,23 @@ int dibs_engine_step_update(dibs_engine* e, int32_t t, const void* recv_dev);
 int64_t dibs_engine_gather_elems_per_rank(const dibs_engine* e);
 int dibs_engine_sync(dibs_engine* e);
 
+/* The same split with the exchange OVERLAPPED (no reference counterpart: the reference has no multi-device code; the arithmetic is
+ * svgd.py:226-267 / 673-721 unchanged).  The kernel matrix and the repulsive term need the VALUES [z | theta] of all particles, which
+ * are final as soon as the previous optimizer step is done; only the GRADIENTS depend on phase A.  So each rank
+ *   dibs_engine_step_update_planes(e, t, planes, vals_send)      ... ends phase B of step t with its new values in `vals_send`, rows
+ *       [Mloc, Ev] of [z | theta] (dibs_engine_export_values writes them for the initial state);
+ *   the caller all-gathers them on a SIDE stream into plane 0 of `planes` ([2][M][Ev] floats) and, behind the gather on that stream,
+ *   dibs_engine_kmat_values(e, plane0, side_stream)              launches the kernel-matrix slab of step t + 1 -- both beside phase A;
+ *   dibs_engine_step_local_grads(e, t + 1, grads_send)           phase A, writing only [grad_z | grad_theta] rows [Mloc, Ev];
+ *   the caller all-gathers the gradient rows into plane 1 (the only exchange between the phases: half the bytes of the packed rows),
+ *   makes the engine stream wait for the side stream's work, and calls dibs_engine_step_update_planes for step t + 1: phi + optimizer.
+ * Results are bit-identical to step_local / step_update and to the single-rank engine.  Ev = dibs_engine_plane_elems_per_rank / Mloc. */
+int64_t dibs_engine_plane_elems_per_rank(const dibs_engine* e);
+int dibs_engine_export_values(dibs_engine* e, void* vals_send_dev);
+int dibs_engine_step_local_grads(dibs_engine* e, int32_t t, void* grads_send_dev);
+int dibs_engine_kmat_values(dibs_engine* e, const void* vals_all_dev, void* stream);
+int dibs_engine_step_update_planes(dibs_engine* e, int32_t t, const void* planes_dev, void* vals_send_dev);
+
 /* debugging / parity: copy a device buffer to the host (nbytes must match); theta size query */
 int dibs_engine_read_buffer(dibs_engine* e, int32_t which, void* host, int64_t nbytes);
 int64_t dibs_engine_buffer_bytes(const dibs_engine* e, int32_t which);

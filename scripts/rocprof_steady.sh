@@ -6,7 +6,7 @@ TAG=${1:-steady}; W=${2:-300}; K=${3:-100}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o $TAG -- python bench.py --no-cpu-baseline --reps 1 --warmup $W --steps $K > $OUT/bench.log 2>&1 || { tail -20 $OUT/bench.log; exit 1; }
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o $TAG -- python bench.py --config ${CONFIG:-headline} --no-cpu-baseline --reps 1 --min-seconds 0 --warmup $W --steps $K > $OUT/bench.log 2>&1 || { tail -20 $OUT/bench.log; exit 1; }
 f=$(find $OUT -name "*kernel_trace.csv" | head -1)
 python - "$f" $K > gpurun_out/${TAG}_steady_kernels.txt <<'PY'
 import csv, sys, collections

@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 from conftest import make_data
 from dibs_amd._abi import make_config
-from dibs_amd.distributed import make_buffers, run_sharded
+from dibs_amd.distributed import OverlapBuffers, make_buffers, run_sharded, run_sharded_overlapped
 from oracle import prng
 
 
@@ -39,6 +39,51 @@ class OracleShardEngine:
     def step_update(self, t, recv_ptr):
         self.co.step_update(self.cfg, self._view(recv_ptr, self.cfg.n_particles * self.E), self.st, n_threads=2)
 
+    # ---- overlapped protocol (values and gradients travel separately; include/dibs_hip.h) on top of the oracle's packed-row phases ----
+    @property
+    def D(self):
+        return self.cfg.n_vars * self.cfg.n_dim * 2
+
+    @property
+    def P(self):
+        return self.co.theta_size(self.cfg)
+
+    @property
+    def Ev(self):
+        return (self.D + self.P + 3) & ~3
+
+    def plane_elems_per_rank(self):
+        return self.Ml * self.Ev
+
+    def export_values(self, vals_send_ptr):
+        v = self._view(vals_send_ptr, self.Ml * self.Ev).reshape(self.Ml, self.Ev)
+        v[:, :self.D] = self.st["z"].reshape(self.Ml, self.D)
+        if self.P:
+            v[:, self.D:self.D + self.P] = self.st["theta"].reshape(self.Ml, self.P)
+
+    def kmat_values(self, vals_all_ptr, stream):
+        pass   # (the oracle's phase B computes the kernel matrix itself)
+
+    def step_local_grads(self, t, grads_send_ptr):
+        D, P = self.D, self.P
+        pack = np.zeros((self.Ml, self.E))
+        self.co.step_local(self.cfg, self.x, self.mask, self.st, t, pack.reshape(-1), n_threads=2)
+        g = self._view(grads_send_ptr, self.Ml * self.Ev).reshape(self.Ml, self.Ev)
+        g[:, :D] = pack[:, D:2 * D]
+        if P:
+            g[:, D:D + P] = pack[:, 2 * D + P:2 * D + 2 * P]
+
+    def step_update_planes(self, t, planes_ptr, vals_send_ptr=None):
+        D, P, M = self.D, self.P, self.cfg.n_particles
+        pl = self._view(planes_ptr, 2 * M * self.Ev).reshape(2, M, self.Ev)
+        pack = np.zeros((M, self.E))
+        pack[:, :D], pack[:, D:2 * D] = pl[0, :, :D], pl[1, :, :D]
+        if P:
+            pack[:, 2 * D:2 * D + P], pack[:, 2 * D + P:2 * D + 2 * P] = pl[0, :, D:D + P], pl[1, :, D:D + P]
+        self.co.step_update(self.cfg, pack.reshape(-1), self.st, n_threads=2)
+        if vals_send_ptr:
+            self.export_values(vals_send_ptr)
+
 
 def _cfg(joint, rank, n_ranks, d, M):
     kw = dict(joint=True, likelihood="lingauss") if joint else {}
@@ -46,7 +91,7 @@ def _cfg(joint, rank, n_ranks, d, M):
                        n_acyclicity_mc_samples=4, rank=rank, n_ranks=n_ranks, **kw)
 
 
-def _worker(rank, world, port, joint, d, M, steps, x, out_dir):
+def _worker(rank, world, port, joint, d, M, steps, x, out_dir, overlapped=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -54,8 +99,13 @@ def _worker(rank, world, port, joint, d, M, steps, x, out_dir):
         from oracle.c_oracle import COracle
         co = COracle("f64")
         eng = OracleShardEngine(co, _cfg(joint, rank, world, d, M), x, None, prng.PRNGKey(4))
-        send, recv = make_buffers(eng, world, torch.device("cpu"), torch.float64)
-        run_sharded(eng, 0, steps, send, recv)
+        if overlapped:   # two chunks: the values gathered after the last step of a chunk serve the first step of the next one
+            buf = OverlapBuffers(eng, world, torch.device("cpu"), torch.float64)
+            run_sharded_overlapped(eng, 0, steps - 1, buf)
+            run_sharded_overlapped(eng, steps - 1, 1, buf)
+        else:
+            send, recv = make_buffers(eng, world, torch.device("cpu"), torch.float64)
+            run_sharded(eng, 0, steps, send, recv)
         z = torch.from_numpy(eng.st["z"])
         zs = [torch.empty_like(z) for _ in range(world)]
         dist.all_gather(zs, z)
@@ -72,12 +122,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("joint", [False, True])
-def test_two_rank_gloo_matches_single_rank(tmp_path, c_oracle64, joint):
+@pytest.mark.parametrize("joint,overlapped", [(False, False), (True, False), (False, True), (True, True)])
+def test_two_rank_gloo_matches_single_rank(tmp_path, c_oracle64, joint, overlapped):
+    """both exchange protocols of dibs_amd/distributed.py: one all-gather of packed rows per step, and values / gradients gathered
+    separately (the values after the optimizer step, the gradients between the phases)"""
     d, M, steps = 6, 8, 3
     data, _, _ = make_data(d, seed=3, joint=joint)
     x = np.ascontiguousarray(data.x, np.float64)
-    mp.spawn(_worker, args=(2, _free_port(), joint, d, M, steps, x, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), joint, d, M, steps, x, str(tmp_path), overlapped), nprocs=2, join=True)
     z2 = np.load(tmp_path / "z.npy")
     key2 = np.load(tmp_path / "key.npy")
     cfg = _cfg(joint, 0, 1, d, M)
@@ -99,3 +151,20 @@ def test_single_process_protocol_equals_fused_step(c_oracle64):
     st = c_oracle64.new_state(cfg, prng.PRNGKey(2))
     c_oracle64.run(cfg, x, None, st, 0, 4)
     assert np.array_equal(eng.st["z"], st["z"])
+
+
+def test_single_process_overlapped_protocol_equals_fused_step(c_oracle64):
+    """run_sharded_overlapped with one rank (copies instead of collectives) == orc_run, for the joint model (theta planes)"""
+    d, M = 5, 4
+    data, _, _ = make_data(d, seed=1, joint=True)
+    x = np.ascontiguousarray(data.x, np.float64)
+    cfg = _cfg(True, 0, 1, d, M)
+    eng = OracleShardEngine(c_oracle64, cfg, x, None, prng.PRNGKey(2))
+    buf = OverlapBuffers(eng, 1, torch.device("cpu"), torch.float64)
+    run_sharded_overlapped(eng, 0, 4, buf)
+    st = c_oracle64.new_state(cfg, prng.PRNGKey(2))
+    c_oracle64.run(cfg, x, None, st, 0, 4)
+    assert np.array_equal(eng.st["z"], st["z"]) and np.array_equal(eng.st["theta"], st["theta"])
+    # plane 0 holds the values of the final state (what sample_sharded returns / hands to the callback)
+    v = buf.vals.view(M, -1).numpy()
+    assert np.array_equal(v[:, :eng.D], st["z"].reshape(M, -1)) and np.array_equal(v[:, eng.D:eng.D + eng.P], st["theta"].reshape(M, -1))

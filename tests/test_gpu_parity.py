@@ -636,6 +636,101 @@ def test_densenn_sample_and_scoring(c_oracle64):
     assert abs(np.exp(mix.logp).sum() - 1) < 1e-6
 
 
+@pytest.mark.parametrize("joint,d", [(False, 20), (True, 20), (False, 50), (True, 50)])
+def test_sharded_engines_overlapped_exchange_matches_single_rank(joint, d):
+    """The overlapped exchange of dibs_amd.distributed.run_sharded_overlapped on ONE GPU: engines for rank 0..R-1 of R in one process; the
+    values [z | theta] are "gathered" (device concat on a SIDE stream, event-ordered exactly as the RCCL path orders them) right after
+    the optimizer step, each rank's kernel-matrix slab is computed from them on that side stream behind the gather, and
+    only the gradient rows are exchanged between the phases.  Must be bit-identical to the single-rank engine."""
+    import torch
+    from dibs_amd.engine import Engine
+    M, R, steps = 16, 4, 5
+    data, _, _ = make_data(d, seed=3, joint=joint)
+    kw = dict(joint=True, likelihood="lingauss") if joint else {}
+    cfg1 = make_config(n_vars=d, n_particles=M, n_observations=100, n_grad_mc_samples=32, n_acyclicity_mc_samples=8, **kw)
+    ref = _engine(cfg1, data.x)
+    ref.init_particles(prng.PRNGKey(8))
+    ref.run(0, steps)
+    sref = ref.get_state()
+    ref.close()
+    tstream, side = torch.cuda.Stream(), torch.cuda.Stream()
+    engs = []
+    for r in range(R):
+        c = make_config(n_vars=d, n_particles=M, n_observations=100, n_grad_mc_samples=32, n_acyclicity_mc_samples=8, rank=r, n_ranks=R, **kw)
+        e = Engine(c, stream=tstream.cuda_stream)
+        e.set_data(data.x)
+        e.init_particles(prng.PRNGKey(8))
+        engs.append(e)
+    n = engs[0].plane_elems_per_rank()
+    exported, ready = torch.cuda.Event(), torch.cuda.Event()
+    with torch.cuda.stream(tstream):
+        vsends = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(R)]
+        gsends = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(R)]
+        planes = torch.zeros(2 * n * R, dtype=torch.float32, device="cuda")
+        vals, grads = planes[:n * R], planes[n * R:]
+
+        def exchange_values(done=False):
+            for r in range(R):
+                if not done:
+                    engs[r].export_values(vsends[r].data_ptr())
+            exported.record(tstream)
+            with torch.cuda.stream(side):
+                side.wait_event(exported)
+                torch.cat(vsends, out=vals)   # stands in for dist.all_gather_into_tensor(vals, vsend) on the side stream
+                for r in range(R):
+                    engs[r].kmat_values(vals.data_ptr(), side.cuda_stream)
+                ready.record(side)
+
+        exchange_values()
+        for t in range(steps):
+            for r in range(R):
+                engs[r].step_local_grads(t, gsends[r].data_ptr())
+            torch.cat(gsends, out=grads)      # stands in for dist.all_gather_into_tensor(grads, gsend)
+            tstream.wait_event(ready)
+            for r in range(R):   # (odd steps: the optimizer kernel writes the send rows itself; even steps: the separate export call)
+                engs[r].step_update_planes(t, planes.data_ptr(), vsends[r].data_ptr() if t % 2 else None)
+            exchange_values(done=bool(t % 2))
+    torch.cuda.synchronize()
+    states = [e.get_state() for e in engs]
+    assert np.array_equal(np.concatenate([s["z"] for s in states]), sref["z"]), "overlapped sharded run must be bit-identical to the single-rank run"
+    assert all((s["key"] == sref["key"]).all() for s in states)
+    if joint:
+        assert np.array_equal(np.concatenate([s["theta"] for s in states]), sref["theta"])
+    D = d * d * 2
+    v = vals.view(M, -1).cpu().numpy()     # plane 0 = the values of the final state (what sample_sharded returns)
+    assert np.array_equal(v[:, :D], sref["z"].reshape(M, D))
+    for e in engs:
+        e.close()
+
+
+def test_run_sharded_overlapped_single_rank_on_gpu():
+    """dibs_amd.distributed.run_sharded_overlapped driven as bench.py / sample_sharded drive it (one rank: copies instead of collectives,
+    the same streams and events) == dibs_engine_run, bit for bit, across two chunks."""
+    import torch
+    from dibs_amd.distributed import OverlapBuffers, run_sharded_overlapped
+    from dibs_amd.engine import Engine
+    d, M = 20, 16
+    data, _, _ = make_data(d, seed=3)
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=100, n_grad_mc_samples=32, n_acyclicity_mc_samples=8)
+    ref = _engine(cfg, data.x)
+    ref.init_particles(prng.PRNGKey(8))
+    ref.run(0, 7)
+    sref = ref.get_state()
+    ref.close()
+    tstream = torch.cuda.Stream()
+    eng = Engine(cfg, stream=tstream.cuda_stream)
+    eng.set_data(data.x)
+    eng.init_particles(prng.PRNGKey(8))
+    with torch.cuda.stream(tstream):
+        buf = OverlapBuffers(eng, 1, torch.device("cuda", 0), torch.float32)
+        run_sharded_overlapped(eng, 0, 4, buf)
+        run_sharded_overlapped(eng, 4, 3, buf)
+    torch.cuda.synchronize()
+    st = eng.get_state()
+    assert np.array_equal(st["z"], sref["z"]) and (st["key"] == sref["key"]).all()
+    eng.close()
+
+
 @pytest.mark.parametrize("joint,d", [(False, 20), (True, 20), (False, 50), (False, 40), (True, 50)])
 def test_sharded_engines_match_single_rank(joint, d):
     """The N > 1 path of bench.py / dibs_amd.distributed on ONE GPU: engines for rank 0..R-1 of R in one process, the
