@@ -2,8 +2,8 @@
 module does not load the HIP library."""
 import ctypes as C
 
-ABI_VERSION = 1
-MAX_HIDDEN_LAYERS = 4
+ABI_VERSION = 2
+MAX_HIDDEN_LAYERS = 8
 
 LIK = {"bge": 0, "lingauss": 1, "densenn": 2}
 PRIOR = {"er": 0, "sf": 1, "uniform": 2}

@@ -57,7 +57,7 @@ struct dibs_engine {
   dibs_config cfg;
   int d, k, M, Mloc, m0, N, S, Sa, W;
   int64_t D, P, E, Ev;  // z elems / theta elems per particle, packed row stride [z | grad_z | theta | grad_theta], plane row stride [z | theta] (floats)
-  int dpad, ldk, acyc_nt, acyc_cpb, acyc_nblk, acyc_units;
+  int dpad, ldk, edge_kc, acyc_nt, acyc_cpb, acyc_nblk, acyc_units;
   float sigz;
   hipStream_t stream;
   bool own_stream;
@@ -72,6 +72,8 @@ struct dibs_engine {
   float* soft_ds;  // [Mloc, S, d, d]  BGe reparam estimator: per-sample score-space gradients
   bool has_data;
   // work
+  float* w_tot;     // [Mloc][d][d] total score-space gradient when a particle's W, U, V do not fit in one block's LDS (kernels_tail.h)
+  float* acyc_big;  // n_vars > 112: buffers of the global-memory matrix powers (kernels_acyc_big.h)
   float *scores, *probs, *w_lik, *acyc_part, *w_acyc, *logprobs_z, *logprobs_th, *pack, *kz, *kt, *phi_z, *phi_th;
   uint32_t* thr;
   uint64_t* masks;
@@ -99,7 +101,7 @@ extern "C" const char* dibs_last_error(void) { return g_err.c_str(); }
 extern "C" int dibs_abi_version(void) { return DIBS_ABI_VERSION; }
 
 static NNParams nn_params(const dibs_config& c) {
-  NNParams p{c.nn_hidden[0], c.nn_activation, c.nn_bias, (float)c.nn_obs_noise, (float)c.nn_sig_param, c.nn_n_hidden, {0, 0, 0, 0}};
+  NNParams p{c.nn_hidden[0], c.nn_activation, c.nn_bias, (float)c.nn_obs_noise, (float)c.nn_sig_param, c.nn_n_hidden, {}};
   for (int l = 0; l < c.nn_n_hidden && l < DIBS_MAX_HIDDEN_LAYERS; ++l) p.hidden[l] = c.nn_hidden[l];
   return p;
 }
@@ -149,8 +151,14 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   e->Ev = ((e->D + e->P) + 3) & ~(int64_t)3;
   e->dpad = (e->d + 15) & ~15;
   {
-    const int kp = (e->k + 3) & ~3;
-    e->ldk = kp + ((2 - kp) % 32 + 32) % 32;  // ldk == 2 (mod 32): conflict-free MFMA operand reads
+    // k_edge_scores walks the latent dimension in chunks of edge_kc columns: one chunk when U and V fit in LDS (n_vars <= 112 with k = d)
+    e->edge_kc = e->k;
+    for (;;) {
+      const int kp = (e->edge_kc + 3) & ~3;
+      e->ldk = kp + ((2 - kp) % 32 + 32) % 32;  // ldk == 2 (mod 32): conflict-free MFMA operand reads
+      if ((size_t)2 * e->dpad * e->ldk * 4 <= LDS_LIMIT - 8192 || e->edge_kc <= 16) break;
+      e->edge_kc = e->edge_kc > 64 ? 64 : e->edge_kc / 2;
+    }
   }
   e->acyc_nt = e->dpad / 16;
   {  // chains per block: fill the 256 CUs in whole rounds (resident blocks per CU limited by the 3 LDS matrices)
@@ -214,8 +222,22 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   HIP_OK(dalloc(&e->probs, Ml * dd));
   HIP_OK(dalloc(&e->thr, Ml * dd));
   HIP_OK(dalloc(&e->w_lik, Ml * dd));
-  HIP_OK(dalloc(&e->acyc_part, Ml * e->acyc_nblk * dd));
+  if (e->d > 112) {
+    if (hipMalloc((void**)&e->acyc_big, acyc_big_elems(e->Mloc, e->d, e->Sa) * 4) != hipSuccess) {
+      e->acyc_big = nullptr;
+      (void)hipGetLastError();
+      return fail("n_vars > 112: the matrix powers of the acyclicity term go through global memory: hipMalloc of " +
+                  std::to_string(acyc_big_elems(e->Mloc, e->d, e->Sa) * 4 >> 20) + " MiB failed");
+    }
+  } else {
+    HIP_OK(dalloc(&e->acyc_part, Ml * e->acyc_nblk * dd));
+  }
   HIP_OK(dalloc(&e->w_acyc, Ml * dd));
+  {
+    const bool score_lik = c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_SCORE;
+    const int ldz = tail_ldz(e->d, e->k, e->S, score_lik, LDS_LIMIT - 2048);
+    if (tail_lds_bytes(e->d, ldz, e->S, e->W, score_lik, 0) > LDS_LIMIT - 2048) HIP_OK(dalloc(&e->w_tot, Ml * dd));
+  }
   HIP_OK(dalloc(&e->logprobs_z, Ml * e->S));
   HIP_OK(dalloc(&e->logprobs_th, Ml * e->S));
   HIP_OK(dalloc(&e->pack, (size_t)e->M * e->E));
@@ -228,7 +250,7 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
     HIP_OK(dalloc(&e->masks, Ml * e->S * e->d * e->W));
     HIP_OK(dalloc(&e->node_scores, Ml * e->S * e->d));
     e->bq.cap = (uint32_t)(Ml * e->S * e->d);
-    HIP_OK(dalloc(&e->bq.list, (size_t)BGE_NQ * e->bq.cap * e->W));  // (one list per size tier, each sized for every problem)
+    HIP_OK(dalloc(&e->bq.list, (size_t)BGE_NQ * e->bq.cap * bge_entry_u4(e->W)));  // (one list per size tier, each sized for every problem)
     HIP_OK(dalloc(&e->bq.counts, (size_t)16));
     if (c.grad_estimator_z == DIBS_EST_REPARAM) HIP_OK(dalloc(&e->soft_ds, Ml * e->S * dd));
   }
@@ -245,7 +267,11 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
   *out = nullptr;
   const dibs_config& c = *cfg;
   if (c.abi_version != DIBS_ABI_VERSION) return fail("dibs_config.abi_version mismatch");
-  if (c.n_vars < 2 || c.n_vars > 112) return fail("n_vars must be in [2, 112]");
+  if (c.n_vars < 2 || c.n_vars > 256) return fail("n_vars must be in [2, 256]");
+  // 113 .. 256 variables: the LDS-resident kernels give way to the global-memory paths (kernels_acyc_big.h, k_backproject_big, chunked
+  // k_edge_scores, k_bge_chol_wide); built for the marginal model with the score estimator, the others keep their kernels' limit
+  if (c.n_vars > 112 && !(c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_SCORE && !c.joint))
+    return fail("n_vars > 112 is implemented for MarginalDiBS + BGe with the score-function estimator only");
   if (c.n_dim < 1) return fail("n_dim must be >= 1");
   if (c.n_particles < 1 || c.n_grad_mc_samples < 1 || c.n_acyclicity_mc_samples < 1) return fail("sizes must be >= 1");
   if (c.n_ranks < 1 || c.rank < 0 || c.rank >= c.n_ranks) return fail("bad rank / n_ranks");
@@ -270,7 +296,7 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
   if (c.likelihood == DIBS_LIK_DENSENN) {
     // one hidden layer of <= 64 units with <= 128 observations runs on the MFMA kernels of kernels_nn.h, every other stack on the
     // general path of kernels_nn_generic.h
-    if (c.nn_n_hidden < 1 || c.nn_n_hidden > DIBS_MAX_HIDDEN_LAYERS) return fail("DenseNonlinearGaussian: 1 to 4 hidden layers");
+    if (c.nn_n_hidden < 1 || c.nn_n_hidden > DIBS_MAX_HIDDEN_LAYERS) return fail("DenseNonlinearGaussian: 1 to " + std::to_string(DIBS_MAX_HIDDEN_LAYERS) + " hidden layers");
     for (int l = 0; l < c.nn_n_hidden; ++l)
       if (c.nn_hidden[l] < 1) return fail("DenseNonlinearGaussian: hidden widths must be >= 1");
     if (c.nn_activation < 0 || c.nn_activation > 3) return fail("Invalid activation function");  // nonlinearGaussian.py:61 (KeyError)
@@ -281,11 +307,12 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
   }
   {
     if ((size_t)2 * 4 * c.n_particles * 4 + 4096 > LDS_LIMIT) return fail("n_particles too large (kernel rows must fit in LDS)");
-    // k_particle_grad keeps a particle's score-space gradient, its Z and (score estimator) the per-sample weights in LDS
+    // k_particle_grad keeps a particle's score-space gradient, its Z and (score estimator) the per-sample weights in LDS; beyond that
+    // size W goes through global memory (k_backproject_big) and only the per-sample weights have to fit
     const bool score_lik = c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_SCORE;
-    const int ldz = tail_ldz(c.n_vars, c.n_dim, c.n_grad_mc_samples, score_lik, LDS_LIMIT - 2048);
-    if (tail_lds_bytes(c.n_vars, ldz, c.n_grad_mc_samples, (c.n_vars + 63) / 64, score_lik, 0) > LDS_LIMIT - 2048)
-      return fail("n_vars * n_dim (or n_grad_mc_samples) too large: a particle's gradient does not fit in LDS");
+    if (tail_lds_bytes(c.n_vars, 0, c.n_grad_mc_samples, (c.n_vars + 63) / 64, score_lik, 0) > LDS_LIMIT - 2048 ||
+        backproject_big_lds(c.n_vars) > LDS_LIMIT - 2048)
+      return fail("n_grad_mc_samples (or n_vars) too large: a particle's sample weights do not fit in LDS");
   }
   // (LinearGaussian: x beyond the LDS capacity takes the Gram-matrix path; DenseNonlinearGaussian the general path)
   int ndev = 0;
@@ -314,7 +341,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (e->stream) hipStreamSynchronize(e->stream);
   void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
-                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds};
+                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot};
   for (void* p : ptrs)
     if (p) hipFree(p);
   joint_free(&e->jw);
@@ -622,10 +649,19 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
   {
     KTimer tm(e, DIBS_K_EDGE);
     const size_t lds = (size_t)2 * e->dpad * e->ldk * 4;
-    allow_lds(k_edge_scores, lds);
+
     const int ntile = (e->dpad / 16) * (e->dpad / 16);
-    hipLaunchKernelGGL(k_edge_scores, dim3(e->Mloc, ntile >= 16 ? 4 : (ntile >= 8 ? 2 : 1)), dim3(256), lds, e->stream, e->z, e->scores, e->thr, e->probs, alpha, e->d, e->k,
-                       e->dpad, e->ldk);
+    int nby = ntile >= 16 ? 4 : (ntile >= 8 ? 2 : 1);
+    while (4 * nby * EDGE_MAXT < ntile) nby *= 2;  // (a wave keeps the accumulators of at most EDGE_MAXT tiles)
+    const int per_wave = (ntile + 4 * nby - 1) / (4 * nby);
+#define EDGE_LAUNCH(MAXT_)                                                                                                             \
+    {                                                                                                                                    \
+      allow_lds(k_edge_scores<MAXT_>, lds);                                                                                              \
+      hipLaunchKernelGGL(k_edge_scores<MAXT_>, dim3(e->Mloc, nby), dim3(256), lds, e->stream, e->z, e->scores, e->thr, e->probs, alpha,  \
+                         e->d, e->k, e->dpad, e->ldk, e->edge_kc);                                                                       \
+    }
+    if (per_wave <= 1) EDGE_LAUNCH(1) else if (per_wave <= 4) EDGE_LAUNCH(4) else EDGE_LAUNCH(EDGE_MAXT)
+#undef EDGE_LAUNCH
   }
   bool score_lik = false;
   // While per-kernel timing is on (set_profiling(1)) the main stream joins right away, so that every duration is a kernel alone on the
@@ -638,7 +674,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
     hipEventRecord(e->ev_fork, e->stream);
     hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
     KTimer tm(e, DIBS_K_ACYC, e->stream2);
-    const AcycLaunch al{e->stream2, e->scores, e->acyc_part, e->w_acyc, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
+    const AcycLaunch al{e->stream2, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
                         e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny};
     acyc_launch(al);
   }
@@ -728,7 +764,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
     hipStreamWaitEvent(e->stream, e->ev_join, 0);  // (covers the kernel matrices: they precede the acyclicity kernel on that stream)
   } else {
     KTimer tm(e, DIBS_K_ACYC);
-    const AcycLaunch al{e->stream, e->scores, e->acyc_part, e->w_acyc, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
+    const AcycLaunch al{e->stream, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
                         e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny};
     acyc_launch(al);
   }
@@ -740,14 +776,22 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
       const double p = c.graph_prior_edges_per_node * e->d / ((e->d * (e->d - 1)) / 2.0);
       er_c = (float)(log(p) - log(1 - p));
     }
-    const int ldz = tail_ldz(e->d, e->k, e->S, score_lik, LDS_LIMIT - 2048);
+    // (w_tot != null: W, U, V of a particle do not fit in one block's LDS -- phases A, B here, the back-projection in k_backproject_big)
+    const int ldz = e->w_tot ? 0 : tail_ldz(e->d, e->k, e->S, score_lik, LDS_LIMIT - 2048);
     const int cap = score_lik ? tail_stage_cap(e->d, ldz, e->S, e->W, LDS_LIMIT - 2048) : 0;
     const size_t lds = tail_lds_bytes(e->d, ldz, e->S, e->W, score_lik, cap);
     const TailArgs ta{score_lik ? e->node_scores : nullptr, e->masks, e->logprobs_z, e->baseline, e->baseline2, c.score_function_baseline,
                       score_lik ? e->bq.counts : nullptr, e->S, e->W, cap, e->probs, e->w_lik, e->w_acyc, alpha, beta, c.graph_prior, er_c,
-                      e->z, pack, rt.stride, rt.copy_vals, e->m0, e->d, e->k, ldz, 1.0f / (e->sigz * e->sigz), e->profiling ? e->counters : nullptr};
+                      e->z, pack, rt.stride, rt.copy_vals, e->m0, e->d, e->k, ldz, 1.0f / (e->sigz * e->sigz), e->profiling ? e->counters : nullptr,
+                      e->w_tot};
     allow_lds(k_particle_grad, lds);
     hipLaunchKernelGGL(k_particle_grad, dim3(e->Mloc), dim3(TAIL_NT), lds, e->stream, ta);
+    if (e->w_tot) {
+      const size_t lb = backproject_big_lds(e->d);
+      allow_lds(k_backproject_big, lb);
+      hipLaunchKernelGGL(k_backproject_big, dim3(e->Mloc, (e->d + 15) / 16, (e->k + 31) / 32), dim3(256), lb, e->stream, e->w_tot, e->z, pack, rt.stride,
+                         rt.copy_vals, e->m0, e->d, e->k, 1.0f / (e->sigz * e->sigz));
+    }
     if (score_lik) std::swap(e->baseline, e->baseline2);
   }
   hipError_t err = hipGetLastError();
@@ -1044,7 +1088,7 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
     DevBuf<unsigned int> q_counts;
     HIP_OK(d_masks.alloc((size_t)d * CH * W));
     HIP_OK(d_ns.alloc((size_t)d * CH));
-    HIP_OK(q_list.alloc((size_t)BGE_NQ * d * CH * W));
+    HIP_OK(q_list.alloc((size_t)BGE_NQ * d * CH * bge_entry_u4(W)));
     HIP_OK(q_counts.alloc((size_t)BGE_NQ));
     const BgeQueues sq{q_list.p, q_counts.p, (uint32_t)(d * CH)};  // scratch queues for this call
     const BgeParams bp = st.params();

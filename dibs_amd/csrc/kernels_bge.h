@@ -44,11 +44,13 @@ struct BgeParams {
 // A queue entry carries everything the factorisation needs -- {code = (m * d + j) * S + s, j, parent-set words} -- so that the consumer
 // issues ONE independent 16-byte load per problem (d > 64: two) instead of the chain list -> code -> masks[code] -> (code / S) % d.
 struct BgeQueues {
-  uint4* list;           // [BGE_NQ][cap][W]  {code, j, w0.lo, w0.hi} (, {w1.lo, w1.hi, 0, 0})
+  uint4* list;           // [BGE_NQ][cap][bge_entry_u4(W)]  {code, j, w0.lo, w0.hi} (, {w1.lo, w1.hi, w2.lo, w2.hi} (, {w3.lo, w3.hi, 0, 0}))
   unsigned int* counts;  // [BGE_NQ]: zero at creation, reset by the consumer of the node scores after every use
   uint32_t cap;
 };
 
+// 16-byte pieces of a queue entry {code, j, w[0 .. W-1]}: 1, 2, 2, 3 for W = 1 .. 4
+__host__ __device__ inline int bge_entry_u4(int W) { return (2 + 2 * W + 3) / 4; }
 __host__ __device__ inline int bge_rows(int l, int d) { return l + 1 <= d - l ? l + 1 : d - l; }
 __host__ __device__ inline int bge_tier(int n) { return n <= 32 ? (n + 3) / 4 - 1 : BGE_NQ - 1; }
 
@@ -151,6 +153,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_sample(const uint32_t* __res
     const Key2 kg = rng_split_row_uniform(kp, 2u, 1u, layout);
     const uint64_t dd = (uint64_t)d * d, nbits = (uint64_t)S * dd;
     if (!SAMPLE) {
+    } else if (W > 2) {
+      // n_vars > 128: plain word loop, one Threefry call per sampled bit whatever the layout (the fallback behind the constructor's
+      // full range, not tuned)
+      for (int s = lane; s < S; s += 64)
+        for (int w = 0; w < W; ++w) {
+          uint64_t a = 0;
+          const int i1 = d < 64 * w + 64 ? d : 64 * w + 64;
+          for (int i = 64 * w; i < i1; ++i) {
+            const uint32_t y = rng_bits_at(kg, nbits, (uint64_t)s * dd + (uint64_t)i * d + j, layout);
+            a |= (uint64_t)((y >> 9) < thrs[i]) << (i & 63);
+          }
+          mk[s * W + w] = a;
+        }
     } else if ((S & 1) == 0) {
       const int hS = S >> 1;
       for (int p = lane; p < hS; p += 64) {
@@ -171,20 +186,42 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_sample(const uint32_t* __res
               uint32_t A = 0u, B = 0u;
               int i = i0;
               for (; i + 1 < i1; i += 2, c0 += 2u * (uint32_t)d, c1 += 2u * (uint32_t)d) {
-                uint32_t y0, y1, y2, y3;
-                threefry2x32_uk2(tk, c0, c1, c0 + (uint32_t)d, c1 + (uint32_t)d, y0, y1, y2, y3);
-                const uint32_t L = lims[i], L2 = lims[i + 1];
-                asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(A) : "v"(y0), "v"(L) : "vcc");
-                asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(B) : "v"(y1), "v"(L) : "vcc");
-                asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(A) : "v"(y2), "v"(L2) : "vcc");
-                asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(B) : "v"(y3), "v"(L2) : "vcc");
+                // A row whose threshold is 0 (the diagonal; p == 0) or 2^23 (p == 1.0f, forced on through `force`) needs no draw, and both
+                // outputs of a call belong to the same row: the call is skipped (wave-uniform: the limits are per row).  Nothing saturates
+                // in the first tens of steps, almost every row does after a few hundred (alpha = t: sigmoid(alpha s) is 0 or 1 in float).
+                const uint32_t L = __builtin_amdgcn_readfirstlane(lims[i]), L2 = __builtin_amdgcn_readfirstlane(lims[i + 1]);
+                const bool k1 = L != 0u && L != 0xFFFFFFFFu, k2 = L2 != 0u && L2 != 0xFFFFFFFFu;
+                if (k1 && k2) {
+                  uint32_t y0, y1, y2, y3;
+                  threefry2x32_uk2(tk, c0, c1, c0 + (uint32_t)d, c1 + (uint32_t)d, y0, y1, y2, y3);
+                  asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(A) : "v"(y0), "v"(L) : "vcc");
+                  asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(B) : "v"(y1), "v"(L) : "vcc");
+                  asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(A) : "v"(y2), "v"(L2) : "vcc");
+                  asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(B) : "v"(y3), "v"(L2) : "vcc");
+                } else if (k1 || k2) {
+                  uint32_t y0, y1;
+                  const uint32_t dk = k1 ? 0u : (uint32_t)d, Lk = k1 ? L : L2;
+                  threefry2x32_uk(tk, c0 + dk, c1 + dk, y0, y1);
+                  if (!k1) { A += A; B += B; }  // (the skipped row's bit: 0 here, a forced row is OR-ed in below)
+                  asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(A) : "v"(y0), "v"(Lk) : "vcc");
+                  asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(B) : "v"(y1), "v"(Lk) : "vcc");
+                  if (k1) { A += A; B += B; }
+                } else {
+                  A <<= 2;
+                  B <<= 2;
+                }
               }
               if (i < i1) {
-                uint32_t y0, y1;
-                threefry2x32_uk(tk, c0, c1, y0, y1);
-                const uint32_t L = lims[i];
-                asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(A) : "v"(y0), "v"(L) : "vcc");
-                asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(B) : "v"(y1), "v"(L) : "vcc");
+                const uint32_t L = __builtin_amdgcn_readfirstlane(lims[i]);
+                if (L != 0u && L != 0xFFFFFFFFu) {
+                  uint32_t y0, y1;
+                  threefry2x32_uk(tk, c0, c1, y0, y1);
+                  asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(A) : "v"(y0), "v"(L) : "vcc");
+                  asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(B) : "v"(y1), "v"(L) : "vcc");
+                } else {
+                  A += A;
+                  B += B;
+                }
                 c0 += (uint32_t)d;
                 c1 += (uint32_t)d;
               }
@@ -236,10 +273,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_sample(const uint32_t* __res
     for (int s0 = 0; s0 < S; s0 += 64) {
       const int s = s0 + lane;
       const bool valid = s < S;
-      const uint64_t w0 = valid ? mk[s * W] : 0ull, w1 = (valid && W > 1) ? mk[s * W + 1] : 0ull;
-      const int l = __popcll(w0) + __popcll(w1);
+      int l = 0;
+      for (int w = 0; w < W; ++w) l += valid ? __popcll(mk[s * W + w]) : 0;
       if (valid && l == 0) ns_out[s] = score_l0;
-      const int tier = (valid && l > 0) ? bge_tier(bge_rows(l, d)) : -1;
+      // (n_vars > 128: every problem goes to the last tier -- k_bge_chol_wide works only that one)
+      const int tier = (valid && l > 0) ? (W > 2 ? BGE_NQ - 1 : bge_tier(bge_rows(l, d))) : -1;
       const unsigned long long lt = (1ull << lane) - 1ull;
       uint32_t myloc = 0xFFFFFFFFu;
       for (int tq = 0; tq < BGE_NQ; ++tq) {
@@ -266,12 +304,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_sample(const uint32_t* __res
       const uint32_t v = loc[s];
       if (v != 0xFFFFFFFFu) {
         const uint32_t tq = v >> 28;
-        uint4* dst = qs.list + ((size_t)tq * qs.cap + blk_base[tq] + (v & 0x0FFFFFFFu)) * W;
+        uint4* dst = qs.list + ((size_t)tq * qs.cap + blk_base[tq] + (v & 0x0FFFFFFFu)) * bge_entry_u4(W);
         const uint64_t w0 = mk[s * W];
         dst[0] = make_uint4((uint32_t)(((size_t)m * d + j) * S + s), (uint32_t)j, (uint32_t)w0, (uint32_t)(w0 >> 32));
         if (W > 1) {
-          const uint64_t w1 = mk[s * W + 1];
-          dst[1] = make_uint4((uint32_t)w1, (uint32_t)(w1 >> 32), 0u, 0u);
+          const uint64_t w1 = mk[s * W + 1], w2 = W > 2 ? mk[s * W + 2] : 0ull;
+          dst[1] = make_uint4((uint32_t)w1, (uint32_t)(w1 >> 32), (uint32_t)w2, (uint32_t)(w2 >> 32));
+        }
+        if (W > 3) {
+          const uint64_t w3 = mk[s * W + 3];
+          dst[2] = make_uint4((uint32_t)w3, (uint32_t)(w3 >> 32), 0u, 0u);
         }
       }
     }
@@ -578,7 +620,7 @@ __global__ __launch_bounds__(256) void k_bge_chol(double* __restrict__ node_scor
     const unsigned int usz = qi < 4 ? 256u * (unsigned int)npl : (qi < 8 ? 64u : (unsigned int)nwg);
     const unsigned int idx = qi < 4 ? (unsigned int)tid : (qi < 8 ? (unsigned int)(tid >> 2) : (unsigned int)wave);
     const bool lane_ok = qi < 8 || wave < nwg;
-    const uint4* lst = qs.list + (size_t)qi * qs.cap * W;
+    const uint4* lst = qs.list + (size_t)qi * qs.cap * W;  // (bge_entry_u4(W) == W for W <= 2)
 #pragma unroll
     for (int v = 0; v < BGE_NPL0; ++v) {
       const unsigned int pi = local * usz + 256u * (unsigned int)v + idx;
@@ -725,8 +767,103 @@ __global__ __launch_bounds__(256) void k_bge_chol(double* __restrict__ node_scor
   }
 }
 
-// out[s] = sum_j node_scores[j][s]   (scoring of given graphs)
+// ------------------------------------------------------------------------------------------------
+// K3b  n_vars > 128 (up to 256: parent sets of three or four mask words): every queued problem (last tier only, see k_bge_sample) is
+//      factorised by ONE wave, the factor in LDS -- the algorithm of bge_chol_wave with the index set taken from up to four words.
+//      n = min(l + 1, d - l) <= (d + 1) / 2 <= 128 rows: lane owns rows r and r + 64.  R / Q are read through the caches.
+//      The fallback behind the constructor's full range, not tuned.
+// grid = any (waves stride over the queue), block = 64 * BGE_WIDE_WAVES; dynamic LDS = BGE_WIDE_WAVES * bge_wide_wave_bytes(d)
+// ------------------------------------------------------------------------------------------------
+#define BGE_WIDE_WAVES 2
+__host__ __device__ inline int bge_wide_nmax(int d) { return (d + 1) / 2; }
+__host__ __device__ inline size_t bge_wide_wave_bytes(int d) {
+  const size_t n = (size_t)bge_wide_nmax(d);
+  return (((n * (n | 1) + 3) & ~(size_t)3) * 4 + (n + 4) * 4 + 15) & ~(size_t)15;
+}
 #ifdef DIBS_TU_BGE
+__global__ __launch_bounds__(64 * BGE_WIDE_WAVES) void k_bge_chol_wide(double* __restrict__ node_scores, BgeParams bp, BgeQueues qs, int d, int W) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned int n_q = qs.counts[BGE_NQ - 1];
+  const int nmax = bge_wide_nmax(d), ldl = nmax | 1, EW = bge_entry_u4(W);
+  float* Lb = reinterpret_cast<float*>(smem_raw + (size_t)wave * bge_wide_wave_bytes(d));
+  int* myidx = reinterpret_cast<int*>(Lb + (((size_t)nmax * ldl + 3) & ~(size_t)3));
+  const uint4* lst = qs.list + (size_t)(BGE_NQ - 1) * qs.cap * EW;
+  const int ldr = d + 1, msz = ldr * ldr;
+  for (unsigned int pi = blockIdx.x * BGE_WIDE_WAVES + wave; pi < n_q; pi += gridDim.x * BGE_WIDE_WAVES) {
+    const uint4 e0 = lst[(size_t)pi * EW];
+    const uint4 e1 = W > 1 ? lst[(size_t)pi * EW + 1] : make_uint4(0u, 0u, 0u, 0u);
+    const uint4 e2 = W > 3 ? lst[(size_t)pi * EW + 2] : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t code = e0.x;
+    const int j = (int)e0.y;
+    uint64_t w[4] = {((uint64_t)e0.w << 32) | e0.z, ((uint64_t)e1.y << 32) | e1.x, ((uint64_t)e1.w << 32) | e1.z, ((uint64_t)e2.y << 32) | e2.x};
+    int l = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) l += __popcll(w[q]);
+    const bool comp = l + 1 > d - l;
+    if (comp) {  // complement form: the non-parents other than j
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int lo = 64 * q, nb = d - lo;
+        const uint64_t valid = nb >= 64 ? ~0ull : (nb > 0 ? (1ull << nb) - 1ull : 0ull);
+        w[q] = ~w[q] & valid;
+        if (j >= lo && j < lo + 64) w[q] &= ~(1ull << (j - lo));
+      }
+    }
+    const int li = comp ? d - 1 - l : l, n = li + 1;  // rows before j; j goes last
+    const float* R = comp ? bp.Qp : bp.Rp;
+    const size_t mat = bp.n_mats > 1 ? (size_t)j * msz : 0;
+    {
+      int base = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if ((w[q] >> lane) & 1ull) myidx[base + __popcll(w[q] & ((1ull << lane) - 1ull))] = 64 * q + lane;
+        base += __popcll(w[q]);
+      }
+      if (lane == 0) myidx[li] = j;
+    }
+    wave_lds_fence();
+    float mypiv[2] = {1.f, 1.f};
+    for (int kk = 0; kk < n; ++kk) {
+      const int ik = myidx[kk];
+      float accs[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = lane + h * 64;
+        float acc = 0.f;
+        if (r >= kk && r < n) {
+          acc = R[mat + (size_t)myidx[r] * ldr + ik];
+          const float* lr = Lb + (size_t)r * ldl;
+          const float* lk = Lb + (size_t)kk * ldl;
+#pragma unroll 8
+          for (int p_ = 0; p_ < kk; ++p_) acc = fmaf(-lr[p_], lk[p_], acc);
+        }
+        accs[h] = acc;
+        if (r == kk) mypiv[h] = acc;
+      }
+      const float piv = __shfl(kk < 64 ? accs[0] : accs[1], kk & 63, 64);
+      const float inv = __builtin_amdgcn_rsqf(piv);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = lane + h * 64;
+        if (r > kk && r < n) Lb[(size_t)r * ldl + kk] = accs[h] * inv;
+      }
+      wave_lds_fence();
+    }
+    float lg = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = lane + h * 64;
+      if (r < li) lg += __log2f(mypiv[h]);
+    }
+    const float ld2 = wave_sum(lg);
+    const float last = __shfl(li < 64 ? mypiv[0] : mypiv[1], li & 63, 64);
+    wave_lds_fence();
+    if (lane == 0) node_scores[code] = bge_score(bp, j, l, d, comp, ld2, last);
+  }
+}
+
+// out[s] = sum_j node_scores[j][s]   (scoring of given graphs)
 __global__ void k_sum_nodes(const double* __restrict__ node_scores, float* __restrict__ out, int d, int S) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;

@@ -29,39 +29,62 @@ __global__ void k_init_theta_lin(float* __restrict__ th, Key2 key, uint64_t n_to
 // K1  edge scores: scores[m] = U V^T via v_mfma_f32_16x16x4_f32 (k-ordered exact-f32 fma chain),
 //     thresholds thr = ceil(sigmoid(alpha * s) * 2^23) for Bernoulli(p) == ((bits >> 9) < thr)
 //     reference: dibs.py:168-184 (edge_probs), dibs.py:115 (bernoulli)
-// grid = Mloc, block = 256; dynamic LDS = 2 * dpad * ldk * 4
+// grid = (Mloc, NB), block = 256; dynamic LDS = 2 * dpad * ldk * 4, ldk = row stride of a latent-dimension chunk of `kc` columns.
+// The latent dimension is walked in chunks of kc columns (one chunk when U, V fit in LDS -- n_vars <= 112 with k = d); a wave keeps the
+// accumulators of its tiles (t = first, first + stride, ...; at most MAXT <= EDGE_MAXT) across the chunks, so the fma chain of every score runs
+// over k in ascending order whatever the chunking: scores do not depend on it.
 // ------------------------------------------------------------------------------------------------
+#define EDGE_MAXT 12
+template <int MAXT>   // accumulator sets per wave: 1 (up to 16 tiles per particle: n_vars <= 64 with four blocks), 4, EDGE_MAXT
 __global__ __launch_bounds__(256) void k_edge_scores(const float* __restrict__ z, float* __restrict__ scores,
                                                      uint32_t* __restrict__ thr, float* __restrict__ probs, float alpha,
-                                                     int d, int k, int dpad, int ldk) {
+                                                     int d, int k, int dpad, int ldk, int kc) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Us = smem;
   float* Vs = smem + (size_t)dpad * ldk;
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float2* zm = reinterpret_cast<const float2*>(z + (size_t)m * d * k * 2);
-  for (int e = tid; e < dpad * ldk; e += 256) {
-    const int i = e / ldk, q = e - i * ldk;
-    float2 uv = make_float2(0.f, 0.f);
-    if (i < d && q < k) uv = zm[(size_t)i * k + q];
-    Us[e] = uv.x;
-    Vs[e] = uv.y;
-  }
-  __syncthreads();
   const int nt = dpad >> 4;
-  const int kp = (k + 3) & ~3;
   // tiles are dealt out over the waves of the gridDim.y blocks of this particle (the epilogue's double-precision sigmoid
   // is most of the work: more blocks, shorter critical path)
-  for (int t = blockIdx.y * 4 + wave; t < nt * nt; t += 4 * gridDim.y) {
+  const int t0 = blockIdx.y * 4 + wave, tstride = 4 * gridDim.y;
+  f32x4 acc[MAXT];
+#pragma unroll
+  for (int u = 0; u < MAXT; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int q0 = 0; q0 < k; q0 += kc) {
+    const int kn = k - q0 < kc ? k - q0 : kc, kp = (kn + 3) & ~3;
+    if (q0) __syncthreads();
+    for (int e = tid; e < dpad * ldk; e += 256) {
+      const int i = e / ldk, q = e - i * ldk;
+      float2 uv = make_float2(0.f, 0.f);
+      if (i < d && q < kn) uv = zm[(size_t)i * k + q0 + q];
+      Us[e] = uv.x;
+      Vs[e] = uv.y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) {
+      const int t = t0 + u * tstride;
+      if (t < nt * nt) {
+        const int ti = t / nt, tj = t - ti * nt;
+        const float* ua = Us + (size_t)(ti * 16 + (lane & 15)) * ldk + (lane >> 4);
+        const float* vb = Vs + (size_t)(tj * 16 + (lane & 15)) * ldk + (lane >> 4);
+        f32x4 a = acc[u];
+        for (int k0 = 0; k0 < kp; k0 += 4) a = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[k0], vb[k0], a, 0, 0, 0);
+        acc[u] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < MAXT; ++u) {
+    const int t = t0 + u * tstride;
+    if (t >= nt * nt) continue;
     const int ti = t / nt, tj = t - ti * nt;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* ua = Us + (size_t)(ti * 16 + (lane & 15)) * ldk + (lane >> 4);
-    const float* vb = Vs + (size_t)(tj * 16 + (lane & 15)) * ldk + (lane >> 4);
-    for (int k0 = 0; k0 < kp; k0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[k0], vb[k0], acc, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = ti * 16 + (lane >> 4) * 4 + r, col = tj * 16 + (lane & 15);
       if (row < d && col < d) {
-        const float s = acc[r];
+        const float s = acc[u][r];
         const size_t o = ((size_t)m * d + row) * d + col;
         scores[o] = s;
         const float pf = (float)sigmoid_d((double)__fmul_rn(alpha, s));

@@ -12,7 +12,7 @@
 #include "kernels_joint.h"
 
 #ifndef DIBS_MAX_HIDDEN_LAYERS
-#define DIBS_MAX_HIDDEN_LAYERS 4
+#define DIBS_MAX_HIDDEN_LAYERS 8
 #endif
 struct NNParams {
   int H, act, bias;  // H = width of the first hidden layer (the tuned one-hidden-layer kernels below)

@@ -44,6 +44,8 @@ struct TailArgs {
   int m0, d, k, ldz;
   float inv_sig2;
   unsigned long long* dbg;  // profiling: phase time stamps of block 0 (100 MHz ticks, accumulated in dbg[1..5]); null in production
+  float* w_tot;             // large n_vars (W, U, V do not fit in LDS): phases A and B only, W goes to w_tot [Mloc][d][d] and
+                            // k_backproject_big does phase C; ldz must be 0 then.  null: everything in this kernel
 };
 
 __host__ __device__ inline int tail_nsplit(int S, int d) {
@@ -55,12 +57,13 @@ __host__ __device__ inline int tail_nsplit(int S, int d) {
 // LDS: [ W dp16 x (dp16 + 2) f32  UNION  phase-A scratch: lp S f64, lp2 nsplit*S f64, wt S f32 ] [U, V: kp4 x ldz f32 each] [colsum d f32]
 //      [nzw S f32] [nzi S i32] [staged parent sets cap*d*W u64]
 __host__ __device__ inline int tail_ldw(int d) { return ((d + 15) & ~15) + 2; }  // == 2 (mod 4): conflict-free MFMA A-operand reads
-__host__ __device__ inline size_t tail_union_bytes(int d, int S, bool lik) {
-  const size_t w = (size_t)((d + 15) & ~15) * tail_ldw(d) * 4, a = lik ? (size_t)S * 8 * (1 + tail_nsplit(S, d)) + (size_t)S * 4 : 0;
+// (ldz == 0: the large-n_vars mode -- no W, U, V in LDS)
+__host__ __device__ inline size_t tail_union_bytes(int d, int S, bool lik, bool big = false) {
+  const size_t w = big ? 0 : (size_t)((d + 15) & ~15) * tail_ldw(d) * 4, a = lik ? (size_t)S * 8 * (1 + tail_nsplit(S, d)) + (size_t)S * 4 : 0;
   return ((w > a ? w : a) + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t tail_fixed_bytes(int d, int ldz, int S, bool lik) {
-  return (tail_union_bytes(d, S, lik) + ((size_t)2 * ((d + 3) & ~3) * ldz + d) * 4 + (lik ? (size_t)S * 8 : 0) + 15) & ~(size_t)15;
+  return (tail_union_bytes(d, S, lik, ldz == 0) + ((size_t)2 * ((d + 3) & ~3) * ldz + d) * 4 + (lik ? (size_t)S * 8 : 0) + 15) & ~(size_t)15;
 }
 // row stride of the U / V images: >= k rounded up to the 16-column tiles; == 16 (mod 32) keeps the B-operand reads conflict-free
 __host__ inline int tail_ldz(int d, int k, int S, bool lik, size_t lds_limit) {
@@ -88,7 +91,8 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
   double* lp = reinterpret_cast<double*>(smem_raw);  // ... phase A scratch in the same bytes
   double* lp2 = lp + S;
   float* wt = reinterpret_cast<float*>(lp2 + (size_t)nsplit * S);
-  float* Us = reinterpret_cast<float*>(smem_raw + tail_union_bytes(d, S, lik));
+  const bool big = A.w_tot != nullptr;  // (ldz == 0)
+  float* Us = reinterpret_cast<float*>(smem_raw + tail_union_bytes(d, S, lik, big));
   float* Vs = Us + (size_t)kp4 * ldz;
   float* cs = Vs + (size_t)kp4 * ldz;
   float* nzw = cs + d;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
     pw[u] = (e < dd && !lik) ? wlg[e] : 0.f;
   }
   const float2* zm = reinterpret_cast<const float2*>(A.z + (size_t)m * d * k * 2);
-  for (int e = tid; e < d * k; e += TAIL_NT) {
+  for (int e = tid; e < (big ? 0 : d * k); e += TAIL_NT) {
     const int j = e / k, q = e - j * k;
     const float2 uv = zm[e];
     Us[j * ldz + q] = uv.x;
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
   }
   __syncthreads();  // (phase A's scratch is dead: W takes its place)
   ts[2] = wall_clock64();
-  for (int e = tid; e < dp16 * ldw; e += TAIL_NT) Wm[e] = 0.f;  // padding rows / columns of the MFMA operand
+  for (int e = tid; e < (big ? 0 : dp16 * ldw); e += TAIL_NT) Wm[e] = 0.f;  // padding rows / columns of the MFMA operand
   __syncthreads();
 
   // ---- B. total score-space gradient of this particle -> LDS
@@ -274,13 +278,16 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
           const float dp = A.alpha * p * (1.0f - p);
           pr = A.prior_kind == 0 ? A.er_c * dp : (-3.0f / (1.0f + cs[j])) * dp;
         }
-        Wm[i * ldw + j] = wl - A.beta * pa[u] + pr;
+        const float wt_ = wl - A.beta * pa[u] + pr;
+        if (big) A.w_tot[(size_t)m * dd + e] = wt_;
+        else Wm[i * ldw + j] = wt_;
       }
     }
   }
   __syncthreads();
 
   ts[3] = wall_clock64();
+  if (big) return;  // (phase C: k_backproject_big)
   // ---- C. back-projection: dU = W V, dV = W^T U, one 16 x 16 tile of both per wave and pass
   // MFMA operands: A[row = lane % 16][k = lane / 16], B[k = lane / 16][col = lane % 16], D[row = 4 (lane / 16) + r][col = lane % 16]
   float* prow = A.pack + (size_t)(A.m0 + m) * A.pack_stride;
@@ -314,4 +321,73 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
   ts[4] = wall_clock64();
   if (A.dbg && m == 0 && tid == 0)
     for (int u = 1; u < 5; ++u) atomicAdd(A.dbg + u, ts[u] - ts[u - 1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7c  phase C of k_particle_grad for sizes whose W, U, V do not fit in one block's LDS: grad = [W V, W^T U] - z / sigma^2 from W in
+//      global memory (k_particle_grad with w_tot), one block per (particle, 16 rows of the result, 32 latent columns):
+//      LDS = the 16 rows and the 16 columns of W the tile needs + the 32-column slices of U and V; waves 0, 1 take the two column tiles
+//      of dU, waves 2, 3 those of dV; the same k-ordered v_mfma_f32_16x16x4_f32 chains as in k_particle_grad.
+// grid = (Mloc, ceil(d / 16), ceil(k / 32)), block = 256; dynamic LDS = backproject_big_lds(d)
+// ------------------------------------------------------------------------------------------------
+#define BPB_LDQ 48  // row stride of the U / V slices: 32 columns + 16 (== 16 mod 32: conflict-free B-operand reads)
+__host__ __device__ inline size_t backproject_big_lds(int d) {
+  const size_t kp4 = (size_t)((d + 3) & ~3);
+  return (16 * (kp4 + 2) + kp4 * 18 + 2 * kp4 * BPB_LDQ) * 4;
+}
+__global__ __launch_bounds__(256) void k_backproject_big(const float* __restrict__ w_tot, const float* __restrict__ z, float* __restrict__ pack,
+                                                         size_t pack_stride, int copy_z, int m0, int d, int k, float inv_sig2) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int m = blockIdx.x, ti = blockIdx.y, q0 = blockIdx.z * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
+  const int kp4 = (d + 3) & ~3, ldr = kp4 + 2;
+  float* Wr = smem;                      // [16][ldr]   W[ti*16 + r][j]
+  float* Wc = Wr + 16 * ldr;             // [kp4][18]   W[j][ti*16 + r]
+  float* Us = Wc + (size_t)kp4 * 18;     // [kp4][BPB_LDQ]
+  float* Vs = Us + (size_t)kp4 * BPB_LDQ;
+  const float* wm = w_tot + (size_t)m * d * d;
+  for (int e = tid; e < 16 * kp4; e += 256) {
+    const int rr = e / kp4, j = e - rr * kp4, i = ti * 16 + rr;
+    Wr[rr * ldr + j] = (i < d && j < d) ? wm[(size_t)i * d + j] : 0.f;
+  }
+  for (int e = tid; e < kp4 * 16; e += 256) {
+    const int j = e >> 4, rr = e & 15, i = ti * 16 + rr;
+    Wc[j * 18 + rr] = (i < d && j < d) ? wm[(size_t)j * d + i] : 0.f;
+  }
+  const float2* zm = reinterpret_cast<const float2*>(z + (size_t)m * d * k * 2);
+  for (int e = tid; e < kp4 * 32; e += 256) {
+    const int j = e >> 5, q = e & 31;
+    float2 uv = make_float2(0.f, 0.f);
+    if (j < d && q0 + q < k) uv = zm[(size_t)j * k + q0 + q];
+    Us[j * BPB_LDQ + q] = uv.x;
+    Vs[j * BPB_LDQ + q] = uv.y;
+  }
+  __syncthreads();
+  const int tj = wave & 1, kind = wave >> 1;  // kind 0: dU = W V, 1: dV = W^T U
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (kind == 0) {
+    const float* wa = Wr + r * ldr + g;
+    const float* vb = Vs + g * BPB_LDQ + tj * 16 + r;
+    for (int k0 = 0; k0 < kp4; k0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k0], vb[k0 * BPB_LDQ], acc, 0, 0, 0);
+  } else {
+    const float* wtr = Wc + g * 18 + r;
+    const float* ub = Us + g * BPB_LDQ + tj * 16 + r;
+    for (int k0 = 0; k0 < kp4; k0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wtr[k0 * 18], ub[k0 * BPB_LDQ], acc, 0, 0, 0);
+  }
+  float* prow = pack + (size_t)(m0 + m) * pack_stride;
+  float* pz = prow;
+  float* pg = prow + (copy_z ? (size_t)d * k * 2 : (size_t)0);
+  const int q = q0 + tj * 16 + r;
+  if (q < k) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int i = ti * 16 + 4 * g + rr;
+      if (i < d) {
+        const float zi = (kind == 0 ? Us : Vs)[i * BPB_LDQ + tj * 16 + r];  // (row i lies inside the slice: all d rows are staged)
+        const size_t o = ((size_t)i * k + q) * 2 + kind;                    // [d][k][2]: (U, V) interleaved
+        if (copy_z) pz[o] = zi;
+        pg[o] = acc[rr] - zi * inv_sig2;
+      }
+    }
+  }
 }

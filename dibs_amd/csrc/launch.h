@@ -24,9 +24,11 @@ struct AcycLaunch {
   const float* scores;
   float* part;            // [Mloc][nblk][d*d] partial sums of the blocks
   float* w_acyc;          // [Mloc][d*d] mean over the chains (k_acyc_reduce, same stream)
+  float* big;             // n_vars > 112: acyc_big_elems() floats (matrix powers through global memory); null otherwise
   Key2 carry;
   int m0, M, Mloc, d, Sa, cpb, units, nblk;  // units != Sa: chains are taken in Threefry pairs
   float alpha, tau;
   int layout, tiny;
 };
 void acyc_launch(const AcycLaunch& a);
+size_t acyc_big_elems(int Mloc, int d, int Sa);

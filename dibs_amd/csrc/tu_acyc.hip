@@ -3,6 +3,7 @@
 #include "launch.h"
 #include "kernels_acyc.h"
 #include "kernels_acyc_bf16.h"
+#include "kernels_acyc_big.h"
 #include <stdlib.h>
 
 template <int NT>
@@ -28,8 +29,43 @@ static bool acyc_use_bf16(const AcycLaunch& a) {
   return !off && a.units != a.Sa && a.d > 32 && a.d <= 64;
 }
 
+// n_vars > 112: matrices in global memory (kernels_acyc_big.h); a.big = three [Mloc * Sa][dp][dp] buffers
+size_t acyc_big_elems(int Mloc, int d, int Sa) {
+  const size_t dp = (size_t)((d + 15) & ~15);
+  return (size_t)3 * Mloc * Sa * dp * dp;
+}
+static void acyc_big_launch(const AcycLaunch& a) {
+  const int dp = (a.d + 15) & ~15, nch = a.Mloc * a.Sa;
+  const size_t msz = (size_t)nch * dp * dp;
+  float* const Mb = a.big;
+  float* const B1 = Mb + msz;
+  float* const B2 = B1 + msz;
+  hipLaunchKernelGGL(k_acycb_init, dim3((dp * dp + 255) / 256, nch), dim3(256), 0, a.stream, a.scores, Mb, a.carry, a.m0, a.M, a.d, dp, a.Sa, a.alpha,
+                     a.tau, a.layout, a.tiny);
+  const dim3 gg((dp + 63) / 64, (dp + 63) / 64, nch);
+  const float* cur = Mb;
+  const int ex = a.d - 1;
+  const int hb = 31 - __builtin_clz((unsigned)ex);
+  for (int bit = hb - 1; bit >= 0; --bit) {  // left-to-right binary powering (as k_acyc)
+    float* dst = cur == B1 ? B2 : B1;
+    hipLaunchKernelGGL(k_bgemm, gg, dim3(256), 0, a.stream, cur, cur, dst, dp);
+    cur = dst;
+    if ((ex >> bit) & 1) {
+      dst = cur == B1 ? B2 : B1;
+      hipLaunchKernelGGL(k_bgemm, gg, dim3(256), 0, a.stream, (const float*)Mb, cur, dst, dp);
+      cur = dst;
+    }
+  }
+  hipLaunchKernelGGL(k_acycb_out, dim3((a.d * a.d + 255) / 256, a.Mloc), dim3(256), 0, a.stream, a.scores, cur, a.w_acyc, a.carry, a.m0, a.M, a.d, dp,
+                     a.Sa, a.alpha, a.tau, a.layout, a.tiny);
+}
+
 static void acyc_launch_power(const AcycLaunch& a);
 void acyc_launch(const AcycLaunch& a) {
+  if (a.big) {
+    acyc_big_launch(a);
+    return;
+  }
   acyc_launch_power(a);
   const int dd = a.d * a.d;
   hipLaunchKernelGGL(k_acyc_reduce, dim3(a.Mloc, (dd + 255) / 256), dim3(256), 0, a.stream, a.part, a.w_acyc, a.nblk, dd, 1.0f / (float)a.Sa);

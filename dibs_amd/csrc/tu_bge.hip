@@ -29,6 +29,12 @@ void bge_launch_sample(bool sample, hipStream_t stream, const uint32_t* thr, uin
 
 void bge_launch_chol(hipStream_t stream, double* node_scores, const BgeParams& bp, const BgeQueues& qs, int d, int S,
                      unsigned long long* counters) {
+  if (d > 128) {  // three or four mask words: one problem per wave, everything in the last tier (k_bge_chol_wide)
+    const size_t lw = BGE_WIDE_WAVES * bge_wide_wave_bytes(d);
+    allow_lds(k_bge_chol_wide, lw);
+    hipLaunchKernelGGL(k_bge_chol_wide, dim3(2048), dim3(64 * BGE_WIDE_WAVES), lw, stream, node_scores, bp, qs, d, (d + 63) / 64);
+    return;
+  }
   const bool w2 = d > 64;
   bool rl = bp.n_mats == 1;
   if (rl && bge_chol_lds_bytes(d, true) > (size_t)150 * 1024) rl = false;

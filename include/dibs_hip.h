@@ -21,8 +21,8 @@
 extern "C" {
 #endif
 
-#define DIBS_ABI_VERSION 1
-#define DIBS_MAX_HIDDEN_LAYERS 4
+#define DIBS_ABI_VERSION 2
+#define DIBS_MAX_HIDDEN_LAYERS 8
 
 enum { DIBS_LIK_BGE = 0, DIBS_LIK_LINGAUSS = 1, DIBS_LIK_DENSENN = 2 };
 enum { DIBS_PRIOR_ER = 0, DIBS_PRIOR_SF = 1, DIBS_PRIOR_UNIFORM = 2 };

@@ -14,7 +14,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ev = [(r["Kernel_Name"].split("(")[0][:40], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "")) for r in rows]
 # the un-profiled timed repetitions come first: find edge-score launches and take steps in the 3rd repetition
-idx = [i for i, e in enumerate(ev) if e[0].startswith("k_edge_scores")]
+idx = [i for i, e in enumerate(ev) if "k_edge_scores" in e[0]]
 start = idx[5 + 2 * 20 + 10]
 end = idx[5 + 2 * 20 + 13]
 t0 = ev[start][1]

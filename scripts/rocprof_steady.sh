@@ -15,11 +15,12 @@ by = collections.defaultdict(list)
 for r in rows:
     by[r["Kernel_Name"].split("(")[0]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 tot = 0.0
+n_steps = sum(len(v) for k, v in by.items() if "k_edge_scores" in k)   # one edge-score launch per step
 print(f"{'kernel':44s} {'launches':>8s} {'avg_us(last %d steps)' % K:>22s}")
 # bench.py replays the timed window once more with per-kernel events: the last 2K launches cover both passes
 for k, v in sorted(by.items(), key=lambda kv: -sum(e - s for s, e in kv[1][-2 * K:])):
     v.sort()
-    per_step = len(v) // (len(by["k_edge_scores"]) or 1) or 1
+    per_step = len(v) // (n_steps or 1) or 1
     w = v[-2 * K * per_step:] if len(v) >= 2 * K * per_step else v
     avg = sum(e - s for s, e in w) / len(w) / 1e3
     print(f"{k[:44]:44s} {len(v):8d} {avg:22.2f}" + (f"  x{per_step}/step" if per_step > 1 else ""))

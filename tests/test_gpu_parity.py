@@ -70,13 +70,20 @@ def test_init_particles_matches_oracle(c_oracle64):
     (112, 2, 16, 4, "er", (1,), "legacy"),          # engine maximum: 112x112 tiles, every BGe tier up to the one-problem-per-wave one
     (96, 8, 64, 8, "er", (1,), "legacy"),           # thousands of queued problems at d > 80: only two waves of a factorisation block fit the
     (112, 6, 64, 4, "sf", (2,), "partitionable"),   # one-problem-per-wave tier, all four need quad index lists (LDS layout bug found by gpu_fuzz.py)
+    (120, 2, 16, 4, "er", (1,), "legacy"),          # > 112: matrix powers through global memory, chunked edge scores, W through global memory
+    (128, 3, 8, 4, "sf", (0, 2), "legacy"),         # two full mask words
+    (130, 2, 8, 2, "er", (1,), "legacy"),           # three mask words: plain sampling loop, one factorisation per wave (k_bge_chol_wide)
+    (200, 2, 8, 2, "er", (1,), "partitionable"),    # four mask words, complement form with up to 100 rows
     (3, 1, 4, 2, "uniform", (0, 1), "legacy"),      # smallest sensible problem, a single particle
     (20, 5, 32, 8, "er", (2,), "partitionable"),   # jax_threefry_partitionable=True streams (no call pairing)
     (5, 3, 16, 4, "sf", (0, 1), "partitionable"),
 ])
 def test_marginal_bge_step_stages(c_oracle64, d, M, S, Sa, prior, steps, layout):
-    data, _, _ = make_data(d, seed=0)
-    cfg = make_config(n_vars=d, n_particles=M, n_observations=100, edges_per_node=1 if d <= 5 else 2, graph_prior=prior,
+    # (more observations than variables beyond d = 112: with N = 100 < d the matrix R = t I + X^T X is a rank-deficient Gram matrix plus a
+    #  small ridge, and float32 pivots of such minors lose another digit -- the reference computes them in float32 as well)
+    n_obs = 100 if d <= 112 else 3 * d
+    data, _, _ = make_data(d, seed=0, n_obs=n_obs)
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=n_obs, edges_per_node=1 if d <= 5 else 2, graph_prior=prior,
                       n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa, rng_layout=layout)
     st = c_oracle64.new_state(cfg, prng.PRNGKey(1))
     eng = _engine(cfg, data.x)
@@ -91,13 +98,19 @@ def test_marginal_bge_step_stages(c_oracle64, d, M, S, Sa, prior, steps, layout)
         assert rel_err(eng.read("SCORES"), dbg["scores"]) < 2e-6
         # fp32 Cholesky pivots: the log-det error is multiplied by (N + alpha_lambd - d + l) / 2 ~ 50-90
         ns = eng.read("NODE_SCORES").reshape(M, d, S).transpose(0, 2, 1)  # device layout [m][j][s]
-        assert rel_err(ns, dbg["node_scores"]) < (1e-4 if d <= 50 else 5e-4)
-        assert rel_err(eng.read("LOGPROBS_Z"), dbg["logprobs_z"]) < 2e-5
+        assert rel_err(ns, dbg["node_scores"]) < (1e-4 if d <= 50 else (5e-4 if d <= 112 else 1e-3))
+        assert rel_err(eng.read("LOGPROBS_Z"), dbg["logprobs_z"]) < (2e-5 if d <= 112 else 5e-5)   # (measured 3.1e-5 at d = 128)
         assert rel_err(eng.read("W_LIK"), dbg["w_lik"]) < 2e-3
         assert rel_err(eng.read("W_ACYC"), dbg["w_acyc"]) < 1e-5
         assert rel_err(eng.read("GRAD_Z"), dbg["grad_z"]) < 1e-4
         assert rel_err(eng.read("KXX"), dbg["kxx"]) < 1e-5
         assert rel_err(eng.read("PHI_Z"), dbg["phi_z"]) < 1e-4
+        if 0.1 * float(np.abs(dbg["phi_z"]).max()) ** 2 > 1e38:
+            # tr((I + G/d)^d) of the dense soft graphs of the first steps grows like 1.5^d: beyond d ~ 128 phi^2 leaves the float32 range in
+            # RMSprop's second moment from d = 128 on (for the reference's float32 arithmetic as for the device's; the f64 oracle does not overflow), so the
+            # comparison ends with phi
+            assert d >= 128
+            continue
         assert rel_err(g["v_z"], st["v_z"]) < 2e-4
         assert rel_err(g["z"], st["z"]) < 1e-4  # north_star tolerance on Z
     eng.close()
@@ -566,6 +579,7 @@ def test_joint_densenn_step_stages(c_oracle64, d, M, S, Sa, H, act, bias, est, i
     (12, 3, 16, 4, (80,), "leakyrelu", True, "reparam", False, (2,), 40),   # one layer wider than the MFMA kernels take
     (6, 3, 16, 4, (5,), "relu", True, "reparam", True, (1,), 150),          # more observations than the MFMA kernels take
     (20, 3, 16, 4, (32,), "relu", True, "reparam", False, (2,), 60),        # (32,): MFMA path, listed next to (8, 8) for comparison
+    (7, 2, 8, 2, (4, 4, 3, 3, 2, 2), "tanh", True, "reparam", True, (1,), 30),   # six hidden layers (the config struct carries up to eight)
 ])
 def test_joint_densenn_general_stacks(c_oracle64, d, M, S, Sa, hidden, act, bias, est, interv, steps, N):
     """DenseNonlinearGaussian with an arbitrary tuple of hidden layers / width / observation count (nonlinearGaussian.py:35-81,
@@ -634,6 +648,76 @@ def test_densenn_sample_and_scoring(c_oracle64):
     assert rel_err(got, ref) < 2e-5
     mix = dibs.get_mixture(g, theta)
     assert abs(np.exp(mix.logp).sum() - 1) < 1e-6
+
+
+@pytest.mark.parametrize("d", [130, 160])
+def test_large_n_vars_paths(c_oracle64, d):
+    """113 .. 256 variables (reference: no size limit, graph_utils.py:8-28, linearGaussian.py:63-118): the global-memory paths of the
+    engine -- three / four mask words, one factorisation per wave, matrix powers through HBM, W through global memory -- with interventions
+    (one R_j per node), the hard-graph scorer at that size, the public sample() call, and two rank engines against one."""
+    import torch
+    from dibs_amd.engine import Engine
+    from dibs_amd.inference import MarginalDiBS
+    from dibs_amd.inference.scoring import score_graphs
+    N, M, S, Sa = 2 * d, 4, 8, 2
+    data, gm, lm = make_data(d, seed=2, n_obs=N)
+    rng = np.random.default_rng(3)
+    mask = (rng.random((N, d)) < 0.08).astype(np.int32)
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=N, n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa, has_interventions=True)
+    st = c_oracle64.new_state(cfg, prng.PRNGKey(5))
+    eng = _engine(cfg, data.x, mask)
+    _sync_states(eng, st)
+    dbg = c_oracle64.step(cfg, data.x, mask, st, 2, debug=True)
+    eng.run(2, 1)
+    assert np.array_equal(_graphs_from_masks(eng.read("PARENT_MASKS"), M, S, d), dbg["g_samples"])
+    ns = eng.read("NODE_SCORES").reshape(M, d, S).transpose(0, 2, 1)
+    assert rel_err(ns, dbg["node_scores"]) < 1e-3
+    assert rel_err(eng.read("LOGPROBS_Z"), dbg["logprobs_z"]) < 5e-5
+    assert rel_err(eng.read("W_LIK"), dbg["w_lik"]) < 2e-3
+    assert rel_err(eng.read("W_ACYC"), dbg["w_acyc"]) < 1e-5
+    assert rel_err(eng.read("GRAD_Z"), dbg["grad_z"]) < 1e-4
+    assert rel_err(eng.read("PHI_Z"), dbg["phi_z"]) < 1e-4
+    eng.close()
+    # hard-graph scorer (dibs_score_graphs): given parent sets of up to four mask words
+    g = (rng.random((7, d, d)) < 0.05).astype(np.int32)
+    g[:, np.arange(d), np.arange(d)] = 0
+    g[0], g[1] = data.g, 0
+    g[2] = np.triu(np.ones((d, d), np.int32), 1)   # complete DAG: parent sets of every size up to d - 1 (complement form)
+    ref = c_oracle64.score_graphs(cfg, data.x, mask, g)
+    assert rel_err(score_graphs(lm, g, None, data.x, mask), ref) < 5e-5
+    # public API + sharding: two rank engines (packed rows) == one engine, bit for bit
+    gs = MarginalDiBS(x=data.x, graph_model=gm, likelihood_model=lm, n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa).sample(
+        key=prng.PRNGKey(1), n_particles=M, steps=3)
+    assert gs.shape == (M, d, d)
+    cfg1 = make_config(n_vars=d, n_particles=M, n_observations=N, n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa)
+    ref_e = _engine(cfg1, data.x)
+    ref_e.init_particles(prng.PRNGKey(8))
+    ref_e.run(0, 3)
+    zref = ref_e.get_state()["z"]
+    ref_e.close()
+    ts = torch.cuda.Stream()
+    engs = []
+    for r in range(2):
+        e = Engine(make_config(n_vars=d, n_particles=M, n_observations=N, n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa, rank=r, n_ranks=2),
+                   stream=ts.cuda_stream)
+        e.set_data(data.x)
+        e.init_particles(prng.PRNGKey(8))
+        engs.append(e)
+    n = engs[0].gather_elems_per_rank()
+    with torch.cuda.stream(ts):
+        sends = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(2)]
+        recv = torch.zeros(2 * n, dtype=torch.float32, device="cuda")
+        for t in range(3):
+            for r in range(2):
+                engs[r].step_local(t, sends[r].data_ptr())
+            torch.cat(sends, out=recv)
+            for r in range(2):
+                engs[r].step_update(t, recv.data_ptr())
+    torch.cuda.synchronize()
+    z2 = np.concatenate([e.get_state()["z"] for e in engs])
+    for e in engs:
+        e.close()
+    assert np.array_equal(z2, zref)
 
 
 @pytest.mark.parametrize("joint,d", [(False, 20), (True, 20), (False, 50), (True, 50)])
