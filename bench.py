@@ -123,6 +123,18 @@ def roofline_of(dom, avg_s, cfgname, M, K, eng_counters):
         flops = M * S_MC * d * (2 * N_OBS * d * H + 2 * N_OBS * H)
         roof.update(rocprof_kernel="k_nn_logprobs + k_nn_grad", pipe="mfma_f32", flops_per_launch=flops, achieved=flops / avg_s / 1e12,
                     flops_model="M*S*d*(2NdH + 2NH): forward pass of one estimator (a third of SURVEY 8(d) F_lik(NN) per estimator)")
+    elif dom in ("phi_update", "kmat"):
+        # particle-coupling kernels (dominant only with many particles on one GPU): vector-ALU kernels on packed f32
+        Dp = 2 * d * d + (d * d if c["model"] == "lingauss" else (d * (d * H + H + H + 1) if c["model"] == "densenn" else 0))
+        flops = (6.0 if dom == "phi_update" else 1.5) * M * M * Dp
+        roof.update(rocprof_kernel="k_phi_update<TA>" if dom == "phi_update" else "k_kmat", pipe="valu_f32 (v_pk_fma_f32)", flops_per_launch=flops,
+                    achieved=flops / avg_s / 1e12,
+                    flops_model=("3*M*M*(D+P) FMA: phi_a = -(1/M) sum_b [k(b,a) grad_b - (2/h) k(b,a) (x_b - x_a)] (SURVEY 8(d) F_kern; z and theta segments "
+                                 "are separate launches: avg_launch_us is their mean, flops their sum / launches)") if dom == "phi_update" else
+                                "3*M*M*(D+P)/2 flop: squared distances by direct differences, upper triangle (z and theta segments are separate launches)")
+        if c["model"] != "bge":
+            roof["flops_per_launch"] = flops / 2.0
+            roof["achieved"] = roof["flops_per_launch"] / avg_s / 1e12
     else:
         roof.update(pipe="valu_f32", achieved=None)
     roof["frac"] = roof["achieved"] / roof["peak"] if roof.get("achieved") else None

@@ -16,7 +16,7 @@ BUF = dict(Z=0, V_Z=1, THETA=2, V_THETA=3, SCORES=4, LOGPROBS_Z=5, W_LIK=6, W_AC
            GRAD_THETA=9, KXX=10, PHI_Z=11, BASELINE=12, NODE_SCORES=13, PARENT_MASKS=14,
            LOGPROBS_THETA=15, PHI_THETA=16, GATHER=17)
 KERNELS = ["edge", "bge_nodes", "lik_weights", "acyc", "zgrad", "kmat", "phi_update", "lin_logprobs",
-           "lin_grad", "nn_theta", "nn_z", "pack", "bge_big", "wtotal", "particle_grad", "k15"]
+           "lin_grad", "nn_theta", "nn_z", "pack", "bge_big", "acyc_reduce", "particle_grad", "k15"]
 K_COUNT = 16
 
 

@@ -673,10 +673,16 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
   if (fork) {
     hipEventRecord(e->ev_fork, e->stream);
     hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
-    KTimer tm(e, DIBS_K_ACYC, e->stream2);
     const AcycLaunch al{e->stream2, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
                         e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny};
-    acyc_launch(al);
+    {
+      KTimer tm(e, DIBS_K_ACYC, e->stream2);
+      acyc_launch_power(al);
+    }
+    {
+      KTimer tm(e, DIBS_K_ACYC_REDUCE, e->stream2);
+      acyc_launch_reduce(al);
+    }
   }
   // Single rank: the kernel matrices need only z (and theta), which are final when the step starts.  For the joint models, and for the
   // marginal model once the matrix is large against the sampling work (M D > 4 S d^2), they follow the acyclicity kernel on the second
@@ -763,10 +769,16 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
   if (fork) {
     hipStreamWaitEvent(e->stream, e->ev_join, 0);  // (covers the kernel matrices: they precede the acyclicity kernel on that stream)
   } else {
-    KTimer tm(e, DIBS_K_ACYC);
     const AcycLaunch al{e->stream, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
                         e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny};
-    acyc_launch(al);
+    {
+      KTimer tm(e, DIBS_K_ACYC);
+      acyc_launch_power(al);
+    }
+    {
+      KTimer tm(e, DIBS_K_ACYC_REDUCE);
+      acyc_launch_reduce(al);
+    }
   }
   {
     // one block per particle: (score estimator: softmax weights -> W_lik,) total score-space gradient, back-projection, packed row

@@ -30,5 +30,6 @@ struct AcycLaunch {
   float alpha, tau;
   int layout, tiny;
 };
-void acyc_launch(const AcycLaunch& a);
+void acyc_launch_power(const AcycLaunch& a);   // matrix powers -> per-block partial sums (n_vars > 112: everything, straight into w_acyc)
+void acyc_launch_reduce(const AcycLaunch& a);  // partial sums -> w_acyc (same stream)
 size_t acyc_big_elems(int Mloc, int d, int Sa);

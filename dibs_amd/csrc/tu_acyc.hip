@@ -60,17 +60,17 @@ static void acyc_big_launch(const AcycLaunch& a) {
                      a.Sa, a.alpha, a.tau, a.layout, a.tiny);
 }
 
-static void acyc_launch_power(const AcycLaunch& a);
-void acyc_launch(const AcycLaunch& a) {
+// mean over the chains: fixed-order sum of the blocks' partial sums (the global-memory path of n_vars > 112 sums inside k_acycb_out)
+void acyc_launch_reduce(const AcycLaunch& a) {
+  if (a.big) return;
+  const int dd = a.d * a.d;
+  hipLaunchKernelGGL(k_acyc_reduce, dim3(a.Mloc, (dd + 255) / 256), dim3(256), 0, a.stream, a.part, a.w_acyc, a.nblk, dd, 1.0f / (float)a.Sa);
+}
+void acyc_launch_power(const AcycLaunch& a) {
   if (a.big) {
     acyc_big_launch(a);
     return;
   }
-  acyc_launch_power(a);
-  const int dd = a.d * a.d;
-  hipLaunchKernelGGL(k_acyc_reduce, dim3(a.Mloc, (dd + 255) / 256), dim3(256), 0, a.stream, a.part, a.w_acyc, a.nblk, dd, 1.0f / (float)a.Sa);
-}
-static void acyc_launch_power(const AcycLaunch& a) {
   if (acyc_use_bf16(a)) {
     size_t lds = 2 * ABF_IMG_BYTES;
       const dim3 grid(a.nblk, (a.Mloc + 7) & ~7);

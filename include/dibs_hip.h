@@ -110,7 +110,7 @@ enum {
 enum {
   DIBS_K_EDGE = 0, DIBS_K_BGE_NODES = 1, DIBS_K_LIK_WEIGHTS = 2, DIBS_K_ACYC = 3, DIBS_K_ZGRAD = 4,
   DIBS_K_KMAT = 5, DIBS_K_PHI_UPDATE = 6, DIBS_K_LIN_THETA = 7, DIBS_K_LIN_Z = 8, DIBS_K_NN_THETA = 9,
-  DIBS_K_NN_Z = 10, DIBS_K_PACK = 11, DIBS_K_BGE_BIG = 12 /* the three queue launches */, DIBS_K_WTOTAL = 13, DIBS_K_TAIL = 14 /* k_particle_grad */,
+  DIBS_K_NN_Z = 10, DIBS_K_PACK = 11, DIBS_K_BGE_BIG = 12 /* the three queue launches */, DIBS_K_ACYC_REDUCE = 13 /* k_acyc_reduce */, DIBS_K_TAIL = 14 /* k_particle_grad */,
   DIBS_K_COUNT = 16
 };
 
