@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed window until the timed regions add up to this much")
     ap.add_argument("--n-particles", type=int, default=None, help="override the particle count of the config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-smoke", action="store_true",
+                    help="with --gpus 1: run the sharded code path (process group of ONE rank, real RCCL calls, overlapped exchange) instead of "
+                         "dibs_engine_run -- exercises on one GPU what --gpus N > 1 executes")
     args = ap.parse_args()
     K, W, N = args.steps, args.warmup, args.gpus
     M = args.n_particles or CONFIGS[args.config]["M"]
@@ -171,8 +174,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    sharded = N > 1 or args.dist_smoke
     dist = None
-    if N > 1:
+    if sharded:
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -186,11 +191,11 @@ def main():
         """Engine + runner for one workload; returns (engine, run, snapshot at t = W, per-repetition seconds)."""
         cfg, x, mask = make_workload(cfgname, M_, rank, N, local_rank)
         # N > 1: engine kernels and the RCCL all-gather share one dedicated (non-default) torch stream
-        tstream = torch.cuda.Stream() if N > 1 else None
+        tstream = torch.cuda.Stream() if sharded else None
         eng = Engine(cfg, stream=tstream.cuda_stream if tstream is not None else None)
         eng.set_data(x, mask)
         eng.init_particles(random.PRNGKey(1))
-        if N > 1:
+        if sharded:
             from dibs_amd.distributed import OverlapBuffers, refresh_values, run_sharded_overlapped
             with torch.cuda.stream(tstream):
                 buf = OverlapBuffers(eng, N, torch.device("cuda", local_rank), torch.float32)
@@ -200,12 +205,12 @@ def main():
                 with torch.cuda.stream(tstream):
                     # per step: phase A (+ kernel-matrix slab from the values gathered on the side stream) -> all-gather of the gradient
                     # rows (RCCL) -> phase B -> export + all-gather of the new values on the side stream, beside the next phase A
-                    run_sharded_overlapped(eng, t0, n, buf)
+                    run_sharded_overlapped(eng, t0, n, buf, always_collective=True)
 
             def restore(snap_):
                 eng.set_state(**snap_)
                 with torch.cuda.stream(tstream):
-                    refresh_values(eng, buf)   # untimed: the values of the restored state (in a run they were gathered during the step before)
+                    refresh_values(eng, buf, always_collective=True)   # untimed: the values of the restored state (in a run they were gathered during the step before)
         else:
             send = recv = None
 
@@ -247,14 +252,14 @@ def main():
         "config": {"workload": c["label"], "name": args.config, "n_vars": d, "n_particles": M, "n_observations": N_OBS,
                    "n_grad_mc_samples": S_MC, "n_acyclicity_mc_samples": SA_MC,
                    "timed_steps": f"t={W}..{W + K - 1} of one trajectory from PRNGKey(1)",
-                   "parallelism": f"particles sharded over {N} rank(s); gradients all-gathered between the phases, values beside phase A" if N > 1 else "single GPU"},
+                   "parallelism": f"particles sharded over {N} rank(s); gradients all-gathered between the phases, values beside phase A" if sharded else "single GPU"},
         "reps": len(rep_s), "timed_seconds_total": float(np.sum(rep_s)),
         "rep_ms_per_step": {"median": 1e3 * elapsed / K, "min": 1e3 * min(rep_s) / K, "max": 1e3 * max(rep_s) / K,
                             "first5": [1e3 * r / K for r in rep_s[:5]]},
         "rep_spread": (float(np.percentile(rep_s, 90)) - float(np.percentile(rep_s, 10))) / elapsed,
     }
 
-    if N > 1:
+    if sharded:
         # ---- diagnosis of a sharded run: per-rank kernel timers, the collective alone, config 4 beside the strong-scaling headline ----
         restore(snap)
         eng.set_profiling(True)
@@ -278,10 +283,10 @@ def main():
         out["sharded"] = {
             "kernel_us_per_step_by_rank": allk, "allgather_us": ag_us, "allgather_bytes_per_rank": int(send.numel() * 4),
             "exchange": "overlapped: the values [z | theta] are all-gathered on a side stream right after the optimizer step (beside the next "
-                        "phase A, where the kernel-matrix slab is computed from them on the engine's second stream); between phase A and phase B "
+                        "phase A) and the kernel-matrix slab is computed from them on that stream, behind the gather; between phase A and phase B "
                         "only the gradient rows travel (allgather_us / allgather_bytes_per_rank are THAT collective)",
-            "strong_scaling_bound": "128 particles: a rank's step is 6-7 dependent launches of 6-20 us that do not shrink with the shard "
-                                    "(profiles/round2_shard_scaling.txt: 212 / 159 / 107 / 96 us per rank-step at 1/2/4/8 ranks on one GPU, "
+            "strong_scaling_bound": "128 particles: a rank's step is five dependent launches of 10-24 us that do not shrink with the shard "
+                                    "(profiles/round3_shard_scaling.txt: 223 / 173 / 118 / 100 us per rank-step at 1/2/4/8 ranks on one GPU, "
                                     "before the collective) => <= 2.2x at 8 GPUs; the >= 6x of north_star needs per-rank work >> launch "
                                     "latency, i.e. config 4 (1024 particles, 128 per rank)"}
         if args.config == "headline":
@@ -292,7 +297,7 @@ def main():
                               "n_gpus": N, "particles_per_rank": 1024 // N, "scaling": "weak vs the 1-GPU headline (128 particles per rank at 8 GPUs)"}
             eng = e4
 
-    if rank == 0 and N == 1:
+    if rank == 0 and not sharded:
         # ---- roofline of the dominant kernel: the same K steps replayed with per-kernel HIP events on the engine's stream ----
         eng.set_state(**snap)
         eng.set_profiling(True)

@@ -1,6 +1,7 @@
 // translation unit: BGe sampling / factorisation kernels and their launchers (kernels_bge.h)
 #define DIBS_TU_BGE
 #include "launch.h"
+#include <stdlib.h>
 
 template <typename K>
 static void allow_lds(K kernel, size_t bytes) { dibs_allow_lds((const void*)kernel, bytes); }

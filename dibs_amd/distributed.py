@@ -100,20 +100,27 @@ def _exchange_values(engine, buf, group, single, exported=False):
     buf.fresh = True
 
 
-def refresh_values(engine, buf, group=None):
+def _is_single(group, always_collective):
+    """one rank: device copies stand in for the collectives, unless the caller wants the real calls (a process group of one rank)"""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return True
+    return dist.get_world_size(group) == 1 and not always_collective
+
+
+def refresh_values(engine, buf, group=None, always_collective=False):
     """(re-)gather the values after the engine's state was set from outside (init_particles / set_state); run_sharded_overlapped does it
     on demand, callers that time a run do it beforehand"""
-    import torch.distributed as dist
-    _exchange_values(engine, buf, group, (not dist.is_initialized()) or dist.get_world_size(group) == 1)
+    _exchange_values(engine, buf, group, _is_single(group, always_collective))
 
 
-def run_sharded_overlapped(engine, t_start, n_steps, buf, group=None):
+def run_sharded_overlapped(engine, t_start, n_steps, buf, group=None, always_collective=False):
     """steps t_start .. t_start + n_steps - 1 with the values exchanged off the critical path (see the module docstring).  Call it inside
     ``torch.cuda.stream(<the engine's stream>)`` on a GPU.  `buf.fresh` must be False whenever the engine's state was set from outside
-    (init_particles, set_state) since the last call."""
+    (init_particles, set_state) since the last call.  always_collective: issue the all-gathers also in a group of one rank (smoke tests
+    of the RCCL call path on one GPU)."""
     import torch
-    import torch.distributed as dist
-    single = (not dist.is_initialized()) or dist.get_world_size(group) == 1
+    single = _is_single(group, always_collective)
     if not buf.fresh:
         _exchange_values(engine, buf, group, single)
     for t in range(t_start, t_start + n_steps):

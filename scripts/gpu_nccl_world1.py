@@ -36,8 +36,8 @@ from dibs_amd.distributed import OverlapBuffers, run_sharded_overlapped
 c = Engine(cfg, stream=ts.cuda_stream); c.set_data(data.x); c.init_particles(random.PRNGKey(1))
 with torch.cuda.stream(ts):
     buf = OverlapBuffers(c, 1, torch.device("cuda", 0), torch.float32)
-    run_sharded_overlapped(c, 0, 20, buf); torch.cuda.synchronize()
-    t0 = time.perf_counter(); run_sharded_overlapped(c, 20, K, buf); torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
+    run_sharded_overlapped(c, 0, 20, buf, always_collective=True); torch.cuda.synchronize()
+    t0 = time.perf_counter(); run_sharded_overlapped(c, 20, K, buf, always_collective=True); torch.cuda.synchronize(); dt2 = time.perf_counter() - t0
 zc = c.get_state()["z"]
 print(f"overlapped protocol, RCCL(world 1): {K/dt2:.0f} steps/s; bit-identical: {np.array_equal(zc, b.get_state()['z'])}")
 assert np.array_equal(zc, b.get_state()["z"])

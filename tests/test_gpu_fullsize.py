@@ -413,3 +413,23 @@ def test_headline_free_run_divergence(c_oracle64, c_oracle32):
             assert abs(r["eshd_gpu"] - r["eshd_f64"]) < 1e-3, r
         else:
             assert abs(r["eshd_gpu"] - r["eshd_f64"]) < 0.1, r
+
+
+def test_bench_sharded_path_on_one_gpu():
+    """`bench.py --gpus N` (N > 1) cannot run here, but everything it executes can: `--dist-smoke` drives the same code -- process group
+    (one rank), engine on a dedicated stream, overlapped exchange through real RCCL all-gathers on the side stream and between the phases,
+    per-rank diagnostics, the config-4 extra key -- and must print one valid JSON line whose trajectory equals dibs_engine_run's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dist-smoke", "--steps", "4", "--warmup", "3", "--reps", "2",
+                        "--min-seconds", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["value"] > 100 and out["n_gpus"] == 1 and out["steps"] == 4
+    sh = out["sharded"]
+    assert sh["allgather_us"] > 0 and sh["allgather_bytes_per_rank"] == 128 * 5000 * 4 and len(sh["kernel_us_per_step_by_rank"]) == 1
+    assert "kmat" not in sh["kernel_us_per_step_by_rank"][0]   # (the kernel matrix runs on the side stream, outside the engine's timers)
+    assert out["config4"]["value"] > 10

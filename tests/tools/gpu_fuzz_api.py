@@ -91,7 +91,10 @@ def _leaves(theta):
     return [theta]
 
 
-def run_sharded(cfg_kw, x, mask, key, R, steps):
+def run_sharded(cfg_kw, x, mask, key, R, steps, overlapped=False):
+    """R rank engines in one process; the all-gathers replaced by device concats.  overlapped: the protocol of
+    dibs_amd.distributed.run_sharded_overlapped (values on a side stream behind the optimizer step, kernel-matrix slab behind that gather,
+    gradient rows between the phases)."""
     import torch
     tstream = torch.cuda.Stream()
     engs = []
@@ -100,16 +103,47 @@ def run_sharded(cfg_kw, x, mask, key, R, steps):
         e.set_data(x, mask)
         e.init_particles(key)
         engs.append(e)
-    n = engs[0].gather_elems_per_rank()
-    with torch.cuda.stream(tstream):
-        sends = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(R)]
-        recv = torch.zeros(n * R, dtype=torch.float32, device="cuda")
-        for t in range(steps):
-            for r in range(R):
-                engs[r].step_local(t, sends[r].data_ptr())
-            torch.cat(sends, out=recv)
-            for r in range(R):
-                engs[r].step_update(t, recv.data_ptr())
+    if overlapped:
+        n = engs[0].plane_elems_per_rank()
+        side, exported, ready = torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.stream(tstream):
+            vs = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(R)]
+            gs = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(R)]
+            planes = torch.zeros(2 * n * R, dtype=torch.float32, device="cuda")
+            vals, grads = planes[:n * R], planes[n * R:]
+
+            def exchange(done):
+                for r in range(R):
+                    if not done:
+                        engs[r].export_values(vs[r].data_ptr())
+                exported.record(tstream)
+                with torch.cuda.stream(side):
+                    side.wait_event(exported)
+                    torch.cat(vs, out=vals)
+                    for r in range(R):
+                        engs[r].kmat_values(vals.data_ptr(), side.cuda_stream)
+                    ready.record(side)
+
+            exchange(False)
+            for t in range(steps):
+                for r in range(R):
+                    engs[r].step_local_grads(t, gs[r].data_ptr())
+                torch.cat(gs, out=grads)
+                tstream.wait_event(ready)
+                for r in range(R):
+                    engs[r].step_update_planes(t, planes.data_ptr(), vs[r].data_ptr())
+                exchange(True)
+    else:
+        n = engs[0].gather_elems_per_rank()
+        with torch.cuda.stream(tstream):
+            sends = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(R)]
+            recv = torch.zeros(n * R, dtype=torch.float32, device="cuda")
+            for t in range(steps):
+                for r in range(R):
+                    engs[r].step_local(t, sends[r].data_ptr())
+                torch.cat(sends, out=recv)
+                for r in range(R):
+                    engs[r].step_update(t, recv.data_ptr())
     torch.cuda.synchronize()
     st = [e.get_state() for e in engs]
     for e in engs:
@@ -170,7 +204,7 @@ def section_bc(rng, n):
         okc = np.array_equal(s2["z"], sref["z"]) and (s2["key"] == sref["key"]).all() and \
             (sref.get("theta") is None or np.array_equal(s2["theta"], sref["theta"]))
         # B: sharded
-        sh = run_sharded(kw, x, mask, key, R, steps)
+        sh = run_sharded(kw, x, mask, key, R, steps, overlapped=bool(trial % 2))
         okb = np.array_equal(sh["z"], sref["z"]) and (sh["key"] == sref["key"]).all() and \
             (sref.get("theta") is None or np.array_equal(sh["theta"], sref["theta"]))
         fin = np.isfinite(sref["z"]).all()
