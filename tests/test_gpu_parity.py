@@ -650,7 +650,7 @@ def test_densenn_sample_and_scoring(c_oracle64):
     assert abs(np.exp(mix.logp).sum() - 1) < 1e-6
 
 
-@pytest.mark.parametrize("d", [130, 160])
+@pytest.mark.parametrize("d", [124, 130, 160])   # 124: two mask words, per-node matrices read through the caches; 130 / 160: three words
 def test_large_n_vars_paths(c_oracle64, d):
     """113 .. 256 variables (reference: no size limit, graph_utils.py:8-28, linearGaussian.py:63-118): the global-memory paths of the
     engine -- three / four mask words, one factorisation per wave, matrix powers through HBM, W through global memory -- with interventions
