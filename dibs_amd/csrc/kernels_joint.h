@@ -554,7 +554,8 @@ void joint_lin_score_given(const JointWork& jw, const float* theta, const int32_
 #include "kernels_lin_gram.h"
 
 bool joint_lin_fast_path(int d, int N) {
-  return !getenv("DIBS_LIN_GRAM") && lin_lds_bytes(d, N, (d + 15) / 16, true) <= (size_t)160 * 1024;
+  // (the MFMA kernels are instantiated for up to 7 tiles of 16 variables)
+  return !getenv("DIBS_LIN_GRAM") && d <= 112 && lin_lds_bytes(d, N, (d + 15) / 16, true) <= (size_t)160 * 1024;
 }
 
 int joint_lin_set_gram(JointWork* w, const float* x, const int32_t* mask, int N, int d) {

@@ -526,7 +526,7 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
 }
 
 bool joint_nn_fast_path(int d, int N, const NNParams& np_) {
-  return np_.n_hidden == 1 && np_.H >= 1 && np_.H <= 64 && N <= 128 && nn_lds_bytes(d, N, (d + 15) / 16, true) <= (size_t)160 * 1024;
+  return np_.n_hidden == 1 && np_.H >= 1 && np_.H <= 64 && N <= 128 && d <= 112 && nn_lds_bytes(d, N, (d + 15) / 16, true) <= (size_t)160 * 1024;
 }
 
 // scratch of the general path: grown on first use (activation records of the work items; see kernels_nn_generic.h)

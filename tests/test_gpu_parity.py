@@ -388,6 +388,8 @@ def test_joint_lingauss_step_stages(c_oracle64, d, M, S, Sa, est, prior, interv,
     (50, 2, 16, 4, "reparam", False, 400, False),
     (112, 2, 8, 4, "score", False, 500, False),     # one Gram matrix that no longer fits LDS beside the operands (d > 100): read through the caches
     (104, 2, 8, 4, "reparam", False, 300, False),   # (launch failure found by tests/tools/gpu_fuzz.py)
+    (128, 2, 8, 2, "reparam", True, 300, False),    # > 112 variables: Gram path + the global-memory acyclicity / back-projection kernels
+    (140, 2, 4, 2, "score", False, 200, False),     # close to the limit of the two LDS operands (141)
 ])
 def test_joint_lingauss_gram_path(c_oracle64, monkeypatch, d, M, S, Sa, est, interv, N, force):
     """LinearGaussian for any number of observations (linearGaussian.py:292-316): the Gram-matrix path of kernels_lin_gram.h,
@@ -420,6 +422,10 @@ def test_joint_lingauss_gram_path(c_oracle64, monkeypatch, d, M, S, Sa, est, int
         assert rel_err(eng.read("GRAD_Z"), dbg["grad_z"]) < 2e-3
         assert rel_err(eng.read("PHI_THETA"), dbg["phi_theta"]) < 2e-3
         assert rel_err(g["theta"], st["theta"]) < 1e-4
+        assert rel_err(eng.read("PHI_Z"), dbg["phi_z"]) < 2e-3
+        if 0.1 * float(np.abs(dbg["phi_z"]).max()) ** 2 > 1e38:   # (d >= 128: phi^2 beyond float32 in RMSprop, see test_marginal_bge_step_stages)
+            assert d >= 128
+            continue
         assert rel_err(g["z"], st["z"]) < 1e-4
     eng.close()
     gs = (rng.random((5, d, d)) < 0.1).astype(np.int32)
@@ -580,6 +586,7 @@ def test_joint_densenn_step_stages(c_oracle64, d, M, S, Sa, H, act, bias, est, i
     (6, 3, 16, 4, (5,), "relu", True, "reparam", True, (1,), 150),          # more observations than the MFMA kernels take
     (20, 3, 16, 4, (32,), "relu", True, "reparam", False, (2,), 60),        # (32,): MFMA path, listed next to (8, 8) for comparison
     (7, 2, 8, 2, (4, 4, 3, 3, 2, 2), "tanh", True, "reparam", True, (1,), 30),   # six hidden layers (the config struct carries up to eight)
+    (128, 2, 4, 2, (4,), "relu", True, "reparam", True, (1,), 60),               # > 112 variables: general path + global-memory kernels
 ])
 def test_joint_densenn_general_stacks(c_oracle64, d, M, S, Sa, hidden, act, bias, est, interv, steps, N):
     """DenseNonlinearGaussian with an arbitrary tuple of hidden layers / width / observation count (nonlinearGaussian.py:35-81,
