@@ -491,58 +491,60 @@ __device__ __forceinline__ void bge_chol_quad(const float* __restrict__ R, int m
   last = lst;
 }
 
-// One problem per WAVE, any n <= 128: lane owns rows r and r + 64, the factor lives in LDS (Lb: [d][d|1] floats + index list).
-__host__ __device__ inline size_t bge_generic_wave_bytes(int d) {
-  return ((((size_t)d * (d | 1) + 3) & ~(size_t)3) * 4 + (size_t)(d + 4) * 4 + 15) & ~(size_t)15;
-}
-__device__ __forceinline__ void bge_chol_wave(const float* __restrict__ R, int mat, int ldr, int d, unsigned char* wbase, uint64_t w0,
-                                              uint64_t w1, int j, int li, float& ld2, float& last) {
-  const int lane = threadIdx.x & 63;
-  float* Lb = reinterpret_cast<float*>(wbase);
-  int* myidx = reinterpret_cast<int*>(Lb + (((size_t)d * (d | 1) + 3) & ~(size_t)3));
-  const int ldl = d | 1, n = li + 1;
-  if ((w0 >> lane) & 1ull) myidx[__popcll(w0 & ((1ull << lane) - 1ull))] = lane;
-  if ((w1 >> lane) & 1ull) myidx[__popcll(w0) + __popcll(w1 & ((1ull << lane) - 1ull))] = 64 + lane;
-  if (lane == 0) myidx[li] = j;
-  wave_lds_fence();
-  float mypiv[2] = {1.f, 1.f};
-  for (int kk = 0; kk < n; ++kk) {
-    const int ik = myidx[kk];
-    float accs[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = lane + h * 64;
-      float acc = 0.f;
-      if (r >= kk && r < n) {
-        acc = R[mat + myidx[r] * ldr + ik];
-        const float* lr = Lb + (size_t)r * ldl;
-        const float* lk = Lb + (size_t)kk * ldl;
-#pragma unroll 8
-        for (int p = 0; p < kk; ++p) acc = fmaf(-lr[p], lk[p], acc);  // (unrolled: several LDS reads in flight)
-      }
-      accs[h] = acc;
-      if (r == kk) mypiv[h] = acc;
-    }
-    const float piv = __shfl(kk < 64 ? accs[0] : accs[1], kk & 63, 64);
-    const float inv = __builtin_amdgcn_rsqf(piv);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = lane + h * 64;
-      if (r > kk && r < n) Lb[(size_t)r * ldl + kk] = accs[h] * inv;
-    }
+// One problem per WAVE with 33 .. 64 rows, RIGHT-looking with the matrix in registers: lane r holds row r of the lower triangle (64
+// VGPRs); column step K scales the pivot column, publishes it in LDS (64 floats) and every lane updates its own row with broadcast reads
+// of that column -- a quarter of an LDS read per multiply-add where the left-looking bge_chol_wave needs two, and half a KiB of LDS per
+// wave instead of a d x d factor (which limited a block to two waves at d = 128).  Rows n .. 63 are padding (index d = the zero row /
+// column of Rp, unit diagonal), so every lane runs the same straight-line code.
+// `col`: 64 floats of LDS of this wave (16-byte aligned); `idx`: the problem's index list in LDS (>= 64 ints, padding entries = d).
+template <int K>
+struct BgeWaveCol {
+  static __device__ __forceinline__ void run(float (&A)[64], float* __restrict__ col, int lane, int li, float& lsum, float& lst) {
+    // (no branch on K < n: the padding steps are exact no-ops -- pivot 1, column 0 -- and cost (64 - n)^2 / 2 multiply-adds, while a
+    //  conditional per step made hipcc spill the 64 row registers)
+    const float piv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A[K]), K));  // (the builtin is int -> int)
+    lsum += K < li ? __log2f(piv) : 0.f;
+    lst = (K == li) ? piv : lst;
+    const float l = A[K] * __builtin_amdgcn_rsqf(piv);  // L[r][K] for r > K (lanes r <= K: unused)
+    col[lane] = l;
     wave_lds_fence();
-  }
-  float lg = 0.f;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int r = lane + h * 64;
-    if (r < li) lg += __log2f(mypiv[h]);
+    for (int c4 = (K + 1) & ~3; c4 < 64; c4 += 4) {
+      const float4 lc = *reinterpret_cast<const float4*>(col + c4);
+      if (c4 + 0 > K) A[c4 + 0] = fmaf(-l, lc.x, A[c4 + 0]);
+      if (c4 + 1 > K) A[c4 + 1] = fmaf(-l, lc.y, A[c4 + 1]);
+      if (c4 + 2 > K) A[c4 + 2] = fmaf(-l, lc.z, A[c4 + 2]);
+      if (c4 + 3 > K) A[c4 + 3] = fmaf(-l, lc.w, A[c4 + 3]);
+    }
+    wave_lds_fence();  // (the column buffer is rewritten by the next step)
+    BgeWaveCol<K + 1>::run(A, col, lane, li, lsum, lst);
   }
-  ld2 = wave_sum(lg);
-  last = __shfl(li < 64 ? mypiv[0] : mypiv[1], li & 63, 64);
-  wave_lds_fence();
+};
+template <>
+struct BgeWaveCol<64> {
+  static __device__ __forceinline__ void run(float (&)[64], float*, int, int, float&, float&) {}
+};
+__device__ __forceinline__ void bge_chol_wave_reg(const float* __restrict__ R, size_t mat, int ldr, int d, float* __restrict__ col,
+                                                  const int* __restrict__ idx, int n, int li, float& ld2, float& last) {
+  const int lane = threadIdx.x & 63;
+  float A[64];
+  const size_t ro = mat + (size_t)idx[lane] * ldr;  // (padding lanes: row d, all zeros)
+#pragma unroll
+  for (int c = 0; c < 64; ++c) A[c] = R[ro + idx[c]];  // (entries right of the diagonal are never used as results)
+  if (lane >= n) A[0] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 64; ++c) A[c] = (c == lane && lane >= n) ? 1.0f : A[c];
+  float lsum = 0.f, lst = 1.f;
+  BgeWaveCol<0>::run(A, col, lane, li, lsum, lst);
+  ld2 = lsum;
+  last = lst;
 }
 
+// (the left-looking variant with the factor in LDS, for up to 128 rows, lives in k_bge_chol_wide)
+__host__ __device__ inline size_t bge_generic_wave_bytes(int d) {
+  (void)d;
+  return (64 + 64 + 8) * 4;  // k_bge_chol (d <= 128, n <= 64): column buffer of bge_chol_wave_reg + index list
+}
 // LDS of k_bge_chol:  [R | Q (optional)] [quad-tier index lists: 4 waves x 16 quads x BGE_QS ints] [one-problem-per-wave tier: nwg factors].
 // The two scratch regions are disjoint on purpose: the waves of a block walk the work units without block barriers, so one wave may
 // already be in the per-wave tier while its neighbour still builds quad index lists.  (Until the randomised test of tests/tools/gpu_fuzz.py
@@ -732,7 +734,19 @@ __global__ __launch_bounds__(256) void k_bge_chol(double* __restrict__ node_scor
           float ld2 = 0.f, last = 1.f;
           Tab tb;
           load(ca[0], cb[0], has, code, jj, l, li, mat, comp, w0, w1, tb);
-          if (has) bge_chol_wave(Rm, mat, ldr, d, gbase, w0, w1, jj, li, ld2, last);
+          if (has) {  // (d <= 128 here: every such problem has 33 .. 64 rows)
+            float* colb = reinterpret_cast<float*>(gbase);
+            int* myidx = reinterpret_cast<int*>(colb + 64);
+            myidx[lane] = d;
+            wave_lds_fence();
+            if ((w0 >> lane) & 1ull) myidx[__popcll(w0 & ((1ull << lane) - 1ull))] = lane;
+            if ((w1 >> lane) & 1ull) myidx[__popcll(w0) + __popcll(w1 & ((1ull << lane) - 1ull))] = 64 + lane;
+            wave_lds_fence();
+            if (lane == 0) myidx[li] = jj;
+            wave_lds_fence();
+            bge_chol_wave_reg(Rm, (size_t)mat, ldr, d, colb, myidx, li + 1, li, ld2, last);
+            wave_lds_fence();
+          }
           store(has && lane == 0, code, jj, tb, l, li, comp, ld2, last);
         }
         break;
@@ -806,6 +820,20 @@ __global__ __launch_bounds__(64 * BGE_WIDE_WAVES) void k_bge_chol_wide(double* _
       if (lane == 0) myidx[li] = j;
     }
     wave_lds_fence();
+    if (n <= 64) {  // (wave-uniform) the register-resident variant: most problems once the particles have sharpened
+      wave_lds_fence();
+      int* idx64 = myidx;
+      // index list padded to 64 entries with d (the scatter above wrote n of them)
+      const int mine = lane < n ? idx64[lane] : d;
+      wave_lds_fence();
+      idx64[lane] = mine;
+      wave_lds_fence();
+      float ld2r, lastr;
+      bge_chol_wave_reg(R, mat, ldr, d, Lb, idx64, n, li, ld2r, lastr);
+      wave_lds_fence();
+      if (lane == 0) node_scores[code] = bge_score(bp, j, l, d, comp, ld2r, lastr);
+      continue;
+    }
     float mypiv[2] = {1.f, 1.f};
     for (int kk = 0; kk < n; ++kk) {
       const int ik = myidx[kk];
