@@ -605,6 +605,20 @@ struct KTimer {
   }
 };
 
+// the matrix-power launch of the acyclicity term; while profiling, a single-kernel launch is stamped by the launch itself (kernel start /
+// end, what rocprofv3 reports) instead of an event pair around it, which on the second stream also times ~7 us of dispatch latency
+static void acyc_power_timed(dibs_engine* e, AcycLaunch al, hipStream_t st) {
+  if (e->profiling && acyc_power_takes_events(al)) {
+    hipEventCreate(&al.ev_start);
+    hipEventCreate(&al.ev_stop);
+    acyc_launch_power(al);
+    e->pending.push_back({DIBS_K_ACYC, {al.ev_start, al.ev_stop}});
+    return;
+  }
+  KTimer tm(e, DIBS_K_ACYC, st);
+  acyc_launch_power(al);
+}
+
 static void drain_timers(dibs_engine* e) {
   for (auto& pe : e->pending) {
     hipEventSynchronize(pe.second.second);
@@ -681,11 +695,8 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
     hipEventRecord(e->ev_fork, e->stream);
     hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
     const AcycLaunch al{e->stream2, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
-                        e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny};
-    {
-      KTimer tm(e, DIBS_K_ACYC, e->stream2);
-      acyc_launch_power(al);
-    }
+                        e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr};
+    acyc_power_timed(e, al, e->stream2);
     {
       KTimer tm(e, DIBS_K_ACYC_REDUCE, e->stream2);
       acyc_launch_reduce(al);
@@ -777,11 +788,8 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
     hipStreamWaitEvent(e->stream, e->ev_join, 0);  // (covers the kernel matrices: they precede the acyclicity kernel on that stream)
   } else {
     const AcycLaunch al{e->stream, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
-                        e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny};
-    {
-      KTimer tm(e, DIBS_K_ACYC);
-      acyc_launch_power(al);
-    }
+                        e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr};
+    acyc_power_timed(e, al, e->stream);
     {
       KTimer tm(e, DIBS_K_ACYC_REDUCE);
       acyc_launch_reduce(al);

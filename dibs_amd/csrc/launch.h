@@ -29,7 +29,11 @@ struct AcycLaunch {
   int m0, M, Mloc, d, Sa, cpb, units, nblk;  // units != Sa: chains are taken in Threefry pairs
   float alpha, tau;
   int layout, tiny;
+  hipEvent_t ev_start, ev_stop;  // profiling: kernel-level start / stop time stamps of the matrix-power kernel (see acyc_power_takes_events); else null
 };
+// true: acyc_launch_power is ONE kernel and stamps a.ev_start / a.ev_stop around it (hipExtLaunchKernelGGL: the kernel's own start and
+// end as the profiler sees them, without the dispatch latency an event pair recorded around the launch includes)
+bool acyc_power_takes_events(const AcycLaunch& a);
 void acyc_launch_power(const AcycLaunch& a);   // matrix powers -> per-block partial sums (n_vars > 112: everything, straight into w_acyc)
 void acyc_launch_reduce(const AcycLaunch& a);  // partial sums -> w_acyc (same stream)
 size_t acyc_big_elems(int Mloc, int d, int Sa);

@@ -5,6 +5,7 @@
 #include "kernels_acyc_bf16.h"
 #include "kernels_acyc_big.h"
 #include <stdlib.h>
+#include <hip/hip_ext.h>
 
 template <int NT>
 static void launch_nt(const AcycLaunch& a) {
@@ -66,6 +67,7 @@ void acyc_launch_reduce(const AcycLaunch& a) {
   const int dd = a.d * a.d;
   hipLaunchKernelGGL(k_acyc_reduce, dim3(a.Mloc, (dd + 255) / 256), dim3(256), 0, a.stream, a.part, a.w_acyc, a.nblk, dd, 1.0f / (float)a.Sa);
 }
+bool acyc_power_takes_events(const AcycLaunch& a) { return !a.big && acyc_use_bf16(a); }
 void acyc_launch_power(const AcycLaunch& a) {
   if (a.big) {
     acyc_big_launch(a);
@@ -74,15 +76,18 @@ void acyc_launch_power(const AcycLaunch& a) {
   if (acyc_use_bf16(a)) {
     size_t lds = 2 * ABF_IMG_BYTES;
       const dim3 grid(a.nblk, (a.Mloc + 7) & ~7);
-    if (a.d > 48) {
-      dibs_allow_lds((const void*)k_acyc_bf<true>, lds);
-      hipLaunchKernelGGL(k_acyc_bf<true>, grid, dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.Mloc, a.d, a.Sa, a.cpb, a.alpha,
-                         a.tau, a.layout, a.tiny, a.nblk);
-    } else {
-      dibs_allow_lds((const void*)k_acyc_bf<false>, lds);
-      hipLaunchKernelGGL(k_acyc_bf<false>, grid, dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.Mloc, a.d, a.Sa, a.cpb, a.alpha,
-                         a.tau, a.layout, a.tiny, a.nblk);
+#define ACYC_BF_LAUNCH(FOUR_)                                                                                                              \
+    {                                                                                                                                        \
+      dibs_allow_lds((const void*)k_acyc_bf<FOUR_>, lds);                                                                                    \
+      if (a.ev_start)                                                                                                                        \
+        hipExtLaunchKernelGGL(k_acyc_bf<FOUR_>, grid, dim3(256), (uint32_t)lds, a.stream, a.ev_start, a.ev_stop, 0u, a.scores, a.part, a.carry, \
+                              a.m0, a.M, a.Mloc, a.d, a.Sa, a.cpb, a.alpha, a.tau, a.layout, a.tiny, a.nblk);                                  \
+      else                                                                                                                                   \
+        hipLaunchKernelGGL(k_acyc_bf<FOUR_>, grid, dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.Mloc, a.d, a.Sa, a.cpb,   \
+                           a.alpha, a.tau, a.layout, a.tiny, a.nblk);                                                                          \
     }
+    if (a.d > 48) ACYC_BF_LAUNCH(true) else ACYC_BF_LAUNCH(false)
+#undef ACYC_BF_LAUNCH
     return;
   }
   switch ((a.d + 15) / 16) {

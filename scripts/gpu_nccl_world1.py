@@ -13,8 +13,9 @@ from dibs_amd.target import make_linear_gaussian_equivalent_model
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-data, _, _ = make_linear_gaussian_equivalent_model(key=random.PRNGKey(0), n_vars=50, graph_prior_str="er", n_observations=100)
-cfg = make_config(n_vars=50, n_particles=128, n_observations=100)
+D_, M_ = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (50, 128)   # (small sizes: the host-side cost per step of either protocol)
+data, _, _ = make_linear_gaussian_equivalent_model(key=random.PRNGKey(0), n_vars=D_, graph_prior_str="er", n_observations=100)
+cfg = make_config(n_vars=D_, n_particles=M_, n_observations=100)
 ts = torch.cuda.Stream()
 a = Engine(cfg, stream=ts.cuda_stream); b = Engine(cfg)
 for e in (a, b):
