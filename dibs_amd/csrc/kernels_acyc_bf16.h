@@ -312,3 +312,251 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       }
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// K5b'  the same scheme for 65 <= d <= 112: NT = ceil(d / 16) in {5, 6, 7} tiles and NT waves per block (one block = one pair of chains,
+//       as above).  Differences to k_acyc_bf: the image of a power has 16 NT rows per column tile (2 x 3 x NT x 16 NT x 32 bytes: 77 / 111 /
+//       151 KB -- one block per CU from NT = 6 on), a k-step covers the tile pair (2 ks, 2 ks + 1) of the left operand, and for odd NT the
+//       last k-step's second half has no rows in the image: those fragment reads go to a zeroed 512-byte page (the left operand's pieces
+//       are zero there anyway, but stale LDS bits could be NaN patterns).  Replaces the f32-MFMA k_acyc<NT> at these sizes (BASELINE
+//       config 5 is d = 100): six 16-cycle bf16 MFMAs per 16 x 16 x 32 block instead of eight 32-cycle f32 ones.
+// grid = (ceil(Sa / 2 / cpb), Mloc rounded up to 8; re-indexed XCD-aware inside), block = 64 NT, dynamic LDS = abfw_lds_bytes(NT)
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+struct Abfw {
+  static constexpr int NKS = (NT + 1) / 2, KROWS = 16 * NT, TILE_BYTES = KROWS * 32, PIECE_BYTES = NT * TILE_BYTES, IMG_BYTES = 3 * PIECE_BYTES,
+                       LDT = 16 * NT + 4;
+};
+__host__ __device__ inline size_t abfw_lds_bytes(int nt) { return (size_t)2 * 3 * nt * (16 * nt) * 32 + 512; }
+
+template <int NT>
+struct AbfwFrag {
+  abf_u32x4 a[(NT + 1) / 2][3];
+};
+template <int NT>
+__device__ __forceinline__ void abfw_make_frag(const f32x4 (&v)[NT], AbfwFrag<NT>& f) {
+#pragma unroll
+  for (int tj = 0; tj < NT; ++tj) {
+    uint32_t h0, m0, l0, h1, m1, l1;
+    abf_split(v[tj][0], v[tj][1], h0, m0, l0);
+    abf_split(v[tj][2], v[tj][3], h1, m1, l1);
+    const int ks = tj >> 1;
+    if (tj & 1) {
+      f.a[ks][0].z = h0; f.a[ks][0].w = h1;
+      f.a[ks][1].z = m0; f.a[ks][1].w = m1;
+      f.a[ks][2].z = l0; f.a[ks][2].w = l1;
+    } else {
+      f.a[ks][0].x = h0; f.a[ks][0].y = h1;
+      f.a[ks][1].x = m0; f.a[ks][1].y = m1;
+      f.a[ks][2].x = l0; f.a[ks][2].y = l1;
+    }
+  }
+  if (NT & 1) {  // (the partner tile of the last one does not exist)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      f.a[NT >> 1][p].z = 0u;
+      f.a[NT >> 1][p].w = 0u;
+    }
+  }
+}
+template <int NT>
+__device__ __forceinline__ void abfw_store_image(unsigned char* img, int wr_off, const AbfwFrag<NT>& f) {
+#pragma unroll
+  for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const abf_u32x4 q = f.a[tj >> 1][p];
+      const abf_u32x2 w = (tj & 1) ? abf_u32x2{q.z, q.w} : abf_u32x2{q.x, q.y};
+      *reinterpret_cast<abf_u32x2*>(img + wr_off + p * Abfw<NT>::PIECE_BYTES + tj * Abfw<NT>::TILE_BYTES) = w;
+    }
+}
+// fragment of rows 32 ks .. 32 ks + 31 of one column tile; HALF: only rows 32 ks .. + 15 exist, the other half comes from the zero page
+template <bool HALF>
+__device__ __forceinline__ abf_bf16x8 abfw_tr_pair(const unsigned char* p, const unsigned char* zero) {
+  typedef __attribute__((address_space(3))) abf_s16x4 lds_s16x4;
+  const abf_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  const abf_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(HALF ? zero : p + 16 * 32));
+  return __builtin_bit_cast(abf_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// k-step KS of the column tiles tj .. tj + NU - 1: 6 fragment reads and 6 MFMAs per tile (small terms first, as in abf_group); the two
+// tiles alternate so that consecutive MFMAs never share an accumulator
+template <int NT, int KS, int NU>
+__device__ __forceinline__ void abfw_tile_step(f32x4 (&acc)[NT], const AbfwFrag<NT>& A, const unsigned char* img, int rd_off, const unsigned char* zero,
+                                               int tj) {
+  constexpr bool HALF = (NT & 1) && KS == (NT >> 1);
+  abf_bf16x8 b[NU][3];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      b[u][p] = abfw_tr_pair<HALF>(img + rd_off + p * Abfw<NT>::PIECE_BYTES + (tj + u) * Abfw<NT>::TILE_BYTES + KS * 32 * 32, zero);
+  const abf_bf16x8 ah = __builtin_bit_cast(abf_bf16x8, A.a[KS][0]), am = __builtin_bit_cast(abf_bf16x8, A.a[KS][1]),
+                   al = __builtin_bit_cast(abf_bf16x8, A.a[KS][2]);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    if (KS == 0) acc[tj + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u][2], ah, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    else acc[tj + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u][2], ah, acc[tj + u], 0, 0, 0);
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) acc[tj + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u][0], al, acc[tj + u], 0, 0, 0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) acc[tj + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u][1], am, acc[tj + u], 0, 0, 0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) acc[tj + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u][1], ah, acc[tj + u], 0, 0, 0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) acc[tj + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u][0], am, acc[tj + u], 0, 0, 0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) acc[tj + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u][0], ah, acc[tj + u], 0, 0, 0);
+}
+template <int NT, int KS>
+struct AbfwSteps {
+  static __device__ __forceinline__ void run(f32x4 (&acc)[NT], const AbfwFrag<NT>& A, const unsigned char* img, int rd_off, const unsigned char* zero) {
+#pragma unroll
+    for (int tj = 0; tj + 1 < NT; tj += 2) abfw_tile_step<NT, KS, 2>(acc, A, img, rd_off, zero, tj);
+    if (NT & 1) abfw_tile_step<NT, KS, 1>(acc, A, img, rd_off, zero, NT - 1);
+    AbfwSteps<NT, KS + 1>::run(acc, A, img, rd_off, zero);
+  }
+};
+template <int NT>
+struct AbfwSteps<NT, (NT + 1) / 2> {
+  static __device__ __forceinline__ void run(f32x4 (&)[NT], const AbfwFrag<NT>&, const unsigned char*, int, const unsigned char*) {}
+};
+template <int NT>
+__device__ __forceinline__ void abfw_matmul(f32x4 (&acc)[NT], const AbfwFrag<NT>& A, const unsigned char* img, int rd_off, const unsigned char* zero) {
+  AbfwSteps<NT, 0>::run(acc, A, img, rd_off, zero);
+}
+template <int NT>
+__device__ __forceinline__ void abfw_m0(const f32x4 (&g)[NT], f32x4 (&v)[NT], int a, int b0, int d, float inv_d) {
+#pragma unroll
+  for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = b0 + 16 * tj + i;
+      v[tj][i] = (a == b && a < d) ? 1.0f : g[tj][i] * inv_d;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void k_acyc_bfw(const float* __restrict__ scores, float* __restrict__ part, Key2 carry, int m0, int M_global,
+                                                      int Mloc, int d, int Sa, int cpb, float alpha, float tau, int layout, int tiny, int n_acyc_blk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned char* const sb = reinterpret_cast<unsigned char*>(smem);
+  constexpr int IMG = Abfw<NT>::IMG_BYTES, LDT = Abfw<NT>::LDT;
+  unsigned char* const zero = sb + 2 * IMG;  // 512 zero bytes
+  const int L = blockIdx.x + gridDim.x * blockIdx.y, p_lo = L & 7, tq = L >> 3;
+  const int bx = tq % (int)gridDim.x, m = (tq / (int)gridDim.x) * 8 + p_lo;
+  if (m >= Mloc) return;  // (block-uniform)
+  const int blk = bx, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g4 = lane >> 4, r = lane & 15;
+  const int a = 16 * wave + r, b0 = 4 * g4;
+  const Key2 km = rng_split_row_uniform(carry, (uint32_t)M_global + 1u, (uint32_t)(m0 + m) + 1u, layout);  // dibs.py:595: key used directly
+  const uint64_t dd = (uint64_t)d * d, nbits = (uint64_t)Sa * dd;
+  const float inv_d = 1.0f / (float)d;
+  const float* sm = scores + (size_t)m * dd;
+  const bool fast = tau == 1.0f;
+  const float ulo = tiny ? 1.17549435e-38f : 1.1920929e-07f;
+  const int n_units = Sa >> 1;
+  const TfKeys tk = tf_keys(km);
+  const int wr_off = a * 32 + ((g4 + (r >> 2)) & 3) * 8;
+  const int rd_off = (4 * g4 + (r >> 2)) * 32 + (((r & 3) + g4) & 3) * 8;
+  float* const po = part + ((size_t)m * n_acyc_blk + blk) * dd + (size_t)a * d;
+  if (tid < 128) reinterpret_cast<uint32_t*>(zero)[tid] = 0u;
+  f32x4 g[NT], gnext[NT], out[NT];
+#pragma unroll
+  for (int tj = 0; tj < NT; ++tj) {
+    gnext[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    out[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int c = 0; c < cpb; ++c) {
+    const int unit = blk * cpb + c;
+    if (unit >= n_units) break;
+    for (int hf = 0; hf < 2; ++hf) {
+      const int sa = unit + hf * (Sa >> 1);
+      const float* sml = sm;
+      asm volatile("" : "+s"(sml));  // opaque per pass: keeps exp(-alpha s) out of loop-invariant registers
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int b = b0 + 16 * tj + i;
+          float gv = 0.f;
+          if (a < d && b < d && a != b) {
+            if (hf == 1) {
+              gv = gnext[tj][i];
+            } else {
+              const float as = alpha * sml[a * d + b];
+              const float ea = fast ? expf(-as) : as;
+              uint32_t y0, y1;
+              const uint32_t c0 = (uint32_t)((uint64_t)sa * dd) + (uint32_t)(a * d + b);
+              threefry2x32_uk(tk, c0, c0 + (uint32_t)(nbits >> 1), y0, y1);
+              if (fast) {
+                const float u0 = rng_uniform(y0, ulo, 1.0f), u1 = rng_uniform(y1, ulo, 1.0f);
+                const float den0 = fmaf(1.0f - u0, ea, u0), den1 = fmaf(1.0f - u1, ea, u1);
+                gv = den0 == u0 ? 1.0f : u0 * __builtin_amdgcn_rcpf(den0);   // (saturated edges give exactly 1: see k_acyc_bf)
+                gnext[tj][i] = den1 == u1 ? 1.0f : u1 * __builtin_amdgcn_rcpf(den1);
+              } else {
+                gv = 1.0f / (1.0f + expf(-tau * (rng_logistic(y0, tiny) + ea)));
+                gnext[tj][i] = 1.0f / (1.0f + expf(-tau * (rng_logistic(y1, tiny) + ea)));
+              }
+            }
+          }
+          g[tj][i] = gv;
+        }
+      AbfwFrag<NT> A;
+      f32x4 acc[NT];
+      abfw_m0<NT>(g, acc, a, b0, d, inv_d);
+      abfw_make_frag<NT>(acc, A);
+      int cur = 0;
+      abfw_store_image<NT>(sb, wr_off, A);
+      __syncthreads();
+      const int ex = d - 1;
+      const int hb = 31 - __builtin_clz((unsigned)ex);
+      for (int bit = hb - 1; bit >= 0; --bit) {
+        const bool mult = (ex >> bit) & 1, last_sq = bit == 0 && !mult;
+        abfw_matmul<NT>(acc, A, sb + cur, rd_off, zero);  // P <- P P
+        cur ^= IMG;
+        if (!last_sq) {
+          abfw_make_frag<NT>(acc, A);
+          abfw_store_image<NT>(sb + cur, wr_off, A);
+          __syncthreads();
+          if (mult) {  // P <- M P
+            f32x4 mv[NT];
+            AbfwFrag<NT> A0;
+            abfw_m0<NT>(g, mv, a, b0, d, inv_d);
+            abfw_make_frag<NT>(mv, A0);
+            abfw_matmul<NT>(acc, A0, sb + cur, rd_off, zero);
+            cur ^= IMG;
+            if (bit != 0) {
+              abfw_make_frag<NT>(acc, A);
+              abfw_store_image<NT>(sb + cur, wr_off, A);
+              __syncthreads();
+            }
+          }
+        }
+      }
+      float* T = reinterpret_cast<float*>(sb + cur);
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) *reinterpret_cast<f32x4*>(T + a * LDT + 16 * tj + b0) = acc[tj];
+      __syncthreads();
+      const float ta = tau * alpha;
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int b = b0 + 16 * tj + i;
+          const float gv = g[tj][i];
+          out[tj][i] += T[b * LDT + a] * (ta * gv * (1.0f - gv));
+        }
+      __syncthreads();
+    }
+  }
+  if (a < d) {
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int b = b0 + 16 * tj + i;
+        if (b < d) po[b] = out[tj][i];
+      }
+  }
+}

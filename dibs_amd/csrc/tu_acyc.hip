@@ -29,6 +29,19 @@ static bool acyc_use_bf16(const AcycLaunch& a) {
   static const bool off = getenv("DIBS_ACYC_F32") != nullptr;
   return !off && a.units != a.Sa && a.d > 32 && a.d <= 64;
 }
+// 65 <= d <= 112 with paired chains: the same scheme with NT = 5 .. 7 tiles and waves (k_acyc_bfw)
+static bool acyc_use_bfw(const AcycLaunch& a) {
+  static const bool off = getenv("DIBS_ACYC_F32") != nullptr;
+  return !off && a.units != a.Sa && a.d > 64 && a.d <= 112;
+}
+template <int NT>
+static void launch_bfw(const AcycLaunch& a) {
+  const size_t lds = abfw_lds_bytes(NT);
+  const dim3 grid(a.nblk, (a.Mloc + 7) & ~7);
+  dibs_allow_lds((const void*)k_acyc_bfw<NT>, lds);
+  hipLaunchKernelGGL(k_acyc_bfw<NT>, grid, dim3(64 * NT), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.Mloc, a.d, a.Sa, a.cpb, a.alpha,
+                     a.tau, a.layout, a.tiny, a.nblk);
+}
 
 // n_vars > 112: matrices in global memory (kernels_acyc_big.h); a.big = three [Mloc * Sa][dp][dp] buffers
 size_t acyc_big_elems(int Mloc, int d, int Sa) {
@@ -88,6 +101,14 @@ void acyc_launch_power(const AcycLaunch& a) {
     }
     if (a.d > 48) ACYC_BF_LAUNCH(true) else ACYC_BF_LAUNCH(false)
 #undef ACYC_BF_LAUNCH
+    return;
+  }
+  if (acyc_use_bfw(a)) {
+    switch ((a.d + 15) / 16) {
+      case 5: launch_bfw<5>(a); break;
+      case 6: launch_bfw<6>(a); break;
+      default: launch_bfw<7>(a); break;
+    }
     return;
   }
   switch ((a.d + 15) / 16) {

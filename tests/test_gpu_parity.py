@@ -198,6 +198,25 @@ def test_acyclicity_kernel_sizes_33_to_64(c_oracle64, d, Sa):
     eng.close()
 
 
+@pytest.mark.parametrize("d,Sa", [(65, 2), (72, 4), (80, 2), (81, 4), (96, 2), (97, 2), (100, 4), (111, 2), (112, 4), (100, 3)])
+def test_acyclicity_kernel_sizes_65_to_112(c_oracle64, d, Sa):
+    """k_acyc_bfw<5 / 6 / 7> (the split-bf16 scheme with 5 .. 7 tiles and waves, kernels_acyc_bf16.h) at the boundaries of its range:
+    first / last size of every tile count, odd tile counts (the last k-step reads its second half from the zero page), d = 100 (BASELINE
+    config 5).  Sa = 3 takes the f32-MFMA kernel (chains cannot be paired): same tolerance.  reference: graph_utils.py:8-28, dibs.py:557-601"""
+    M, S = 2, 2
+    data, _, _ = make_data(d, seed=2, n_obs=2 * d)
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=2 * d, n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa)
+    st = c_oracle64.new_state(cfg, prng.PRNGKey(5))
+    eng = _engine(cfg, data.x)
+    for t in (1, 6):
+        _sync_states(eng, st)
+        dbg = c_oracle64.step(cfg, data.x, None, st, t, debug=True)
+        eng.run(t, 1)
+        assert rel_err(eng.read("W_ACYC"), dbg["w_acyc"]) < 1e-5
+        assert rel_err(eng.read("PHI_Z"), dbg["phi_z"]) < 1e-4
+    eng.close()
+
+
 @pytest.mark.parametrize("d,Sa", [(20, 4), (40, 4), (50, 4), (50, 3), (70, 2)])
 def test_acyclicity_gradient_of_saturated_soft_graphs_is_zero(c_oracle64, d, Sa):
     """Once alpha * score leaves the range where float32 resolves sigmoid from 0 / 1 (every edge after the first few hundred steps of a
