@@ -119,6 +119,14 @@ def roofline_of(dom, avg_s, cfgname, M, K, eng_counters):
         flops = 2 * M * S_MC * 2 * N_OBS * d * d   # both estimators' forward products x (G o theta): half of SURVEY 8(d) F_lik(LinG)
         roof.update(rocprof_kernel="k_lin_logprobs_pair" if dom == "lin_logprobs" else "k_lin_grad", pipe="mfma_f32", flops_per_launch=flops,
                     achieved=flops / avg_s / 1e12, flops_model="2 estimators * M*S*2*N*d^2 (forward products of SURVEY 8(d) F_lik(LinG))")
+        if dom == "lin_logprobs" and 32 < d <= 64:
+            # k_lin_logprobs_bf: the float products run on the bf16 matrix pipe with three-way split operands (as k_acyc_bf above):
+            # `achieved` / `frac` price the algorithmic float flops against the FP32 peak, the bf16 flops actually issued (row tiles of 16
+            # observations, 64-padded contraction, 16-wide column tiles, 6 products) against the dense bf16 peak next to it.
+            bf16_flops = 2 * M * S_MC * 6 * 2 * (16 * ((N_OBS + 15) // 16)) * 64 * (64 if d > 48 else 48)
+            roof.update(rocprof_kernel="k_lin_logprobs_bf", pipe="mfma_bf16 (3-way split operands: 6 bf16 products per f32 product)",
+                        executed_bf16_tflops=bf16_flops / avg_s / 1e12, peak_bf16_tflops=PEAK_BF16_TFLOPS,
+                        frac_of_bf16_peak=bf16_flops / avg_s / 1e12 / PEAK_BF16_TFLOPS)
     elif dom in ("nn_theta", "nn_z"):
         flops = M * S_MC * d * (2 * N_OBS * d * H + 2 * N_OBS * H)
         roof.update(rocprof_kernel="k_nn_logprobs + k_nn_grad", pipe="mfma_f32", flops_per_launch=flops, achieved=flops / avg_s / 1e12,

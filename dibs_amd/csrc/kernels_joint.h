@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include "rng.h"
 #include "common.h"
+#include "kernels_acyc_bf16.h"
 
 enum { LIN_MODE_THETA = 0, LIN_MODE_Z_SCORE = 1, LIN_MODE_Z_REPARAM = 2, LIN_MODE_GIVEN = 3 };
 
@@ -295,8 +296,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 4 ? 3
     if (soft) {
       if (fast) {  // sigmoid(eps + a), eps = log(u / (1 - u))  ==  u / (u + (1 - u) exp(-a))
         const float u0 = rng_uniform(y0, ulo, 1.0f), u1 = rng_uniform(y1, ulo, 1.0f);
-        g0 = u0 / (u0 + (1.0f - u0) * aux);
-        g1 = u1 / (u1 + (1.0f - u1) * aux);
+        g0 = u0 * __builtin_amdgcn_rcpf(fmaf(1.0f - u0, aux, u0));  // (v_rcp_f32: 1 ulp; an IEEE division is ten instructions)
+        g1 = u1 * __builtin_amdgcn_rcpf(fmaf(1.0f - u1, aux, u1));
       } else {
         g0 = 1.0f / (1.0f + expf(-tau * (rng_logistic(y0, tiny) + aux)));
         g1 = 1.0f / (1.0f + expf(-tau * (rng_logistic(y1, tiny) + aux)));
@@ -366,6 +367,173 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 4 ? 3
     __syncthreads();
     if (tid == 0) logprobs[(size_t)m * S + s0] = (float)(red[0] + red[1] + red[2] + red[3]);
     if (tid == 1) logprobs[(size_t)m * S + s0 + hS] = (float)(red[4] + red[5] + red[6] + red[7]);
+  }
+}
+
+// Same pairing, 33 <= d <= 64, on the bf16 MFMA with three-way split operands (the arithmetic of k_acyc_bf, kernels_acyc_bf16.h: a float
+// is carried as h + m + l, a product as six v_mfma_f32_16x16x32_bf16 -- 96 MFMA cycles for a 16 x 16 x 64 block where the f32 MFMA needs
+// 512).  x's row fragments (left operand, split once per block) stay in registers; the per-sample operand g o theta is split as it is
+// built -- both samples of the pair in ONE packed split, low halves to the first image, high halves to the second -- and written with
+// 2-byte stores into the transposing-read image layout of k_acyc_bf ([piece][column tile][row k][16 columns], chunk swizzle
+// (c + (k >> 2)) % 4).  The MFMA is issued with swapped operands as there, so lane (g, r) holds pred[n = 16 ti + r][j = 16 tj + 4 g + i].
+// grid = (ceil(S / 2 / ppb), Mloc), block = 256, dynamic LDS = 2 * ABF_IMG_BYTES + 64
+template <int EPQ, bool FOUR, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 3, NW == 8 ? 4 : 3))) void k_lin_logprobs_bf(
+    const float* __restrict__ x, const int32_t* __restrict__ mask, const float* __restrict__ theta, const float* __restrict__ scores,
+    const uint32_t* __restrict__ thr, float* __restrict__ logprobs, Key2 carry, int mode, int m0, int M_global, int d, int N, int S, int ppb,
+    float alpha, float tau, int layout, int tiny, float obs_noise, float mu, float sig, int any_mask) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned char* const sb = reinterpret_cast<unsigned char*>(smem);
+  double* red = reinterpret_cast<double*>(sb + 2 * ABF_IMG_BYTES);
+  constexpr int NU = 8 / NW, NTHR = 64 * NW;
+  const int nrt = (N + 15) >> 4;
+  const int m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, r = lane & 15;
+  const int dd = d * d;
+  const float* __restrict__ TH = theta + (size_t)m * dd;
+  const uint32_t* __restrict__ thr_m = thr + (size_t)m * dd;
+  const float* __restrict__ sc_m = scores + (size_t)m * dd;
+  // row n = (wave + 4 u) * 16 + r of x: the same 16 values (columns 16 tj + 4 g + i) are the lane's left-operand fragment and the x of its
+  // output elements
+  AbfFrag XA[NU];
+  float xe[NU][ABF_NT][4];
+  uint32_t ok[NU];
+  float nvalid = 0.f;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int n = (wave + NW * u) * 16 + r;
+    f32x4 v[ABF_NT];
+    ok[u] = 0u;
+#pragma unroll
+    for (int tj = 0; tj < ABF_NT; ++tj)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * tj + 4 * g4 + i;
+        const bool inb = n < N && j < d;
+        const float xv = inb ? x[(size_t)n * d + j] : 0.f;
+        const bool valid = inb && !(any_mask && mask[(size_t)n * d + j]);
+        v[tj][i] = xv;
+        xe[u][tj][i] = valid ? xv : 0.f;
+        ok[u] |= (uint32_t)valid << (tj * 4 + i);
+        nvalid += valid ? 1.0f : 0.0f;
+      }
+    abf_make_frag(v, XA[u]);
+  }
+  const TfKeys tk = tf_keys(lin_mode_key(mode, carry, M_global, m0 + m, layout));
+  const uint32_t half = (uint32_t)(((uint64_t)S * dd) >> 1);
+  const int hS = S >> 1;
+  const float inv2 = 0.5f / obs_noise;
+  const float lognorm_x = -0.5f * logf(obs_noise) - 0.918938533204672742f;
+  const bool soft = mode == LIN_MODE_Z_REPARAM, fast = tau == 1.0f;
+  const float ulo = tiny ? 1.17549435e-38f : 1.1920929e-07f;
+  const int rd_off = (4 * g4 + (r >> 2)) * 32 + (((r & 3) + g4) & 3) * 8;
+  const float inv_d = 1.0f / (float)d;
+  for (int e = tid; e < 2 * ABF_IMG_BYTES / 16; e += NTHR) reinterpret_cast<float4*>(sb)[e] = make_float4(0.f, 0.f, 0.f, 0.f);  // padding, diagonal
+  // sample-independent factors of element e = (i, j): byte offset of W[i][j] inside a piece, theta, logN(theta), aux (as k_lin_logprobs_pair)
+  auto factors = [&](int e, int& off, float& th, float& ln, float& aux) {
+    const int i = (int)(((float)e + 0.5f) * inv_d), j = e - i * d;  // exact for e < 2^20
+    off = (i == j) ? -1 : (j >> 4) * ABF_TILE_BYTES + i * 32 + ((((j & 15) >> 2) + (i >> 2)) & 3) * 8 + (j & 3) * 2;
+    th = TH[e];
+    ln = lin_logn(th, mu, sig);
+    if (soft) {
+      const float as = alpha * sc_m[e];
+      aux = fast ? expf(-as) : as;
+    } else {
+      aux = __uint_as_float(thr_m[e]);
+    }
+  };
+  int offs[EPQ > 0 ? EPQ : 1];
+  float ths[EPQ > 0 ? EPQ : 1], lns[EPQ > 0 ? EPQ : 1], auxs[EPQ > 0 ? EPQ : 1];
+  if constexpr (EPQ > 0) {
+#pragma unroll
+    for (int q = 0; q < EPQ; ++q) {
+      const int e = tid + NTHR * q;
+      offs[q] = -1;
+      ths[q] = lns[q] = auxs[q] = 0.f;
+      if (e < dd) factors(e, offs[q], ths[q], lns[q], auxs[q]);
+    }
+  }
+  float part[2];
+  auto element = [&](int e, uint32_t cbase, int off, float th, float ln, float aux) {
+    if (off < 0) return;
+    uint32_t y0, y1;
+    threefry2x32_uk(tk, cbase + (uint32_t)e, cbase + (uint32_t)e + half, y0, y1);
+    float g0, g1;
+    if (soft) {
+      if (fast) {
+        const float u0 = rng_uniform(y0, ulo, 1.0f), u1 = rng_uniform(y1, ulo, 1.0f);
+        g0 = u0 * __builtin_amdgcn_rcpf(fmaf(1.0f - u0, aux, u0));  // (v_rcp_f32: 1 ulp; an IEEE division is ten instructions)
+        g1 = u1 * __builtin_amdgcn_rcpf(fmaf(1.0f - u1, aux, u1));
+      } else {
+        g0 = 1.0f / (1.0f + expf(-tau * (rng_logistic(y0, tiny) + aux)));
+        g1 = 1.0f / (1.0f + expf(-tau * (rng_logistic(y1, tiny) + aux)));
+      }
+    } else {
+      const uint32_t ta = __float_as_uint(aux);
+      g0 = (y0 >> 9) < ta ? 1.0f : 0.0f;
+      g1 = (y1 >> 9) < ta ? 1.0f : 0.0f;
+    }
+    uint32_t ph, pm, pl;
+    abf_split(g0 * th, g1 * th, ph, pm, pl);
+    unsigned char* const w0 = sb + off;
+    *reinterpret_cast<uint16_t*>(w0) = (uint16_t)ph;
+    *reinterpret_cast<uint16_t*>(w0 + ABF_PIECE_BYTES) = (uint16_t)pm;
+    *reinterpret_cast<uint16_t*>(w0 + 2 * ABF_PIECE_BYTES) = (uint16_t)pl;
+    *reinterpret_cast<uint16_t*>(w0 + ABF_IMG_BYTES) = (uint16_t)(ph >> 16);
+    *reinterpret_cast<uint16_t*>(w0 + ABF_IMG_BYTES + ABF_PIECE_BYTES) = (uint16_t)(pm >> 16);
+    *reinterpret_cast<uint16_t*>(w0 + ABF_IMG_BYTES + 2 * ABF_PIECE_BYTES) = (uint16_t)(pl >> 16);
+    part[0] = fmaf(g0, ln, part[0]);
+    part[1] = fmaf(g1, ln, part[1]);
+  };
+  for (int c = 0; c < ppb; ++c) {
+    const int s0 = blockIdx.x * ppb + c;
+    if (s0 >= hS) break;
+    __syncthreads();
+    part[0] = part[1] = nvalid * lognorm_x;
+    const uint32_t cbase = (uint32_t)((uint64_t)s0 * (uint64_t)dd);
+    if constexpr (EPQ > 0) {
+#pragma unroll
+      for (int q = 0; q < EPQ; ++q) element(tid + NTHR * q, cbase, offs[q], ths[q], lns[q], auxs[q]);
+    } else {
+      for (int e = tid; e < dd; e += NTHR) {
+        int off;
+        float th, ln, aux;
+        factors(e, off, th, ln, aux);
+        element(e, cbase, off, th, ln, aux);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int hsel = 0; hsel < 2; ++hsel) {
+      const unsigned char* img = sb + hsel * ABF_IMG_BYTES;
+      float sq = 0.f;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if (wave + NW * u >= nrt) continue;
+        f32x4 acc[ABF_NT];
+        abf_matmul<FOUR>(acc, XA[u], img, rd_off);
+#pragma unroll
+        for (int tj = 0; tj < ABF_NT; ++tj)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float pv = acc[tj][i];
+            asm volatile("" : "+v"(pv));
+            const float er = ((ok[u] >> (tj * 4 + i)) & 1u) ? xe[u][tj][i] - pv : 0.f;
+            sq = fmaf(er, er, sq);
+          }
+      }
+      part[hsel] = fmaf(-inv2, sq, part[hsel]);
+    }
+    const double t0 = wave_sum_d((double)part[0]), t1 = wave_sum_d((double)part[1]);
+    if (lane == 0) {
+      red[wave] = t0;
+      red[NW + wave] = t1;
+    }
+    __syncthreads();
+    if (tid < 2) {
+      double tot = 0.0;
+      for (int w8 = 0; w8 < NW; ++w8) tot += red[tid * NW + w8];
+      logprobs[(size_t)m * S + s0 + tid * hS] = (float)tot;
+    }
   }
 }
 
@@ -656,10 +824,30 @@ static void joint_lin_logprobs(JointWork* w, const JointLaunch& jl, Key2 carry, 
   float* lp = mode == LIN_MODE_THETA ? jl.logprobs_th : jl.logprobs_z;
   const bool paired = jl.layout == 0 && (jl.S & 1) == 0 && (uint64_t)jl.S * jl.d * jl.d < 0xFFFFFFFFull && jl.N <= 128;
   if (paired) {
-    const int ppb = 4;
+    static const bool lin_f32 = getenv("DIBS_LIN_F32") != nullptr;  // (A/B switch for measurements: the f32-MFMA kernel at 33 <= d <= 64)
+    const bool use_bf = NT <= 4 && jl.d > 32 && !lin_f32;
+    // pairs per block: the block's prologue (x fragments, operand factors, zeroed images) is ~a third of a pair's work; 8 pairs when that
+    // still leaves two full rounds of blocks (config 3: 1 914 -> 1 964 steps/s; 16 pairs: 1 856)
+    const int ppb = (use_bf && (jl.S / 2 / 8) * jl.Mloc >= 1024) ? 8 : 4;
     const size_t ldsp = lin_lds_bytes_pair(jl.d, NT);
     const dim3 grid((jl.S / 2 + ppb - 1) / ppb, jl.Mloc);
     const int epq = (jl.d * jl.d + 255) / 256;
+    if (use_bf) {
+      const int ldsb = 2 * ABF_IMG_BYTES + 128;
+      const int epq8 = (jl.d * jl.d + 511) / 512;
+#define LIN_BF_LAUNCH(EPQ_, FOUR_, NW_)                                                                                                      \
+      {                                                                                                                                      \
+        hipFuncSetAttribute((const void*)k_lin_logprobs_bf<EPQ_, FOUR_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);             \
+        hipLaunchKernelGGL((k_lin_logprobs_bf<EPQ_, FOUR_, NW_>), grid, dim3(64 * NW_), ldsb, jl.stream, w->x, w->mask, jl.theta, jl.scores, \
+                           jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, ppb, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise,  \
+                           jl.mean_edge, jl.sig_edge, w->any_mask);                                                                          \
+      }
+      if (jl.d <= 48) LIN_BF_LAUNCH(5, false, 8)
+      else if (epq8 <= 5) LIN_BF_LAUNCH(5, true, 8)
+      else LIN_BF_LAUNCH(8, true, 8)
+#undef LIN_BF_LAUNCH
+      return;
+    }
 #define LIN_PAIR_LAUNCH(EPQ_)                                                                                                      \
     {                                                                                                                              \
       if (ldsp > 48 * 1024) hipFuncSetAttribute((const void*)k_lin_logprobs_pair<NT, EPQ_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp); \

@@ -362,6 +362,13 @@ def test_sample_api_contract():
     (5, 3, 16, 4, "score", "sf", True, (1, 3)),
     (20, 6, 64, 16, "reparam", "er", True, (1, 4)),
     (50, 4, 128, 32, "reparam", "er", False, (2,)),
+    (33, 3, 32, 8, "score", "sf", True, (1,)),        # 33..64: k_lin_logprobs_bf (split-bf16 operands); 33..48 skips the fourth column tile
+    (40, 3, 32, 8, "reparam", "er", True, (2,)),
+    (48, 3, 32, 8, "score", "er", False, (1,)),
+    (49, 3, 32, 8, "reparam", "sf", True, (1,)),
+    (50, 3, 64, 8, "reparam", "sf", True, (1, 3)),
+    (57, 3, 32, 8, "reparam", "er", False, (2,)),     # 51..64: eight operand elements per thread
+    (64, 3, 32, 8, "score", "er", True, (1,)),
     (100, 3, 32, 8, "reparam", "er", True, (2,)),     # d of BASELINE config 5: largest LDS footprint of the LinG kernels
     (112, 2, 16, 4, "score", "sf", False, (1,)),      # engine maximum
 ])
