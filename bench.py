@@ -143,6 +143,13 @@ def roofline_of(dom, avg_s, cfgname, M, K, eng_counters):
         if c["model"] != "bge":
             roof["flops_per_launch"] = flops / 2.0
             roof["achieved"] = roof["flops_per_launch"] / avg_s / 1e12
+        if dom == "phi_update" and M >= 256:
+            # many particles: the transform runs as one GEMM on the f32 MFMA ([ks | -kr] x [grad ; x], k_phi_gemm): 2 * M * 2M * len flop per
+            # launch, i.e. 4 (not 6) flop per (a, b, i) -- the (x_b - x_a) subtraction became a rank-one row-sum term
+            roof.update(rocprof_kernel="k_phi_gemm", pipe="mfma_f32", flops_per_launch=roof["flops_per_launch"] * 4.0 / 6.0,
+                        achieved=roof["flops_per_launch"] * 4.0 / 6.0 / avg_s / 1e12,
+                        flops_model="4*M*M*len: [kz + kt | -(2/h) kseg] (M x 2M) times [grad ; x] (2M x len) on v_mfma_f32_16x16x4_f32, plus the rank-one "
+                                    "row-sum term (SURVEY 8(d) F_kern regrouped)")
     else:
         roof.update(pipe="valu_f32", achieved=None)
     roof["frac"] = roof["achieved"] / roof["peak"] if roof.get("achieved") else None

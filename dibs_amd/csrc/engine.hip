@@ -241,8 +241,10 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   HIP_OK(dalloc(&e->logprobs_z, Ml * e->S));
   HIP_OK(dalloc(&e->logprobs_th, Ml * e->S));
   HIP_OK(dalloc(&e->pack, (size_t)e->M * e->E));
-  HIP_OK(dalloc(&e->kz, Ml * e->M));
-  if (c.joint) HIP_OK(dalloc(&e->kt, Ml * e->M));
+  // (k_phi_gemm reads whole 128-row x 32-column tiles without bounds checks: rows padded to a multiple of 128, one more tile row of slack)
+  const size_t kpad = (((Ml + 127) / 128) * 128 - Ml) * e->M + 64;
+  HIP_OK(dalloc(&e->kz, Ml * e->M + kpad));
+  if (c.joint) HIP_OK(dalloc(&e->kt, Ml * e->M + kpad));
   HIP_OK(dalloc(&e->phi_z, Ml * e->D));
   HIP_OK(dalloc(&e->phi_th, Ml * e->P));
   HIP_OK(dalloc(&e->counters, (size_t)8));
@@ -865,6 +867,17 @@ static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_s
       // particles per block: as many as keep >= 1024 blocks in flight and the [M][TA] tables within 48 KiB of LDS
       // (headline size: TA = 16 / 8 / 4 measured 20.5 / 18.9 / 26.0 us)
       const long cols = (long)((len + 63) / 64);
+      static const bool phi_valu = getenv("DIBS_PHI_VALU") != nullptr;  // (A/B switch for measurements)
+      if (e->M >= 256 && !phi_valu) {  // many particles: the transform as one GEMM on the matrix pipe (a function of the GLOBAL count only)
+        const int nrb = (e->Mloc + PG_BM - 1) / PG_BM;
+#define PHI_GEMM(J_)                                                                                                                        \
+        hipLaunchKernelGGL(k_phi_gemm<J_>, dim3((unsigned)(8 * nrb * ((cols + 7) / 8))), dim3(256), 0, e->stream, pack, rs.stride, val_off,   \
+                           grad_off, (int)len, e->kz, e->kt, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize,              \
+                           c.optimizer == DIBS_OPT_RMSPROP, (int)cols, nrb, vals_send, (size_t)e->Ev, is_theta ? (size_t)e->D : (size_t)0);
+        if (e->kt) { PHI_GEMM(true) } else { PHI_GEMM(false) }
+#undef PHI_GEMM
+        return;
+      }
       int ta = 16;
       while (ta > 4 && (cols * ((e->Mloc + ta - 1) / ta) < 1024 || (size_t)2 * ta * e->M * 4 > 48 * 1024)) ta >>= 1;
       const size_t lds = ((size_t)2 * ta * e->M + (size_t)4 * ta * 64) * 4;

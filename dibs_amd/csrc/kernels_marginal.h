@@ -227,3 +227,194 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// K8c  the same transform + optimizer step for MANY particles (M >= 256: config 4's 1 024, config 5's 256) as one GEMM on the f32 MFMA:
+//     -M phi_a(i) = sum_b ks[a,b] grad_b(i)  +  sum_b (-kr[a,b]) x_b(i)  +  x_a(i) sum_b kr[a,b],      ks = kz + kt,  kr = (2/h) kseg
+//   i.e. [ks | -kr] (Mloc x 2M) times [grad ; x] (2M x len) plus a rank-one term whose row sums are accumulated from the same LDS tiles.
+//   (k_phi_update evaluates kr (x_b - x_a) per pair on the vector ALU -- three instructions per packed FMA, 847 us at M = 1 024.  The
+//   regrouped sum differs by the rounding of c |x_a| per particle, ~1e-7 of the gradient's own magnitude; PHI within 1e-5 in the tests.)
+// Block = 64 particles x 64 elements, 4 waves (wave w: rows 16 w .. 16 w + 15, 1 x 4 MFMA tiles; 128-particle blocks leave 2.5 blocks per
+// CU at config 4 -- CUs with three set the time: 310 us against [see below] with five 64-particle blocks per CU), k-chunks of 32 particles, the next
+// chunk's tiles prefetched into registers while the current one is multiplied.  The accumulation order of every output element is a
+// function of M only (chunks in ascending b, first the gradient half, then the value half): results do not depend on the rank count.
+// grid = 8 * ceil(Mloc / 64) * ceil(ceil(len / 64) / 8) (one-dimensional, re-indexed XCD-aware inside), block = 256
+// ------------------------------------------------------------------------------------------------
+#define PG_RT 1            // row tiles (of 16 particles) per wave
+#define PG_BM (64 * PG_RT)
+#define PG_BN 64
+#define PG_BK 32
+#define PG_LDA 36  // A tile [a][k]: fragment reads (row = lane % 16, k = lane / 16) two-way (the 64-lane minimum)
+#define PG_LDB 80  // B tile [k][i]: row stride == 16 mod 32
+template <bool JOINT>
+__global__ __launch_bounds__(256) void k_phi_gemm(const float* __restrict__ pack, size_t pack_stride, size_t val_off, size_t grad_off, int len,
+                                                  const float* __restrict__ kz, const float* __restrict__ kt, int seg_is_theta,
+                                                  float* __restrict__ x, float* __restrict__ v, float* __restrict__ phi_out, int m0, int Mloc,
+                                                  int M, float h, float stepsize, int rmsprop, int ncols, int nrb, float* __restrict__ vout,
+                                                  size_t vout_stride, size_t vout_off) {
+  __shared__ __attribute__((aligned(16))) float As[PG_BM * PG_LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[PG_BK * PG_LDB];
+  __shared__ float rs_s[PG_BM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
+  // 1-D grid, XCD-aware (as k_phi_update): linear id L = 8 (nrb c_hi + rb) + c_lo runs the nrb row blocks of column slab c = 8 c_hi + c_lo
+  // on XCD c_lo at the same time -- the slab's [grad ; x] columns (2 M x 256 bytes) come out of that L2 for all but the first reader
+  const int L = blockIdx.x, c_lo = L & 7, tq = L >> 3, rb = tq % nrb, cb = (tq / nrb) * 8 + c_lo;
+  if (cb >= ncols) return;  // (block-uniform)
+  const int i0 = cb * PG_BN, a0 = rb * PG_BM;
+  const float c2h = 2.0f / h;
+  const int nch = (M + PG_BK - 1) / PG_BK;  // chunks per half
+  // loader roles: A tile -- k = tid % 32, rows tid / 32 + 8 j (32 lanes read 128 contiguous bytes of a kernel-matrix row);
+  //               B tile -- rows tid / 16 and tid / 16 + 16, columns 4 (tid % 16) .. + 3
+  // The next chunk's tiles wait in registers while the current one is multiplied out of LDS (a chunk is 64 MFMAs per wave: the loads of
+  // a slab nobody has touched yet come from beyond the L2).
+  const int lk = tid & 31, la = tid >> 5;
+  const int lb = tid >> 4, lc = (tid & 15) * 4;
+  const bool vec_ok = ((pack_stride | val_off | grad_off) & 3) == 0;
+  // (loads are unconditional -- the kernel matrices are allocated with a tile of slack, the rows of `pack` are clamped -- and the raw values
+  //  wait in registers: they are masked / combined only when they are stored to LDS, since any arithmetic on them here would put the wait
+  //  for the loads in front of the MFMAs.  One 32-bit lane offset serves all rows of the A tile: their bases are uniform.)
+  float pz[8 * PG_RT], pt[JOINT ? 8 * PG_RT : 1];
+  float4 pb[2];
+  const bool full_cols = vec_ok && i0 + PG_BN <= len;  // block-uniform
+  const uint32_t aoff = (uint32_t)((a0 + la) * M + lk) * 4u;
+  auto fetch = [&](int ch) {
+    const bool xhalf = ch >= nch;
+    const int b0 = (xhalf ? ch - nch : ch) * PG_BK;
+    const uint32_t vo = aoff + (uint32_t)b0 * 4u;
+#pragma unroll
+    for (int j = 0; j < 8 * PG_RT; ++j) {
+      pz[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(kz + (size_t)j * 8 * M) + vo);
+      if constexpr (JOINT) pt[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(kt + (size_t)j * 8 * M) + vo);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int bb = b0 + lb + 16 * u, bbc = bb < M ? bb : M - 1, i = i0 + lc;
+      const float* src = pack + (size_t)bbc * pack_stride + (xhalf ? val_off : grad_off);
+      if (full_cols) {
+        pb[u] = *reinterpret_cast<const float4*>(src + i);
+      } else {
+        const int last = len - 1;
+        pb[u].x = src[i < last ? i : last];
+        pb[u].y = src[i + 1 < last ? i + 1 : last];
+        pb[u].z = src[i + 2 < last ? i + 2 : last];
+        pb[u].w = src[i + 3 < last ? i + 3 : last];
+      }
+    }
+  };
+  auto stash = [&](int ch) {
+    const bool xhalf = ch >= nch;
+    const int b0 = (xhalf ? ch - nch : ch) * PG_BK;
+    const float sz = xhalf ? (seg_is_theta ? 0.f : -c2h) : 1.0f, st = xhalf ? (seg_is_theta ? -c2h : 0.f) : 1.0f;
+    // (rows beyond Mloc hold garbage: their outputs are never written; columns beyond M must be exact zeros)
+    const bool bok = b0 + lk < M;
+#pragma unroll
+    for (int j = 0; j < 8 * PG_RT; ++j) {
+      const float val = JOINT ? fmaf(st, pt[j], sz * pz[j]) : sz * pz[j];
+      As[(la + 8 * j) * PG_LDA + lk] = bok ? val : 0.f;
+    }
+    if (full_cols && b0 + PG_BK <= M) {  // (block-uniform)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) *reinterpret_cast<float4*>(&Bs[(lb + 16 * u) * PG_LDB + lc]) = pb[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = i0 + lc;
+        float4 q = pb[u];
+        const bool rok = b0 + lb + 16 * u < M;
+        q.x = (rok && i < len) ? q.x : 0.f;
+        q.y = (rok && i + 1 < len) ? q.y : 0.f;
+        q.z = (rok && i + 2 < len) ? q.z : 0.f;
+        q.w = (rok && i + 3 < len) ? q.w : 0.f;
+        *reinterpret_cast<float4*>(&Bs[(lb + 16 * u) * PG_LDB + lc]) = q;
+      }
+    }
+  };
+  f32x4 acc[PG_RT][4];
+#pragma unroll
+  for (int ti = 0; ti < PG_RT; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float rs[PG_RT];  // partial row sums of kr (a function of M only: chunks in ascending order, fixed quarters)
+#pragma unroll
+  for (int ti = 0; ti < PG_RT; ++ti) rs[ti] = 0.f;
+  fetch(0);
+  for (int ch = 0; ch < 2 * nch; ++ch) {
+    __syncthreads();  // (the previous chunk has been read)
+    stash(ch);
+    __syncthreads();
+    if (ch + 1 < 2 * nch) fetch(ch + 1);
+    const float* A = As + (16 * PG_RT * wave + r) * PG_LDA + g;
+    const float* B = Bs + g * PG_LDB + r;
+    // fragments of k-step ks + 1 are read while the MFMAs of k-step ks run
+    float fa[2][PG_RT], fb[2][4];
+#pragma unroll
+    for (int ti = 0; ti < PG_RT; ++ti) fa[0][ti] = A[16 * ti * PG_LDA];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) fb[0][tj] = B[16 * tj];
+#pragma unroll
+    for (int ks = 0; ks < PG_BK / 4; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < PG_BK / 4) {
+#pragma unroll
+        for (int ti = 0; ti < PG_RT; ++ti) fa[nxt][ti] = A[16 * ti * PG_LDA + 4 * (ks + 1)];
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) fb[nxt][tj] = B[4 * (ks + 1) * PG_LDB + 16 * tj];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise sinks each read to its MFMA and waits for it there)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < PG_RT; ++ti)
+          acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][ti], fb[cur][tj], acc[ti][tj], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ch >= nch) {  // row sums of kr: thread t adds the quarter t % 4 (8 columns) of row t / 4 (+ 64) of this chunk
+#pragma unroll
+      for (int ti = 0; ti < PG_RT; ++ti) {
+        const float4 q0 = *reinterpret_cast<const float4*>(&As[((tid >> 2) + 64 * ti) * PG_LDA + 8 * (tid & 3)]);
+        const float4 q1 = *reinterpret_cast<const float4*>(&As[((tid >> 2) + 64 * ti) * PG_LDA + 8 * (tid & 3) + 4]);
+        rs[ti] -= ((q0.x + q0.y) + (q0.z + q0.w)) + ((q1.x + q1.y) + (q1.z + q1.w));
+      }
+    }
+  }
+  // rs_s[row] = sum of the four quarter sums, in quarter order
+#pragma unroll
+  for (int ti = 0; ti < PG_RT; ++ti) {
+    float t = rs[ti];
+    const float t1 = __shfl_xor(t, 1);
+    t = (tid & 1) ? t1 + t : t + t1;        // (same operands, same order on both lanes)
+    const float t2 = __shfl_xor(t, 2);
+    t = (tid & 2) ? t2 + t : t + t2;
+    if ((tid & 3) == 0) rs_s[(tid >> 2) + 64 * ti] = t;
+  }
+  __syncthreads();
+  const float inv_m = 1.0f / (float)M;
+#pragma unroll
+  for (int ti = 0; ti < PG_RT; ++ti)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int al = 16 * PG_RT * wave + 16 * ti + 4 * g + q, a = a0 + al;
+      if (a >= Mloc) continue;
+      const float rsa = rs_s[al];
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) {
+        const int i = i0 + 16 * tj + r;
+        if (i >= len) continue;
+        const float xv = pack[(size_t)(m0 + a) * pack_stride + val_off + i];
+        const float tot = fmaf(rsa, xv, acc[ti][tj][q]);
+        const float phi = -tot * inv_m;
+        const size_t o = (size_t)a * len + i;
+        if (phi_out) phi_out[o] = phi;
+        float xn;
+        if (rmsprop) {
+          const float vv = v[o] * 0.9f + phi * phi * 0.1f;
+          v[o] = vv;
+          xn = xv - stepsize * phi / sqrtf(vv + 1e-8f);
+        } else {
+          xn = xv - stepsize * phi;
+        }
+        x[o] = xn;
+        if (vout) vout[(size_t)a * vout_stride + vout_off + i] = xn;
+      }
+    }
+}

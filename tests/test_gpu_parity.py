@@ -77,6 +77,7 @@ def test_init_particles_matches_oracle(c_oracle64):
     (3, 1, 4, 2, "uniform", (0, 1), "legacy"),      # smallest sensible problem, a single particle
     (20, 5, 32, 8, "er", (2,), "partitionable"),   # jax_threefry_partitionable=True streams (no call pairing)
     (5, 3, 16, 4, "sf", (0, 1), "partitionable"),
+    (6, 272, 8, 4, "er", (0, 2), "legacy"),         # >= 256 particles: the SVGD transform as a GEMM (k_phi_gemm), ragged 128-particle tiles
 ])
 def test_marginal_bge_step_stages(c_oracle64, d, M, S, Sa, prior, steps, layout):
     # (more observations than variables beyond d = 112: with N = 100 < d the matrix R = t I + X^T X is a rank-deficient Gram matrix plus a
@@ -360,6 +361,7 @@ def test_sample_api_contract():
 @pytest.mark.parametrize("d,M,S,Sa,est,prior,interv,steps", [
     (5, 3, 16, 4, "reparam", "er", False, (1, 2)),
     (5, 3, 16, 4, "score", "sf", True, (1, 3)),
+    (6, 260, 8, 4, "reparam", "er", False, (1, 2)),   # >= 256 particles: k_phi_gemm on both segments (z and theta)
     (20, 6, 64, 16, "reparam", "er", True, (1, 4)),
     (50, 4, 128, 32, "reparam", "er", False, (2,)),
     (33, 3, 32, 8, "score", "sf", True, (1,)),        # 33..64: k_lin_logprobs_bf (split-bf16 operands); 33..48 skips the fourth column tile
@@ -753,15 +755,15 @@ def test_large_n_vars_paths(c_oracle64, d):
     assert np.array_equal(z2, zref)
 
 
-@pytest.mark.parametrize("joint,d", [(False, 20), (True, 20), (False, 50), (True, 50)])
-def test_sharded_engines_overlapped_exchange_matches_single_rank(joint, d):
+@pytest.mark.parametrize("joint,d,M", [(False, 20, 16), (True, 20, 16), (False, 50, 16), (True, 50, 16), (True, 6, 264)])
+def test_sharded_engines_overlapped_exchange_matches_single_rank(joint, d, M):
     """The overlapped exchange of dibs_amd.distributed.run_sharded_overlapped on ONE GPU: engines for rank 0..R-1 of R in one process; the
     values [z | theta] are "gathered" (device concat on a SIDE stream, event-ordered exactly as the RCCL path orders them) right after
     the optimizer step, each rank's kernel-matrix slab is computed from them on that side stream behind the gather, and
     only the gradient rows are exchanged between the phases.  Must be bit-identical to the single-rank engine."""
     import torch
     from dibs_amd.engine import Engine
-    M, R, steps = 16, 4, 5
+    R, steps = 4, 5
     data, _, _ = make_data(d, seed=3, joint=joint)
     kw = dict(joint=True, likelihood="lingauss") if joint else {}
     cfg1 = make_config(n_vars=d, n_particles=M, n_observations=100, n_grad_mc_samples=32, n_acyclicity_mc_samples=8, **kw)
@@ -848,15 +850,16 @@ def test_run_sharded_overlapped_single_rank_on_gpu():
     eng.close()
 
 
-@pytest.mark.parametrize("joint,d", [(False, 20), (True, 20), (False, 50), (False, 40), (True, 50)])
-def test_sharded_engines_match_single_rank(joint, d):
+@pytest.mark.parametrize("joint,d,M", [(False, 20, 16), (True, 20, 16), (False, 50, 16), (False, 40, 16), (True, 50, 16),
+                                       (False, 6, 272), (True, 6, 264)])   # >= 256 particles: k_phi_gemm, 68 / 66 particles per rank
+def test_sharded_engines_match_single_rank(joint, d, M):
     """The N > 1 path of bench.py / dibs_amd.distributed on ONE GPU: engines for rank 0..R-1 of R in one process, the
     all-gather replaced by a device-side concat.  Must be bit-identical to the single-rank engine (PRNG rows are global,
     phi sums over b in global order).  d = 50 / 40: both instantiations of the split-bf16 acyclicity kernel, on the ranks with the score
     estimator's blocks riding along in its launch and on its own stream for the single engine."""
     import torch
     from dibs_amd.engine import Engine
-    M, R, steps = 16, 4, 5
+    R, steps = 4, 5
     data, _, _ = make_data(d, seed=3, joint=joint)
     kw = dict(joint=True, likelihood="lingauss") if joint else {}
     cfg1 = make_config(n_vars=d, n_particles=M, n_observations=100, n_grad_mc_samples=32, n_acyclicity_mc_samples=8, **kw)
