@@ -19,6 +19,8 @@ struct JointWork {
   int32_t* mask;   // [N, d]
   float* wsm;      // [Mloc, S] softmax weights scratch
   float* ln_tab;   // [Mloc, d, d] DenseNN: per-particle first-layer prior table (kernels_nn.h), else null
+  float* w1t;      // [Mloc, H, d, d] DenseNN fast path: first-layer weights re-laid out per hidden unit, W1T[h][a][j] = W1[j][a][h]
+  size_t w1t_floats;
   int any_mask;
   double* gram;    // LinearGaussian Gram path (kernels_lin_gram.h): C^(j) [n_gram][d][d], observations not intervened on j
   double* ncnt;    // [d] their count
@@ -771,6 +773,8 @@ int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) {
   w->x = nullptr;
   w->mask = nullptr;
   w->ln_tab = nullptr;
+  w->w1t = nullptr;
+  w->w1t_floats = 0;
   w->any_mask = 0;
   w->nng_scratch = nullptr;
   w->nng_scratch_floats = 0;
@@ -786,6 +790,9 @@ void joint_free(JointWork* w) {
   if (w->mask) hipFree(w->mask);
   if (w->wsm) hipFree(w->wsm);
   if (w->ln_tab) hipFree(w->ln_tab);
+  if (w->w1t) hipFree(w->w1t);
+  w->w1t = nullptr;
+  w->w1t_floats = 0;
   if (w->nng_scratch) hipFree(w->nng_scratch);
   if (w->gram) hipFree(w->gram);
   if (w->ncnt) hipFree(w->ncnt);

@@ -60,6 +60,10 @@ __host__ __device__ inline size_t nn_lds_bytes(int d, int N, int NT, bool grad) 
   if (grad) f += (size_t)4 * g.ldw;
   return ((f * 4 + 15) & ~(size_t)15) + 64 * 8;
 }
+// k_nn_logprobs also keeps the small leaves b1 | W2 | b2 ([d][H] | [d][H] | [d]) behind `red`
+__host__ __device__ inline size_t nn_lds_bytes_logprobs(int d, int N, int NT, int H) {
+  return nn_lds_bytes(d, N, NT, false) + (((size_t)2 * d * H + d) * 4 + 15 & ~(size_t)15);
+}
 
 // pre = X * TW for the row tiles of this wave, results left in registers: acc[u][tj] (row tile ti = wave + 4 u)
 template <int NT, int NU, int NW = 4>
@@ -93,13 +97,18 @@ __device__ __forceinline__ void nn_gemm_x_tw(const float* X, const float* TW, co
 // (nonlinearGaussian.py:264-269).  It does not depend on the sample: one table per particle and step instead of H logN
 // evaluations per element of every sampled graph.   grid = (ceil(d*d / 256), Mloc)
 #ifdef DIBS_TU_NN
-__global__ void k_nn_prior_table(const float* __restrict__ theta, size_t P, float* __restrict__ ln_tab, int d, int H, float sigp) {
+__global__ void k_nn_prior_table(const float* __restrict__ theta, size_t P, float* __restrict__ ln_tab, float* __restrict__ w1t, int d, int H,
+                                 float sigp) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
   if (e >= d * d) return;
   const int a = e / d, j = e - a * d;
   const float* w = theta + (size_t)m * P + ((size_t)j * d + a) * H;
   float t = 0.f;
-  for (int h = 0; h < H; ++h) t += lin_logn(w[h], 0.f, sigp);
+  for (int h = 0; h < H; ++h) {
+    const float wv = w[h];
+    t += lin_logn(wv, 0.f, sigp);
+    if (w1t) w1t[((size_t)m * H + h) * d * d + e] = wv;  // W1T[h][a][j]: what k_nn_logprobs multiplies the sampled graph with, element by element
+  }
   ln_tab[(size_t)m * d * d + e] = t;
 }
 #endif
@@ -138,18 +147,71 @@ __device__ __forceinline__ float nn_build_tw(float* TW, const float* GS, const f
   return prior;
 }
 
+// The same two steps for k_nn_logprobs with the per-particle tables (prior table LN, re-laid-out weights W1T): element index e = a d + j
+// advances by the block size with a carry instead of a division, W1T is read coalesced (W1[j][a][h] itself is a 4 d H byte stride between
+// neighbouring j), and only the d x d interior of the zero-padded operand is rewritten per hidden unit.
+struct NNStep {
+  int da, dj;  // block size = da * d + dj
+};
+__device__ __forceinline__ float nn_build_graph_tab(float* GS, int mode, Key2 key, uint64_t nbits, int s, const uint32_t* thr_m, const float* sc_m,
+                                                    float alpha, float tau, int layout, int tiny, int d, int tid, int a0, int j0, NNStep st,
+                                                    const float* __restrict__ ln_m, int nthr) {
+  const uint64_t dd = (uint64_t)d * d;
+  float prior = 0.f;
+  int a = a0, j = j0;
+  for (int e = tid; e < d * d; e += nthr) {
+    const float gv = lin_sample_g(mode, key, nbits, dd, s, a, j, d, thr_m, sc_m, alpha, tau, layout, tiny);
+    GS[e] = gv;
+    prior = fmaf(gv, ln_m[e], prior);
+    a += st.da;
+    j += st.dj;
+    if (j >= d) {
+      j -= d;
+      ++a;
+    }
+  }
+  return prior;
+}
+// EPT >= ceil(d * d / nthr): all of the thread's table loads are issued before the first product (one trip to the L2 per hidden unit, not one
+// per element)
+template <int EPT>
+__device__ __forceinline__ void nn_build_tw_tab(float* TW, const float* GS, const float* __restrict__ w1t_h, int d, int ldw, int tid, int a0, int j0,
+                                                NNStep st, int nthr) {
+  const int dd = d * d;
+  int a = a0, j = j0;
+  for (int e0 = tid; e0 < dd; e0 += EPT * nthr) {
+    float wv[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int e = e0 + q * nthr;
+      wv[q] = w1t_h[e < dd ? e : dd - 1];
+    }
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int e = e0 + q * nthr;
+      if (e < dd) TW[a * ldw + j] = GS[e] * wv[q];
+      a += st.da;
+      j += st.dj;
+      if (j >= d) {
+        j -= d;
+        ++a;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // log p(theta, D | G_s) for all samples.  grid = (ceil(S / spb), Mloc), block = 256
 // ------------------------------------------------------------------------------------------------
 // NW waves per block (8 when the operands leave room for one block per CU only: two waves per SIMD hide the barriers and
 // LDS / L2 waits of the build -> MFMA -> epilogue cycle of every hidden unit)
-template <int NT, int NW>
+template <int NT, int NW, int ACT = -1>
 __global__ __launch_bounds__(64 * NW) void k_nn_logprobs(const float* __restrict__ x, const int32_t* __restrict__ mask,
                                                      const float* __restrict__ theta, size_t P, const float* __restrict__ scores,
                                                      const uint32_t* __restrict__ thr, float* __restrict__ logprobs, Key2 carry,
                                                      int mode, int m0, int M_global, int d, int N, int S, int spb, float alpha,
                                                      float tau, int layout, int tiny, NNParams np_, int any_mask,
-                                                     const float* __restrict__ ln_tab) {
+                                                     const float* __restrict__ ln_tab, const float* __restrict__ w1t) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const LinGeom g = lin_geom(d, N, NT);
   constexpr int NU = NW >= 8 ? 1 : 8 / NW, NTHR = 64 * NW;  // row tiles per wave (np / 16 <= 8, i.e. N <= 128)
@@ -174,12 +236,44 @@ __global__ __launch_bounds__(64 * NW) void k_nn_logprobs(const float* __restrict
   const float inv2 = 0.5f / np_.obs_noise;
   const float lognorm_x = -0.5f * logf(np_.obs_noise) - 0.918938533204672742f;
   const int nrt = g.np >> 4;
+  const bool tab = ln_tab && w1t && mode != LIN_MODE_GIVEN;  // (block-uniform)
+  // small leaves in LDS (every hidden unit's epilogue reads b1 / W2 of the lane's nodes), validity of the lane's output elements as bits
+  float* LV = reinterpret_cast<float*>(red + 64);
+  for (int e = tid; e < 2 * d * H + d; e += NTHR) {
+    float v = 0.f;
+    if (e < d * H) v = np_.bias ? th_m[off.b1 + e] : 0.f;
+    else if (e < 2 * d * H) v = th_m[off.w2 + (e - d * H)];
+    else v = np_.bias ? th_m[off.b2 + (e - 2 * d * H)] : 0.f;
+    LV[e] = v;
+  }
+  uint32_t okb[NU];
+  float nvalid = 0.f;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    okb[u] = 0u;
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = (wave + NW * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
+        const bool v = n < N && j < d && wave + NW * u < (g.np >> 4) && !(any_mask && mask[(size_t)n * d + j]);
+        okb[u] |= (uint32_t)v << (tj * 4 + r);
+        nvalid += v ? 1.0f : 0.0f;
+      }
+  }
+  static_assert(NT * 4 <= 32, "validity bits of a row tile");
+  const int a0 = tid / d, j0 = tid - a0 * d;
+  const NNStep st{NTHR / d, NTHR % d};
+  if (tab)
+    for (int e = tid; e < nn_tr_rows(g) * g.ldw; e += NTHR) TW[e] = 0.f;  // padding of the operand: written once
   for (int c = 0; c < spb; ++c) {
     const int s = blockIdx.x * spb + c;
     if (s >= S) break;
     __syncthreads();
-    const float pg = nn_build_graph(GS, mode, key, nbits, s, thr + (size_t)m * dd, scores ? scores + (size_t)m * dd : nullptr, alpha,
-                                    tau, layout, tiny, d, tid, ln_tab ? ln_tab + (size_t)m * dd : nullptr, NTHR);
+    const float pg = tab ? nn_build_graph_tab(GS, mode, key, nbits, s, thr + (size_t)m * dd, scores ? scores + (size_t)m * dd : nullptr, alpha, tau,
+                                              layout, tiny, d, tid, a0, j0, st, ln_tab + (size_t)m * dd, NTHR)
+                         : nn_build_graph(GS, mode, key, nbits, s, thr + (size_t)m * dd, scores ? scores + (size_t)m * dd : nullptr, alpha,
+                                          tau, layout, tiny, d, tid, ln_tab ? ln_tab + (size_t)m * dd : nullptr, NTHR);
     float part = prior_rest + pg;
     f32x4 macc[NU][NT];
 #pragma unroll
@@ -188,37 +282,44 @@ __global__ __launch_bounds__(64 * NW) void k_nn_logprobs(const float* __restrict
       for (int tj = 0; tj < NT; ++tj) macc[u][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int h = 0; h < H; ++h) {
       __syncthreads();
-      if (ln_tab) nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid, NTHR);
+      if (tab) nn_build_tw_tab<(NW >= 16 ? 13 : 8)>(TW, GS, w1t + ((size_t)m * H + h) * dd, d, g.ldw, tid, a0, j0, st, NTHR);
+      else if (ln_tab) nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid, NTHR);
       else part += nn_build_tw<true>(TW, GS, th_m, h, H, np_.sig_param, g, tid, NTHR);
       __syncthreads();
       f32x4 acc[NU][NT];
       nn_gemm_x_tw<NT, NU, NW>(X, TW, g, lane, wave, acc);
+      // ACT >= 0: the activation is a compile-time constant (relu, the reference's default); a run-time switch per element compiles to a
+      // branch ladder of 45 instructions per element -- 44 k of the kernel's 67 k wave-instructions per sample at config 5
 #pragma unroll
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj) {
           const int j = tj * 16 + (lane & 15);
           if (j < d && wave + NW * u < nrt) {
-            const float b1 = np_.bias ? th_m[off.b1 + (size_t)j * H + h] : 0.f;
-            const float w2 = th_m[off.w2 + (size_t)j * H + h];
+            const float b1 = LV[j * H + h];
+            const float w2 = LV[d * H + j * H + h];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) macc[u][tj][r] += w2 * nn_act(np_.act, acc[u][tj][r] + b1);
+            for (int r = 0; r < 4; ++r) macc[u][tj][r] += w2 * nn_act(ACT >= 0 ? ACT : np_.act, acc[u][tj][r] + b1);
           }
         }
     }
+    float sq = 0.f;
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
-      for (int tj = 0; tj < NT; ++tj)
+      for (int tj = 0; tj < NT; ++tj) {
+        const int j = tj * 16 + (lane & 15);
+        const float b2 = j < d ? LV[2 * d * H + j] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int n = (wave + NW * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
-          if (n < N && j < d && wave + NW * u < nrt && !(any_mask && mask[(size_t)n * d + j])) {
-            const float mean = macc[u][tj][r] + (np_.bias ? th_m[off.b2 + j] : 0.f);
-            const float e = X[n * g.ldx + j] - mean;
-            part += lognorm_x - inv2 * e * e;
+          const int n = (wave + NW * u) * 16 + (lane >> 4) * 4 + r;
+          if ((okb[u] >> (tj * 4 + r)) & 1u) {
+            const float e = X[n * g.ldx + j] - (macc[u][tj][r] + b2);
+            sq = fmaf(e, e, sq);
           }
         }
+      }
+    part += nvalid * lognorm_x - inv2 * sq;
     const double tot = wave_sum_d((double)part);
     __syncthreads();
     if (lane == 0) red[wave] = tot;
@@ -499,24 +600,36 @@ void joint_nn_init_theta(float* theta, size_t P, Key2 key, int m0, int Mloc, int
 
 template <int NT>
 static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P) {
-  const int spb = 2;
-  const size_t lds1 = nn_lds_bytes(jl.d, jl.N, NT, false), lds2 = nn_lds_bytes(jl.d, jl.N, NT, true);
+  // samples per block: the block's prologue (x and the small leaves into LDS, validity bits) is shared by them; 4 while that leaves at least
+  // four rounds of blocks (config 5: spb 2 / 4 / 8 -> 51.2 / 53.0 / 53.1 steps/s)
+  static const int spb_env = getenv("DIBS_NN_SPB") ? atoi(getenv("DIBS_NN_SPB")) : 0;
+  const int spb = spb_env > 0 ? spb_env : ((jl.S / 4) * jl.Mloc >= 1024 ? 4 : 2);
+  const size_t lds1 = nn_lds_bytes_logprobs(jl.d, jl.N, NT, np_.H), lds2 = nn_lds_bytes(jl.d, jl.N, NT, true);
   if (lds2 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_grad<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
   float* lp = mode == LIN_MODE_THETA ? jl.logprobs_th : jl.logprobs_z;
-  if (mode == LIN_MODE_THETA && w->ln_tab)  // theta is the same for both estimators of a step: the table is built once (theta runs first)
-    hipLaunchKernelGGL(k_nn_prior_table, dim3((jl.d * jl.d + 255) / 256, jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->ln_tab, jl.d,
-                       np_.H, np_.sig_param);
-  if (lds1 > 80 * 1024) {  // one block per CU: run it with 8 waves
-    if (lds1 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_logprobs<NT, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    hipLaunchKernelGGL((k_nn_logprobs<NT, 16>), dim3((jl.S + spb - 1) / spb, jl.Mloc), dim3(1024), lds1, jl.stream, w->x, w->mask, jl.theta, P,
-                       jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, spb, jl.alpha, jl.tau, jl.layout, jl.tiny, np_,
-                       w->any_mask, w->ln_tab);
-  } else {
-    if (lds1 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_logprobs<NT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    hipLaunchKernelGGL((k_nn_logprobs<NT, 4>), dim3((jl.S + spb - 1) / spb, jl.Mloc), dim3(256), lds1, jl.stream, w->x, w->mask, jl.theta, P,
-                       jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, spb, jl.alpha, jl.tau, jl.layout, jl.tiny, np_,
-                       w->any_mask, w->ln_tab);
+  const size_t w1t_need = (size_t)jl.Mloc * np_.H * jl.d * jl.d;
+  if (w->w1t_floats < w1t_need) {  // (first launch; optional: without it the kernel reads W1 in place)
+    if (w->w1t) hipFree(w->w1t);
+    w->w1t = nullptr;
+    w->w1t_floats = hipMalloc((void**)&w->w1t, w1t_need * 4) == hipSuccess ? w1t_need : 0;
+    if (!w->w1t_floats) w->w1t = nullptr;
   }
+  if (mode == LIN_MODE_THETA && w->ln_tab)  // theta is the same for both estimators of a step: the tables are built once (theta runs first)
+    hipLaunchKernelGGL(k_nn_prior_table, dim3((jl.d * jl.d + 255) / 256, jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->ln_tab, w->w1t, jl.d,
+                       np_.H, np_.sig_param);
+#define NN_LP_LAUNCH(NW_, ACT_)                                                                                                             \
+  {                                                                                                                                         \
+    if (lds1 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_logprobs<NT, NW_, ACT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); \
+    hipLaunchKernelGGL((k_nn_logprobs<NT, NW_, ACT_>), dim3((jl.S + spb - 1) / spb, jl.Mloc), dim3(64 * NW_), lds1, jl.stream, w->x, w->mask,   \
+                       jl.theta, P, jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, spb, jl.alpha, jl.tau, jl.layout,    \
+                       jl.tiny, np_, w->any_mask, w->ln_tab, w->w1t);                                                                       \
+  }
+  if (lds1 > 80 * 1024) {  // one block per CU: run it with 16 waves
+    if (np_.act == 0) NN_LP_LAUNCH(16, 0) else NN_LP_LAUNCH(16, -1)
+  } else {
+    if (np_.act == 0) NN_LP_LAUNCH(4, 0) else NN_LP_LAUNCH(4, -1)
+  }
+#undef NN_LP_LAUNCH
   float* out = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off : jl.w_lik;
   const size_t ostride = mode == LIN_MODE_THETA ? jl.pack_stride : (size_t)jl.d * jl.d;
   float* tcopy = (mode == LIN_MODE_THETA && jl.copy_theta) ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr;
@@ -586,11 +699,11 @@ int joint_nn_dispatch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode,
 template <int NT>
 static void launch_nn_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N,
                             const NNParams& np_, size_t P, hipStream_t stream) {
-  const size_t lds = nn_lds_bytes(d, N, NT, false);
+  const size_t lds = nn_lds_bytes_logprobs(d, N, NT, np_.H);
   if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_logprobs<NT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((k_nn_logprobs<NT, 4>), dim3(1, n), dim3(256), lds, stream, jw.x, jw.mask, theta, P, (const float*)nullptr,
                      reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, N, 1, 1, 0.f, 1.f, 0, 0, np_,
-                     jw.any_mask, (const float*)nullptr);
+                     jw.any_mask, (const float*)nullptr, (const float*)nullptr);
 }
 int joint_nn_score_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N, const NNParams& np_,
                          size_t P, hipStream_t stream) {
