@@ -67,8 +67,9 @@ __host__ __device__ inline size_t nn_lds_bytes_logprobs(int d, int N, int NT, in
 
 // pre = X * TW for the row tiles of this wave, results left in registers: acc[u][tj] (row tile ti = wave + 4 u)
 template <int NT, int NU, int NW = 4>
-__device__ __forceinline__ void nn_gemm_x_tw(const float* X, const float* TW, const LinGeom g, int lane, int wave, f32x4 (&acc)[NU][NT]) {
-  const int nrt = g.np >> 4;
+__device__ __forceinline__ void nn_gemm_x_tw(const float* X, const float* TW, const LinGeom g, int lane, int wave, f32x4 (&acc)[NU][NT],
+                                             int ldw_tw = 0) {
+  const int nrt = g.np >> 4, ldw = ldw_tw ? ldw_tw : g.ldw;
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int ti = wave + NW * u;
@@ -76,11 +77,11 @@ __device__ __forceinline__ void nn_gemm_x_tw(const float* X, const float* TW, co
     for (int tj = 0; tj < NT; ++tj) acc[u][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (ti >= nrt) continue;
     const int ap = (ti * 16 + (lane & 15)) * g.ldx + (lane >> 4);
-    const int bq = (lane >> 4) * g.ldw + (lane & 15);
+    const int bq = (lane >> 4) * ldw + (lane & 15);
     for (int k0 = 0; k0 < g.kp; k0 += 4) {
       const float a = X[ap + k0];
 #pragma unroll
-      for (int tj = 0; tj < NT; ++tj) acc[u][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, TW[bq + k0 * g.ldw + tj * 16], acc[u][tj], 0, 0, 0);
+      for (int tj = 0; tj < NT; ++tj) acc[u][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, TW[bq + k0 * ldw + tj * 16], acc[u][tj], 0, 0, 0);
     }
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj)
@@ -153,14 +154,44 @@ __device__ __forceinline__ float nn_build_tw(float* TW, const float* GS, const f
 struct NNStep {
   int da, dj;  // block size = da * d + dj
 };
-__device__ __forceinline__ float nn_build_graph_tab(float* GS, int mode, Key2 key, uint64_t nbits, int s, const uint32_t* thr_m, const float* sc_m,
-                                                    float alpha, float tau, int layout, int tiny, int d, int tid, int a0, int j0, NNStep st,
-                                                    const float* __restrict__ ln_m, int nthr) {
+// FAST: legacy PRNG layout with an even number of samples and S d d < 2^32 -- element e of sample s is word (s < S/2 ? 0 : 1) of the Threefry
+// call on counters (c, c + S d d / 2), c = (s mod S/2) d d + e: 32-bit counters, key schedule hoisted (threefry2x32_uk), and for tau = 1
+// sigmoid(eps + a) = u / (u + (1 - u) exp(-a)) on v_rcp_f32.  (The generic path -- 64-bit element index, layout switch, key schedule and an
+// IEEE division per element -- is 320 vector instructions per element, 50 k of the kernel's 66 k wave-instructions per sample at config 5.)
+template <bool FAST>
+__device__ __forceinline__ float nn_build_graph_tab(float* GS, int mode, Key2 key, const TfKeys& tk, uint64_t nbits, int s, int S, const uint32_t* thr_m,
+                                                    const float* sc_m, float alpha, float tau, int layout, int tiny, int d, int tid, int a0, int j0,
+                                                    NNStep st, const float* __restrict__ ln_m, int nthr) {
   const uint64_t dd = (uint64_t)d * d;
   float prior = 0.f;
   int a = a0, j = j0;
+  const int hS = S >> 1;
+  const bool hi = s >= hS;
+  const uint32_t cbase = (uint32_t)(hi ? s - hS : s) * (uint32_t)dd, half = (uint32_t)(nbits >> 1);
+  const float ulo = tiny ? 1.17549435e-38f : 1.1920929e-07f;
   for (int e = tid; e < d * d; e += nthr) {
-    const float gv = lin_sample_g(mode, key, nbits, dd, s, a, j, d, thr_m, sc_m, alpha, tau, layout, tiny);
+    float gv;
+    if constexpr (FAST) {
+      gv = 0.f;
+      if (a != j) {
+        uint32_t y0, y1;
+        threefry2x32_uk(tk, cbase + (uint32_t)e, cbase + (uint32_t)e + half, y0, y1);
+        const uint32_t y = hi ? y1 : y0;
+        if (mode == LIN_MODE_Z_REPARAM) {
+          const float as = alpha * sc_m[e];
+          if (tau == 1.0f) {
+            const float u = rng_uniform(y, ulo, 1.0f);
+            gv = u * __builtin_amdgcn_rcpf(fmaf(1.0f - u, expf(-as), u));
+          } else {
+            gv = 1.0f / (1.0f + expf(-tau * (rng_logistic(y, tiny) + as)));
+          }
+        } else {
+          gv = (y >> 9) < thr_m[e] ? 1.0f : 0.0f;
+        }
+      }
+    } else {
+      gv = lin_sample_g(mode, key, nbits, dd, s, a, j, d, thr_m, sc_m, alpha, tau, layout, tiny);
+    }
     GS[e] = gv;
     prior = fmaf(gv, ln_m[e], prior);
     a += st.da;
@@ -237,6 +268,8 @@ __global__ __launch_bounds__(64 * NW) void k_nn_logprobs(const float* __restrict
   const float lognorm_x = -0.5f * logf(np_.obs_noise) - 0.918938533204672742f;
   const int nrt = g.np >> 4;
   const bool tab = ln_tab && w1t && mode != LIN_MODE_GIVEN;  // (block-uniform)
+  const bool fastg = layout == 0 && (S & 1) == 0 && (uint64_t)S * dd < 0xFFFFFFFFull;
+  const TfKeys tk = tf_keys(key);
   // small leaves in LDS (every hidden unit's epilogue reads b1 / W2 of the lane's nodes), validity of the lane's output elements as bits
   float* LV = reinterpret_cast<float*>(red + 64);
   for (int e = tid; e < 2 * d * H + d; e += NTHR) {
@@ -264,14 +297,19 @@ __global__ __launch_bounds__(64 * NW) void k_nn_logprobs(const float* __restrict
   static_assert(NT * 4 <= 32, "validity bits of a row tile");
   const int a0 = tid / d, j0 = tid - a0 * d;
   const NNStep st{NTHR / d, NTHR % d};
+  // table path: operand rows of 16 NT (+ 16 for even NT) floats, i.e. == 16 mod 32 -- the four k-rows of a B-fragment read then cover all
+  // 32 banks (with the d + 2 stride of the shared geometry 39 % of the kernel's LDS cycles were bank conflicts)
+  const int ldw_tw = (tab && g.kp * lin_ldw2<NT>() <= nn_tr_rows(g) * g.ldw) ? lin_ldw2<NT>() : g.ldw;  // (even NT: only if it fits the region)
   if (tab)
-    for (int e = tid; e < nn_tr_rows(g) * g.ldw; e += NTHR) TW[e] = 0.f;  // padding of the operand: written once
+    for (int e = tid; e < g.kp * ldw_tw; e += NTHR) TW[e] = 0.f;  // padding of the operand: written once
   for (int c = 0; c < spb; ++c) {
     const int s = blockIdx.x * spb + c;
     if (s >= S) break;
     __syncthreads();
-    const float pg = tab ? nn_build_graph_tab(GS, mode, key, nbits, s, thr + (size_t)m * dd, scores ? scores + (size_t)m * dd : nullptr, alpha, tau,
-                                              layout, tiny, d, tid, a0, j0, st, ln_tab + (size_t)m * dd, NTHR)
+    const float pg = tab ? (fastg ? nn_build_graph_tab<true>(GS, mode, key, tk, nbits, s, S, thr + (size_t)m * dd, scores ? scores + (size_t)m * dd : nullptr,
+                                                             alpha, tau, layout, tiny, d, tid, a0, j0, st, ln_tab + (size_t)m * dd, NTHR)
+                                  : nn_build_graph_tab<false>(GS, mode, key, tk, nbits, s, S, thr + (size_t)m * dd, scores ? scores + (size_t)m * dd : nullptr,
+                                                              alpha, tau, layout, tiny, d, tid, a0, j0, st, ln_tab + (size_t)m * dd, NTHR))
                          : nn_build_graph(GS, mode, key, nbits, s, thr + (size_t)m * dd, scores ? scores + (size_t)m * dd : nullptr, alpha,
                                           tau, layout, tiny, d, tid, ln_tab ? ln_tab + (size_t)m * dd : nullptr, NTHR);
     float part = prior_rest + pg;
@@ -282,12 +320,12 @@ __global__ __launch_bounds__(64 * NW) void k_nn_logprobs(const float* __restrict
       for (int tj = 0; tj < NT; ++tj) macc[u][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int h = 0; h < H; ++h) {
       __syncthreads();
-      if (tab) nn_build_tw_tab<(NW >= 16 ? 13 : 8)>(TW, GS, w1t + ((size_t)m * H + h) * dd, d, g.ldw, tid, a0, j0, st, NTHR);
+      if (tab) nn_build_tw_tab<(NW >= 16 ? 13 : 8)>(TW, GS, w1t + ((size_t)m * H + h) * dd, d, ldw_tw, tid, a0, j0, st, NTHR);
       else if (ln_tab) nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid, NTHR);
       else part += nn_build_tw<true>(TW, GS, th_m, h, H, np_.sig_param, g, tid, NTHR);
       __syncthreads();
       f32x4 acc[NU][NT];
-      nn_gemm_x_tw<NT, NU, NW>(X, TW, g, lane, wave, acc);
+      nn_gemm_x_tw<NT, NU, NW>(X, TW, g, lane, wave, acc, ldw_tw);
       // ACT >= 0: the activation is a compile-time constant (relu, the reference's default); a run-time switch per element compiles to a
       // branch ladder of 45 instructions per element -- 44 k of the kernel's 67 k wave-instructions per sample at config 5
 #pragma unroll
