@@ -206,10 +206,9 @@ __device__ __forceinline__ float nn_build_graph_tab(float* GS, int mode, Key2 ke
 // EPT >= ceil(d * d / nthr): all of the thread's table loads are issued before the first product (one trip to the L2 per hidden unit, not one
 // per element)
 template <int EPT>
-__device__ __forceinline__ void nn_build_tw_tab(float* TW, const float* GS, const float* __restrict__ w1t_h, int d, int ldw, int tid, int a0, int j0,
-                                                NNStep st, int nthr) {
-  const int dd = d * d;
-  int a = a0, j = j0;
+__device__ __forceinline__ void nn_build_tw_tab(float* TW, const float* GS, const float* __restrict__ w1t_h, int d, int ldw, int tid, int nthr) {
+  const int dd = d * d, pad = ldw - d;
+  const float inv_d = 1.0f / (float)d;
   for (int e0 = tid; e0 < dd; e0 += EPT * nthr) {
     float wv[EPT];
 #pragma unroll
@@ -220,13 +219,8 @@ __device__ __forceinline__ void nn_build_tw_tab(float* TW, const float* GS, cons
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
       const int e = e0 + q * nthr;
-      if (e < dd) TW[a * ldw + j] = GS[e] * wv[q];
-      a += st.da;
-      j += st.dj;
-      if (j >= d) {
-        j -= d;
-        ++a;
-      }
+      const int a = (int)(((float)e + 0.5f) * inv_d);  // e / d, exact for e < 2^20 (a carry chain over (a, j) is 25 instructions per element)
+      if (e < dd) TW[e + a * pad] = GS[e] * wv[q];
     }
   }
 }
@@ -320,7 +314,7 @@ __global__ __launch_bounds__(64 * NW) void k_nn_logprobs(const float* __restrict
       for (int tj = 0; tj < NT; ++tj) macc[u][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int h = 0; h < H; ++h) {
       __syncthreads();
-      if (tab) nn_build_tw_tab<(NW >= 16 ? 13 : 8)>(TW, GS, w1t + ((size_t)m * H + h) * dd, d, ldw_tw, tid, a0, j0, st, NTHR);
+      if (tab) nn_build_tw_tab<(NW >= 16 ? 13 : 8)>(TW, GS, w1t + ((size_t)m * H + h) * dd, d, ldw_tw, tid, NTHR);
       else if (ln_tab) nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid, NTHR);
       else part += nn_build_tw<true>(TW, GS, th_m, h, H, np_.sig_param, g, tid, NTHR);
       __syncthreads();
