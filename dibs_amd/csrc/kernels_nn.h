@@ -371,7 +371,7 @@ __global__ __launch_bounds__(64 * NW) void k_nn_logprobs(const float* __restrict
 //   mode Z_SCORE   : W = scale * alpha (sum_s w_s G_s - P), off-diagonal           -> w_lik
 // grid = Mloc, block = 256.  Accumulation goes to global memory; every output element is owned by one thread.
 // ------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int ACT = -1>   // ACT >= 0: compile-time activation (relu), as in k_nn_logprobs
 __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, const int32_t* __restrict__ mask,
                                                  const float* __restrict__ theta, size_t P, const float* __restrict__ scores,
                                                  const uint32_t* __restrict__ thr, const float* __restrict__ logprobs,
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
             const float b1 = np_.bias ? th_m[off.b1 + (size_t)j * H + h] : 0.f;
             const float w2 = th_m[off.w2 + (size_t)j * H + h];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) macc[u][tj][r] += w2 * nn_act(np_.act, acc[u][tj][r] + b1);
+            for (int r = 0; r < 4; ++r) macc[u][tj][r] += w2 * nn_act(ACT >= 0 ? ACT : np_.act, acc[u][tj][r] + b1);
           }
         }
     }
@@ -512,9 +512,9 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
             const int n = (wave + 4 * u) * 16 + (lane >> 4) * 4 + r;
             if (n < g.np && wave + 4 * u < nrt) {
               const float pre = acc[u][tj][r] + b1;
-              const float hv = nn_act(np_.act, pre);
+              const float hv = nn_act(ACT >= 0 ? ACT : np_.act, pre);
               const float dm = macc[u][tj][r];
-              RS[n * g.ldw + j] = dm * w2 * nn_dact(np_.act, pre, hv);  // dpre
+              RS[n * g.ldw + j] = dm * w2 * nn_dact(ACT >= 0 ? ACT : np_.act, pre, hv);  // dpre
               t2 += dm * hv;                                              // for d/dW2
             }
           }
@@ -637,7 +637,10 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
   static const int spb_env = getenv("DIBS_NN_SPB") ? atoi(getenv("DIBS_NN_SPB")) : 0;
   const int spb = spb_env > 0 ? spb_env : ((jl.S / 4) * jl.Mloc >= 1024 ? 4 : 2);
   const size_t lds1 = nn_lds_bytes_logprobs(jl.d, jl.N, NT, np_.H), lds2 = nn_lds_bytes(jl.d, jl.N, NT, true);
-  if (lds2 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_grad<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+  if (lds2 > 48 * 1024) {
+    hipFuncSetAttribute((const void*)k_nn_grad<NT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipFuncSetAttribute((const void*)k_nn_grad<NT, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+  }
   float* lp = mode == LIN_MODE_THETA ? jl.logprobs_th : jl.logprobs_z;
   const size_t w1t_need = (size_t)jl.Mloc * np_.H * jl.d * jl.d;
   if (w->w1t_floats < w1t_need) {  // (first launch; optional: without it the kernel reads W1 in place)
@@ -665,9 +668,15 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
   float* out = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off : jl.w_lik;
   const size_t ostride = mode == LIN_MODE_THETA ? jl.pack_stride : (size_t)jl.d * jl.d;
   float* tcopy = (mode == LIN_MODE_THETA && jl.copy_theta) ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr;
-  hipLaunchKernelGGL(k_nn_grad<NT>, dim3(jl.Mloc), dim3(256), lds2, jl.stream, w->x, w->mask, jl.theta, P, jl.scores, jl.thr, lp, out,
+  if (np_.act == 0) {
+    hipLaunchKernelGGL((k_nn_grad<NT, 0>), dim3(jl.Mloc), dim3(256), lds2, jl.stream, w->x, w->mask, jl.theta, P, jl.scores, jl.thr, lp, out,
                      ostride, tcopy, jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode, jl.m0,
                      jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask);
+  } else {
+    hipLaunchKernelGGL((k_nn_grad<NT, -1>), dim3(jl.Mloc), dim3(256), lds2, jl.stream, w->x, w->mask, jl.theta, P, jl.scores, jl.thr, lp, out,
+                     ostride, tcopy, jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode, jl.m0,
+                     jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask);
+  }
 }
 
 bool joint_nn_fast_path(int d, int N, const NNParams& np_) {

@@ -202,7 +202,10 @@ def main():
                 # (a net for gross errors in trials whose Z is not compared: the suite holds 2e-5 on ordinary states; a state 30 steps into a
                 #  badly scaled run -- phi ~ 1e10 -- showed 2.5e-4 with phi itself at 3e-6)
                 stage["LOGPROBS_Z"] = (float(np.abs(lp_d - lp_o)[sel].max() / max(np.abs(lp_o[sel]).max(), 1e-300)), 1e-3)
-            if (same_s is None or same_s.all()) and np.isfinite(dbg["w_lik"]).all() and np.abs(dbg["w_lik"]).max() > 0:
+            # (log-scores beyond 2^23: their float32 spacing exceeds 1, so the softmax weights over the samples are not determined in float32 --
+            #  seed 911 trial 89: gradient descent blown up to |scores| ~ 1e6, log-scores ~ 1.5e9 equal to 1.4e-7, W_LIK 10 % apart)
+            lp_resolved = np.isfinite(lp_o).all() and np.abs(lp_o).max() < 8.0e6
+            if lp_resolved and (same_s is None or same_s.all()) and np.isfinite(dbg["w_lik"]).all() and np.abs(dbg["w_lik"]).max() > 0:
                 # (softmax-weighted: a near-tie of two log-scores moves single entries by O(alpha); the RMS over the matrix catches a wrong kernel)
                 wd, wo = eng.read("W_LIK").astype(np.float64).ravel(), np.asarray(dbg["w_lik"], np.float64).ravel()
                 # (saturated graphs: every sample equals P, so W_lik = alpha (sum_s w_s - 1) P is rounding noise around 0 -- 1e-16 alpha in the
