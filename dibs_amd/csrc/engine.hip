@@ -74,6 +74,7 @@ struct dibs_engine {
   // work
   float* w_tot;     // [Mloc][d][d] total score-space gradient when a particle's W, U, V do not fit in one block's LDS (kernels_tail.h)
   float* acyc_big;  // n_vars > 112: buffers of the global-memory matrix powers (kernels_acyc_big.h)
+  float* eas;       // [Mloc][d][d] exp(-alpha s) of this step (k_edge_scores -> k_acyc_hf); n_vars in 33 .. 64 only
   float *scores, *probs, *w_lik, *acyc_part, *w_acyc, *logprobs_z, *logprobs_th, *pack, *kz, *kt, *phi_z, *phi_th;
   uint32_t* thr;
   uint64_t* masks;
@@ -220,6 +221,7 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   HIP_OK(dalloc(&e->baseline2, Ml));
   HIP_OK(dalloc(&e->scores, Ml * dd));
   HIP_OK(dalloc(&e->probs, Ml * dd));
+  if (e->d > 32 && e->d <= 64) HIP_OK(dalloc(&e->eas, Ml * dd));
   HIP_OK(dalloc(&e->thr, Ml * dd));
   HIP_OK(dalloc(&e->w_lik, Ml * dd));
   if (e->d > 112) {
@@ -348,7 +350,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (!e) return 0;
   hipSetDevice(e->cfg.device_id);
   if (e->stream) hipStreamSynchronize(e->stream);
-  void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
+  void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->eas, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
                   e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot};
   for (void* p : ptrs)
@@ -680,8 +682,8 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
 #define EDGE_LAUNCH(MAXT_)                                                                                                             \
     {                                                                                                                                    \
       allow_lds(k_edge_scores<MAXT_>, lds);                                                                                              \
-      hipLaunchKernelGGL(k_edge_scores<MAXT_>, dim3(e->Mloc, nby), dim3(256), lds, e->stream, e->z, e->scores, e->thr, e->probs, alpha,  \
-                         e->d, e->k, e->dpad, e->ldk, e->edge_kc);                                                                       \
+      hipLaunchKernelGGL(k_edge_scores<MAXT_>, dim3(e->Mloc, nby), dim3(256), lds, e->stream, e->z, e->scores, e->thr, e->probs, e->eas,  \
+                         alpha, e->d, e->k, e->dpad, e->ldk, e->edge_kc);                                                                       \
     }
     if (per_wave <= 1) EDGE_LAUNCH(1) else if (per_wave <= 4) EDGE_LAUNCH(4) else EDGE_LAUNCH(EDGE_MAXT)
 #undef EDGE_LAUNCH
@@ -697,7 +699,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
     hipEventRecord(e->ev_fork, e->stream);
     hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
     const AcycLaunch al{e->stream2, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
-                        e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr};
+                        e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr, e->eas};
     acyc_power_timed(e, al, e->stream2);
     {
       KTimer tm(e, DIBS_K_ACYC_REDUCE, e->stream2);
@@ -790,7 +792,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
     hipStreamWaitEvent(e->stream, e->ev_join, 0);  // (covers the kernel matrices: they precede the acyclicity kernel on that stream)
   } else {
     const AcycLaunch al{e->stream, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
-                        e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr};
+                        e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr, e->eas};
     acyc_power_timed(e, al, e->stream);
     {
       KTimer tm(e, DIBS_K_ACYC_REDUCE);

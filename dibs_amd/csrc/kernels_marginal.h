@@ -37,8 +37,8 @@ __global__ void k_init_theta_lin(float* __restrict__ th, Key2 key, uint64_t n_to
 #define EDGE_MAXT 12
 template <int MAXT>   // accumulator sets per wave: 1 (up to 16 tiles per particle: n_vars <= 64 with four blocks), 4, EDGE_MAXT
 __global__ __launch_bounds__(256) void k_edge_scores(const float* __restrict__ z, float* __restrict__ scores,
-                                                     uint32_t* __restrict__ thr, float* __restrict__ probs, float alpha,
-                                                     int d, int k, int dpad, int ldk, int kc) {
+                                                     uint32_t* __restrict__ thr, float* __restrict__ probs, float* __restrict__ eas,
+                                                     float alpha, int d, int k, int dpad, int ldk, int kc) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Us = smem;
   float* Vs = smem + (size_t)dpad * ldk;
@@ -87,7 +87,11 @@ __global__ __launch_bounds__(256) void k_edge_scores(const float* __restrict__ z
         const float s = acc[u][r];
         const size_t o = ((size_t)m * d + row) * d + col;
         scores[o] = s;
-        const float pf = (float)sigmoid_d((double)__fmul_rn(alpha, s));
+        // (eas: exp(-alpha s) as float, the factor of the Gumbel-soft graphs u / (u + (1 - u) exp(-alpha s)) that is common to all
+        //  acyclicity chains of the particle -- k_acyc_hf would evaluate it once per pair of chains)
+        const double ex = exp(-(double)__fmul_rn(alpha, s));
+        const float pf = (float)(1.0 / (1.0 + ex));
+        if (eas) eas[o] = (float)ex;
         thr[o] = row == col ? 0u : (uint32_t)ceilf(pf * 8388608.0f);
         probs[o] = row == col ? 0.f : pf;  // edge_probs (dibs.py:168-184), reused by the prior / estimator kernels
       }

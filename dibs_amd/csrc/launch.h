@@ -30,6 +30,7 @@ struct AcycLaunch {
   float alpha, tau;
   int layout, tiny;
   hipEvent_t ev_start, ev_stop;  // profiling: kernel-level start / stop time stamps of the matrix-power kernel (see acyc_power_takes_events); else null
+  const float* eas;       // [Mloc][d*d] exp(-alpha scores) (k_edge_scores), read by k_acyc_hf when tau == 1; may be null (then it is evaluated in place)
 };
 // true: acyc_launch_power is ONE kernel and stamps a.ev_start / a.ev_stop around it (hipExtLaunchKernelGGL: the kernel's own start and
 // end as the profiler sees them, without the dispatch latency an event pair recorded around the launch includes)

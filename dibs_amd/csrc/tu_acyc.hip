@@ -3,6 +3,7 @@
 #include "launch.h"
 #include "kernels_acyc.h"
 #include "kernels_acyc_bf16.h"
+#include "kernels_acyc_f16.h"
 #include "kernels_acyc_big.h"
 #include <stdlib.h>
 #include <hip/hip_ext.h>
@@ -87,20 +88,35 @@ void acyc_launch_power(const AcycLaunch& a) {
     return;
   }
   if (acyc_use_bf16(a)) {
-    size_t lds = 2 * ABF_IMG_BYTES;
-      const dim3 grid(a.nblk, (a.Mloc + 7) & ~7);
-#define ACYC_BF_LAUNCH(FOUR_)                                                                                                              \
+    // two-piece f16 operands (kernels_acyc_f16.h: half the matrix instructions); DIBS_ACYC_BF16=1 keeps the three-piece bf16 kernel (A/B runs)
+    static const bool bf16 = getenv("DIBS_ACYC_BF16") != nullptr;
+    const size_t lds = bf16 ? (size_t)2 * ABF_IMG_BYTES : (size_t)AHF_LDS_BYTES;
+    const dim3 grid(a.nblk, (a.Mloc + 7) & ~7);
+#define ACYC_BF_LAUNCH(KERNEL_)                                                                                                            \
     {                                                                                                                                        \
-      dibs_allow_lds((const void*)k_acyc_bf<FOUR_>, lds);                                                                                    \
+      dibs_allow_lds((const void*)KERNEL_, lds);                                                                                             \
       if (a.ev_start)                                                                                                                        \
-        hipExtLaunchKernelGGL(k_acyc_bf<FOUR_>, grid, dim3(256), (uint32_t)lds, a.stream, a.ev_start, a.ev_stop, 0u, a.scores, a.part, a.carry, \
+        hipExtLaunchKernelGGL(KERNEL_, grid, dim3(256), (uint32_t)lds, a.stream, a.ev_start, a.ev_stop, 0u, ACYC_SRC, a.part, a.carry,       \
                               a.m0, a.M, a.Mloc, a.d, a.Sa, a.cpb, a.alpha, a.tau, a.layout, a.tiny, a.nblk);                                  \
       else                                                                                                                                   \
-        hipLaunchKernelGGL(k_acyc_bf<FOUR_>, grid, dim3(256), lds, a.stream, a.scores, a.part, a.carry, a.m0, a.M, a.Mloc, a.d, a.Sa, a.cpb,   \
+        hipLaunchKernelGGL(KERNEL_, grid, dim3(256), lds, a.stream, ACYC_SRC, a.part, a.carry, a.m0, a.M, a.Mloc, a.d, a.Sa, a.cpb,            \
                            a.alpha, a.tau, a.layout, a.tiny, a.nblk);                                                                          \
     }
-    if (a.d > 48) ACYC_BF_LAUNCH(true) else ACYC_BF_LAUNCH(false)
+#define ACYC_SRC a.scores
+    if (bf16) {
+      if (a.d > 48) ACYC_BF_LAUNCH(k_acyc_bf<true>) else ACYC_BF_LAUNCH(k_acyc_bf<false>)
+    } else {
+#undef ACYC_SRC
+#define ACYC_SRC a.scores, a.eas
+      static const bool wpe3 = getenv("DIBS_ACYC_WPE4") == nullptr;  // three waves per SIMD (no spills, M's fragments kept); DIBS_ACYC_WPE4=1: four (A/B runs)
+      if (wpe3) {
+        if (a.d > 48) ACYC_BF_LAUNCH((k_acyc_hf<true, 3>)) else ACYC_BF_LAUNCH((k_acyc_hf<false, 3>))
+      } else {
+        if (a.d > 48) ACYC_BF_LAUNCH((k_acyc_hf<true, 4>)) else ACYC_BF_LAUNCH((k_acyc_hf<false, 4>))
+      }
+    }
 #undef ACYC_BF_LAUNCH
+#undef ACYC_SRC
     return;
   }
   if (acyc_use_bfw(a)) {
