@@ -528,6 +528,7 @@ extern "C" int dibs_engine_init_particles(dibs_engine* e, const uint32_t key[2])
       return fail("sample_parameters not implemented for this likelihood");
     }
   }
+  e->kmat_ext = false;  // (a kernel slab computed by dibs_engine_kmat_values belonged to the particles that were just replaced)
   HIP_OK(hipMemsetAsync(e->vz, 0, (size_t)e->Mloc * e->D * 4, e->stream));
   if (e->P) HIP_OK(hipMemsetAsync(e->vtheta, 0, (size_t)e->Mloc * e->P * 4, e->stream));
   HIP_OK(hipMemsetAsync(e->baseline, 0, (size_t)e->Mloc * 4, e->stream));
@@ -542,6 +543,8 @@ extern "C" int dibs_engine_set_state(dibs_engine* e, const float* z, const float
   HIP_OK(hipSetDevice(e->cfg.device_id));
   HIP_OK(hipStreamSynchronize(e->stream));
   const size_t nz = (size_t)e->Mloc * e->D * 4, nt = (size_t)e->Mloc * e->P * 4;
+  if (z || theta) e->kmat_ext = false;  // (an externally computed kernel slab belonged to the old values: phase B computes its own unless
+                                        //  dibs_engine_kmat_values is called again for the new ones)
   if (z) HIP_OK(hipMemcpy(e->z, z, nz, hipMemcpyHostToDevice));
   if (v_z) HIP_OK(hipMemcpy(e->vz, v_z, nz, hipMemcpyHostToDevice));
   if (theta && nt) HIP_OK(hipMemcpy(e->theta, theta, nt, hipMemcpyHostToDevice));
@@ -713,7 +716,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
   // latent matrix stays inside the k_bge_sample launch (KmatFuse: 8 us of that kernel's 70; on the second stream 3 999 -> 3 902 steps/s,
   // and ahead of the acyclicity kernel it delays that kernel).
   const bool kmat_on_s2 = c.joint || (long)e->M * e->D > 4L * e->S * e->d * e->d;
-  if (fork && kmat_on_s2 && e->Mloc == e->M && !getenv("DIBS_NO_KMAT_EARLY")) {
+  if (fork && kmat_on_s2 && e->Mloc == e->M && !e->kmat_ext && !getenv("DIBS_NO_KMAT_EARLY")) {
     if (join_now) {  // per-kernel timing: one kernel at a time
       hipEventRecord(e->ev_k1, e->stream2);
       hipStreamWaitEvent(e->stream, e->ev_k1, 0);
@@ -745,7 +748,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
       KmatFuse kf{nullptr, nullptr, 0, 0, 0, 0.f, 0.f};
       e->kmat_fused = false;
       // single rank, vector fits one LDS chunk: the latent kernel matrix rides along (see KmatFuse)
-      if (!e->kmat_early && e->Mloc == e->M && e->D <= KMAT_CH && (size_t)e->D * 4 + 64 <= 80 * 1024 && !getenv("DIBS_NO_KMAT_FUSE")) {
+      if (!e->kmat_early && !e->kmat_ext && e->Mloc == e->M && e->D <= KMAT_CH && (size_t)e->D * 4 + 64 <= 80 * 1024 && !getenv("DIBS_NO_KMAT_FUSE")) {
         kf = KmatFuse{e->z, e->kz, (int)e->D, e->M, (e->d + 3) / 4, (float)c.scale_latent, (float)c.h_latent};
         e->kmat_fused = true;
       }

@@ -71,7 +71,8 @@ class OverlapBuffers:
         self.side = torch.cuda.Stream(device=device) if self.cuda else None
         self.vals_ready = torch.cuda.Event() if self.cuda else None
         self.exported = torch.cuda.Event() if self.cuda else None
-        self.fresh = False   # plane 0 holds the values of the engine's current state
+        self.fresh = False   # plane 0 holds the values of the engine's current state ...
+        self.gen = None      # ... i.e. of this generation of it (Engine.state_gen: bumped by init_particles / set_state)
 
 
 def _gather(dst, src, group, single):
@@ -95,9 +96,16 @@ def _exchange_values(engine, buf, group, single, exported=False):
             _gather(buf.vals, buf.vsend, group, single)
             engine.kmat_values(buf.vals.data_ptr(), buf.side.cuda_stream)   # kernel-matrix slab of the next phase B, behind the gather
             buf.vals_ready.record(buf.side)
-    else:
+    else:   # (CPU harness of the protocol: tests/test_distributed_gloo.py)
         _gather(buf.vals, buf.vsend, group, single)
+        engine.kmat_values(buf.vals.data_ptr(), 0)
     buf.fresh = True
+    buf.gen = getattr(engine, "state_gen", None)
+
+
+def _stale(engine, buf):
+    """plane 0 (and the kernel slab computed from it) does not belong to the engine's current particles"""
+    return (not buf.fresh) or buf.gen != getattr(engine, "state_gen", None)
 
 
 def _is_single(group, always_collective):
@@ -116,12 +124,12 @@ def refresh_values(engine, buf, group=None, always_collective=False):
 
 def run_sharded_overlapped(engine, t_start, n_steps, buf, group=None, always_collective=False):
     """steps t_start .. t_start + n_steps - 1 with the values exchanged off the critical path (see the module docstring).  Call it inside
-    ``torch.cuda.stream(<the engine's stream>)`` on a GPU.  `buf.fresh` must be False whenever the engine's state was set from outside
-    (init_particles, set_state) since the last call.  always_collective: issue the all-gathers also in a group of one rank (smoke tests
+    ``torch.cuda.stream(<the engine's stream>)`` on a GPU.  A state set from outside since the last call (init_particles, set_state) is
+    noticed through the engine's state generation and the values are gathered again.  always_collective: issue the all-gathers also in a group of one rank (smoke tests
     of the RCCL call path on one GPU)."""
     import torch
     single = _is_single(group, always_collective)
-    if not buf.fresh:
+    if _stale(engine, buf):
         _exchange_values(engine, buf, group, single)
     for t in range(t_start, t_start + n_steps):
         engine.step_local_grads(t, buf.gsend.data_ptr())                                # phase A
@@ -137,7 +145,7 @@ def _all_particles(eng, buf, n_particles, group):
     the device after every step (no extra collective, one device-to-host copy)."""
     import torch
     import torch.distributed as dist
-    if not buf.fresh:
+    if _stale(eng, buf):
         _exchange_values(eng, buf, group, (not dist.is_initialized()) or dist.get_world_size(group) == 1)
     if buf.cuda:
         buf.vals_ready.synchronize()

@@ -25,6 +25,8 @@ class Engine:
         self.M, self.d, self.k = cfg.n_particles, cfg.n_vars, cfg.n_dim
         self.Mloc = cfg.n_particles // cfg.n_ranks
         self.P = int(self.lib.dibs_engine_theta_size(self._h))
+        self.state_gen = 0   # bumped whenever the particles are replaced from outside (init_particles / set_state): the overlapped
+                             # exchange of dibs_amd.distributed compares it with the generation its gathered values belong to
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -47,6 +49,7 @@ class Engine:
     def init_particles(self, key):
         key = np.ascontiguousarray(key, np.uint32).reshape(2)
         _lib.check(self.lib.dibs_engine_init_particles(self._h, _ptr(key)))
+        self.state_gen += 1
 
     def set_state(self, z=None, v_z=None, theta=None, v_theta=None, key=None, baseline=None):
         f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
@@ -54,6 +57,7 @@ class Engine:
         key = None if key is None else np.ascontiguousarray(key, np.uint32)
         _lib.check(self.lib.dibs_engine_set_state(self._h, _ptr(z), _ptr(v_z), _ptr(theta), _ptr(v_theta), _ptr(key),
                                                   _ptr(baseline)))
+        self.state_gen += 1
 
     def get_state(self):
         z = np.empty((self.Mloc, self.d, self.k, 2), np.float32)

@@ -25,6 +25,15 @@ class OracleShardEngine:
         self.st = co.new_local_state(cfg, key)
         self.E = co.pack_stride(cfg)
         self.Ml = cfg.n_particles // cfg.n_ranks
+        self.state_gen = 0        # as Engine.state_gen: bumped when the particles are replaced from outside
+        self._slab = None         # the externally computed kernel slab (kmat_values): checksum of the values it was computed from
+        self.slabs_consumed = 0
+
+    def set_state(self, **kw):
+        for k, v in kw.items():
+            self.st[k][...] = v
+        self.state_gen += 1
+        self._slab = None         # (dibs_engine_set_state clears kmat_ext)
 
     def gather_elems_per_rank(self):
         return self.Ml * self.E
@@ -62,7 +71,11 @@ class OracleShardEngine:
             v[:, self.D:self.D + self.P] = self.st["theta"].reshape(self.Ml, self.P)
 
     def kmat_values(self, vals_all_ptr, stream):
-        pass   # (the oracle's phase B computes the kernel matrix itself)
+        # The oracle's phase B computes the kernel matrix itself; what the adapter checks is the PROTOCOL of the externally computed slab
+        # (the engine's kmat_ext flag): computed once per step from the gathered values, consumed exactly once, by the phase B whose
+        # plane 0 holds those same values -- never a slab of replaced particles.
+        assert self._slab is None, "kernel slab computed twice without a phase B in between"
+        self._slab = self._view(vals_all_ptr, self.cfg.n_particles * self.Ev).copy()
 
     def step_local_grads(self, t, grads_send_ptr):
         D, P = self.D, self.P
@@ -76,6 +89,12 @@ class OracleShardEngine:
     def step_update_planes(self, t, planes_ptr, vals_send_ptr=None):
         D, P, M = self.D, self.P, self.cfg.n_particles
         pl = self._view(planes_ptr, 2 * M * self.Ev).reshape(2, M, self.Ev)
+        assert self._slab is not None, "phase B of the overlapped protocol without a kernel slab for this step"
+        assert np.array_equal(self._slab, pl[0].reshape(-1)), "kernel slab was computed from other values than phase B reads"
+        own = pl[0, self.cfg.rank * self.Ml:(self.cfg.rank + 1) * self.Ml]
+        assert np.array_equal(own[:, :D], self.st["z"].reshape(self.Ml, D)), "plane 0 does not hold the engine's current particles"
+        self._slab = None
+        self.slabs_consumed += 1
         pack = np.zeros((M, self.E))
         pack[:, :D], pack[:, D:2 * D] = pl[0, :, :D], pl[1, :, :D]
         if P:
@@ -168,3 +187,24 @@ def test_single_process_overlapped_protocol_equals_fused_step(c_oracle64):
     # plane 0 holds the values of the final state (what sample_sharded returns / hands to the callback)
     v = buf.vals.view(M, -1).numpy()
     assert np.array_equal(v[:, :eng.D], st["z"].reshape(M, -1)) and np.array_equal(v[:, eng.D:eng.D + eng.P], st["theta"].reshape(M, -1))
+
+
+def test_overlapped_protocol_notices_a_replaced_state(c_oracle64):
+    """set_state between two overlapped chunks (checkpoint restore): the values gathered after the last step of the first chunk -- and the
+    kernel slab computed from them -- belong to the old particles and must not serve the first step of the second chunk (the engine
+    clears kmat_ext, run_sharded_overlapped compares Engine.state_gen and gathers again).  Result == the same steps run from that state."""
+    d, M = 5, 4
+    data, _, _ = make_data(d, seed=1, joint=True)
+    x = np.ascontiguousarray(data.x, np.float64)
+    cfg = _cfg(True, 0, 1, d, M)
+    eng = OracleShardEngine(c_oracle64, cfg, x, None, prng.PRNGKey(2))
+    buf = OverlapBuffers(eng, 1, torch.device("cpu"), torch.float64)
+    run_sharded_overlapped(eng, 0, 2, buf)
+    assert eng.slabs_consumed == 2
+    other = c_oracle64.new_state(cfg, prng.PRNGKey(9))          # a different particle set, as a checkpoint would bring
+    c_oracle64.run(cfg, x, None, other, 0, 2)
+    eng.set_state(**{k: other[k] for k in ("z", "v_z", "theta", "v_theta", "key", "baseline")})
+    run_sharded_overlapped(eng, 2, 2, buf)                        # (the adapter's asserts fail if the stale slab / plane were used)
+    assert eng.slabs_consumed == 4
+    c_oracle64.run(cfg, x, None, other, 2, 2)
+    assert np.array_equal(eng.st["z"], other["z"]) and np.array_equal(eng.st["theta"], other["theta"])
