@@ -96,6 +96,26 @@ struct dibs_engine {
   std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending;
   bool has_mean_obs;
   std::vector<float> mean_obs;
+  // dibs_score_graphs: statistics / device copies of the last (x_ho, mask_ho) scored against (held-out evaluators and mixture weights
+  // call it repeatedly with the same data: svgd.py:110-113, 370-372)
+  struct ScoreCache {
+    std::vector<float> x;
+    std::vector<int32_t> mask;
+    bool has_mask = false, valid = false;
+    BgeStats st;
+    JointWork jw;
+    ScoreCache() { memset(&jw, 0, sizeof jw); }
+    ~ScoreCache() { joint_free(&jw); }
+    bool matches(const float* x_, const int32_t* m_, size_t n) const {
+      return valid && x.size() == n && has_mask == (m_ != nullptr) && memcmp(x.data(), x_, n * 4) == 0 && (!m_ || memcmp(mask.data(), m_, n * 4) == 0);
+    }
+    void remember(const float* x_, const int32_t* m_, size_t n) {
+      x.assign(x_, x_ + n);
+      has_mask = m_ != nullptr;
+      if (m_) mask.assign(m_, m_ + n);
+      valid = true;
+    }
+  } score_cache;
 };
 
 extern "C" const char* dibs_last_error(void) { return g_err.c_str(); }
@@ -479,6 +499,7 @@ extern "C" int dibs_engine_set_data(dibs_engine* e, const float* x, const int32_
   if (!e || !x) return fail("null argument");
   HIP_OK(hipSetDevice(e->cfg.device_id));
   HIP_OK(hipStreamSynchronize(e->stream));
+  e->score_cache.valid = false;  // (the BGe prior mean travels with the data)
   e->has_data = false;  // (a failure below leaves the engine without data: the next step reports it instead of reading freed statistics)
   const size_t n = (size_t)e->N * e->d;
   if (e->x) hipFree(e->x);
@@ -639,6 +660,16 @@ static void drain_timers(dibs_engine* e) {
   e->pending.clear();
 }
 
+// device buffer that frees itself (error paths)
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  ~DevBuf() {
+    if (p) hipFree(p);
+  }
+  hipError_t alloc(size_t n) { return dalloc(&p, n); }
+};
+
 // ---- one SVGD step, split at the exchange point ----------------------------------------------
 // carry keys: the loop-carry key advances by one split(key, M+1) per estimator batch (svgd.py:245, 251 / 695, 699, 703);
 // the host walks the chain (row 0), kernels derive row 1 + m.
@@ -656,22 +687,45 @@ static RowTarget packed_rows(const dibs_engine* e, float* pack) {
   return RowTarget{pack, (size_t)e->E, (size_t)e->D, (size_t)(2 * e->D), (size_t)(2 * e->D + e->P), 1};
 }
 
-static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
+// explicit per-particle keys of one evaluation (dibs_engine_eval_gradients): device arrays Key2[Mloc], one per estimator family
+struct StepKeys {
+  const Key2 *theta, *lik, *prior;
+};
+enum { TERMS_LIK = 1, TERMS_PRIOR = 2, TERMS_ALL = 3 };
+// (rng.h: rng_explicit_row) the carry slot carries the address of the key of GLOBAL particle 0
+static Key2 key_array_as_carry(const Key2* local, int m0) {
+  const uint64_t p = (uint64_t)(uintptr_t)(local - m0);
+  return Key2{(uint32_t)p, (uint32_t)(p >> 32)};
+}
+
+// xk == null: the step of the SVGD loop (keys from the loop-carry key, which advances).  xk != null: the same kernels with the caller's
+// per-particle keys, the loop-carry key untouched; `terms` selects the likelihood part (estimators + their share of grad_z), the prior
+// part (acyclicity, Gaussian and graph prior), or both.
+static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys* xk = nullptr, int terms = TERMS_ALL, const float* zero_w = nullptr) {
   float* const pack = rt.base;
   const dibs_config& c = e->cfg;
   const float alpha = (float)(c.alpha_linear * t), beta = (float)(c.beta_linear * t);
   const int L = c.rng_layout;
-  Key2 carry = e->key;
   Key2 carry_theta{0, 0}, carry_lik, carry_prior;
-  if (c.joint) {
-    carry_theta = carry;
+  int Mg = e->M;  // particle count of the key derivation (row 1 + m of split(carry, M + 1)); -1: explicit keys
+  if (xk) {
+    Mg = -1;
+    carry_theta = key_array_as_carry(xk->theta, e->m0);
+    carry_lik = key_array_as_carry(xk->lik, e->m0);
+    carry_prior = key_array_as_carry(xk->prior, e->m0);
+  } else {
+    Key2 carry = e->key;
+    if (c.joint) {
+      carry_theta = carry;
+      carry = next_carry(e, carry);
+    }
+    carry_lik = carry;
     carry = next_carry(e, carry);
+    carry_prior = carry;
+    carry = next_carry(e, carry);
+    e->key = carry;
   }
-  carry_lik = carry;
-  carry = next_carry(e, carry);
-  carry_prior = carry;
-  carry = next_carry(e, carry);
-  e->key = carry;
+  const bool do_lik = (terms & TERMS_LIK) != 0, do_prior = (terms & TERMS_PRIOR) != 0;
 
   e->kmat_early = false;
   {
@@ -697,11 +751,11 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
   // on the main stream and 96 us on its own.
   // (a small acyclicity launch -- <= 512 blocks: config 2, or a rank of a sharded headline run -- stays on the main stream: the fork / join
   //  events cost 6 + 6 us of the critical path, more than such a launch can hide; measured at config 2: 16 100 -> see DESIGN.md)
-  const bool fork = e->stream2 != nullptr && (long)e->acyc_nblk * e->Mloc > 512, join_now = e->profiling && !e->profiling_concurrent;
+  const bool fork = do_prior && do_lik && e->stream2 != nullptr && (long)e->acyc_nblk * e->Mloc > 512, join_now = e->profiling && !e->profiling_concurrent;
   if (fork) {
     hipEventRecord(e->ev_fork, e->stream);
     hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
-    const AcycLaunch al{e->stream2, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
+    const AcycLaunch al{e->stream2, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, Mg, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
                         e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr, e->eas};
     acyc_power_timed(e, al, e->stream2);
     {
@@ -716,7 +770,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
   // latent matrix stays inside the k_bge_sample launch (KmatFuse: 8 us of that kernel's 70; on the second stream 3 999 -> 3 902 steps/s,
   // and ahead of the acyclicity kernel it delays that kernel).
   const bool kmat_on_s2 = c.joint || (long)e->M * e->D > 4L * e->S * e->d * e->d;
-  if (fork && kmat_on_s2 && e->Mloc == e->M && !e->kmat_ext && !getenv("DIBS_NO_KMAT_EARLY")) {
+  if (fork && !xk && kmat_on_s2 && e->Mloc == e->M && !e->kmat_ext && !getenv("DIBS_NO_KMAT_EARLY")) {
     if (join_now) {  // per-kernel timing: one kernel at a time
       hipEventRecord(e->ev_k1, e->stream2);
       hipStreamWaitEvent(e->stream, e->ev_k1, 0);
@@ -736,10 +790,12 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
   }
   if (fork) hipEventRecord(e->ev_join, e->stream2);
   if (fork && join_now) hipStreamWaitEvent(e->stream, e->ev_join, 0);
-  if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_REPARAM) {
+  if (!do_lik) {
+    // (prior terms only: no estimator runs, the tail takes a zero likelihood gradient)
+  } else if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_REPARAM) {
     const BgeSoftParams sp{e->bge.R, e->bge.Nj, e->bge.alpha_lambd, e->bge.alpha_mu, e->bge.log_t, e->bge.n_mats};
     KTimer tm(e, DIBS_K_BGE_NODES);
-    bge_soft_launch(sp, e->scores, carry_lik, e->m0, e->M, e->Mloc, e->d, e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny,
+    bge_soft_launch(sp, e->scores, carry_lik, e->m0, Mg, e->Mloc, e->d, e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny,
                     e->soft_ds, e->logprobs_z, e->w_lik, e->stream);
   } else if (c.likelihood == DIBS_LIK_BGE) {
     const BgeParams bp = e->bge.params();
@@ -748,11 +804,11 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
       KmatFuse kf{nullptr, nullptr, 0, 0, 0, 0.f, 0.f};
       e->kmat_fused = false;
       // single rank, vector fits one LDS chunk: the latent kernel matrix rides along (see KmatFuse)
-      if (!e->kmat_early && !e->kmat_ext && e->Mloc == e->M && e->D <= KMAT_CH && (size_t)e->D * 4 + 64 <= 80 * 1024 && !getenv("DIBS_NO_KMAT_FUSE")) {
+      if (!xk && !e->kmat_early && !e->kmat_ext && e->Mloc == e->M && e->D <= KMAT_CH && (size_t)e->D * 4 + 64 <= 80 * 1024 && !getenv("DIBS_NO_KMAT_FUSE")) {
         kf = KmatFuse{e->z, e->kz, (int)e->D, e->M, (e->d + 3) / 4, (float)c.scale_latent, (float)c.h_latent};
         e->kmat_fused = true;
       }
-      bge_launch_sample(true, e->stream, e->thr, e->masks, e->node_scores, bp, carry_lik, e->m0, e->M, e->Mloc, e->d, e->S, e->W, L,
+      bge_launch_sample(true, e->stream, e->thr, e->masks, e->node_scores, bp, carry_lik, e->m0, Mg, e->Mloc, e->d, e->S, e->W, L,
                         e->bq, kf);
     }
     {
@@ -762,7 +818,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
     score_lik = true;  // softmax weights, W_lik and the baseline are part of k_particle_grad below
   } else if (c.likelihood == DIBS_LIK_LINGAUSS) {
     JointLaunch jl{e->stream, e->z, e->theta, e->scores, e->thr, e->w_lik, e->logprobs_z, e->logprobs_th, e->baseline,
-                   e->baseline2, pack, rt.stride, rt.th_off, rt.gth_off, rt.copy_vals, e->m0, e->M, e->Mloc, e->d,
+                   e->baseline2, pack, rt.stride, rt.th_off, rt.gth_off, rt.copy_vals, e->m0, Mg, e->Mloc, e->d,
                    e->N, e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny, c.grad_estimator_z, c.score_function_baseline,
                    (float)c.lin_obs_noise, (float)c.lin_mean_edge, (float)c.lin_sig_edge};
     {
@@ -776,7 +832,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
     }
   } else if (c.likelihood == DIBS_LIK_DENSENN) {
     JointLaunch jl{e->stream, e->z, e->theta, e->scores, e->thr, e->w_lik, e->logprobs_z, e->logprobs_th, e->baseline,
-                   e->baseline2, pack, rt.stride, rt.th_off, rt.gth_off, rt.copy_vals, e->m0, e->M, e->Mloc, e->d,
+                   e->baseline2, pack, rt.stride, rt.th_off, rt.gth_off, rt.copy_vals, e->m0, Mg, e->Mloc, e->d,
                    e->N, e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny, c.grad_estimator_z, c.score_function_baseline,
                    0.f, 0.f, 0.f};
     const NNParams np_ = nn_params(c);
@@ -793,8 +849,8 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
   }
   if (fork) {
     hipStreamWaitEvent(e->stream, e->ev_join, 0);  // (covers the kernel matrices: they precede the acyclicity kernel on that stream)
-  } else {
-    const AcycLaunch al{e->stream, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, e->M, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
+  } else if (do_prior) {
+    const AcycLaunch al{e->stream, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, Mg, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
                         e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr, e->eas};
     acyc_power_timed(e, al, e->stream);
     {
@@ -814,9 +870,12 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
     const int ldz = e->w_tot ? 0 : tail_ldz(e->d, e->k, e->S, score_lik, LDS_LIMIT - 2048);
     const int cap = score_lik ? tail_stage_cap(e->d, ldz, e->S, e->W, LDS_LIMIT - 2048) : 0;
     const size_t lds = tail_lds_bytes(e->d, ldz, e->S, e->W, score_lik, cap);
+    // (terms: without the prior part beta = 0, no graph prior, no Gaussian term; without the likelihood part a zero W_lik is the input)
+    const float inv_sig2 = do_prior ? 1.0f / (e->sigz * e->sigz) : 0.f;
     const TailArgs ta{score_lik ? e->node_scores : nullptr, e->masks, e->logprobs_z, e->baseline, e->baseline2, c.score_function_baseline,
-                      score_lik ? e->bq.counts : nullptr, e->S, e->W, cap, e->probs, e->w_lik, e->w_acyc, alpha, beta, c.graph_prior, er_c,
-                      e->z, pack, rt.stride, rt.copy_vals, e->m0, e->d, e->k, ldz, 1.0f / (e->sigz * e->sigz), e->profiling ? e->counters : nullptr,
+                      score_lik ? e->bq.counts : nullptr, e->S, e->W, cap, e->probs, do_lik ? e->w_lik : const_cast<float*>(zero_w), e->w_acyc, alpha,
+                      do_prior ? beta : 0.f, do_prior ? c.graph_prior : (int)DIBS_PRIOR_UNIFORM, er_c,
+                      e->z, pack, rt.stride, rt.copy_vals, e->m0, e->d, e->k, ldz, inv_sig2, e->profiling ? e->counters : nullptr,
                       e->w_tot};
     allow_lds(k_particle_grad, lds);
     hipLaunchKernelGGL(k_particle_grad, dim3(e->Mloc), dim3(TAIL_NT), lds, e->stream, ta);
@@ -824,7 +883,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt) {
       const size_t lb = backproject_big_lds(e->d);
       allow_lds(k_backproject_big, lb);
       hipLaunchKernelGGL(k_backproject_big, dim3(e->Mloc, (e->d + 15) / 16, (e->k + 31) / 32), dim3(256), lb, e->stream, e->w_tot, e->z, pack, rt.stride,
-                         rt.copy_vals, e->m0, e->d, e->k, 1.0f / (e->sigz * e->sigz));
+                         rt.copy_vals, e->m0, e->d, e->k, inv_sig2);
     }
     if (score_lik) std::swap(e->baseline, e->baseline2);
   }
@@ -987,6 +1046,47 @@ extern "C" int dibs_engine_step_update(dibs_engine* e, int32_t t, const void* re
   return step_update(e, t, packed_source(e, (const float*)recv_dev));
 }
 
+// ---- gradient estimators for explicit per-particle keys (include/dibs_hip.h) ------------------------------------------------
+// reference: DiBS.eltwise_grad_z_likelihood (dibs.py:295-321), eltwise_grad_theta_likelihood (:467-485), eltwise_grad_latent_prior (:626-658)
+extern "C" int dibs_engine_eval_gradients(dibs_engine* e, int32_t t, const uint32_t* keys_theta, const uint32_t* keys_lik, const uint32_t* keys_prior,
+                                          float* grad_z_lik, float* baseline_out, float* grad_theta, float* grad_z_prior) {
+  if (!e) return fail("null engine");
+  if (!e->has_data) return fail("dibs_engine_set_data has not been called");
+  const dibs_config& c = e->cfg;
+  const bool want_lik = keys_lik != nullptr || keys_theta != nullptr, want_prior = keys_prior != nullptr;
+  if (c.joint && want_lik && (!keys_lik || !keys_theta)) return fail("joint model: pass the keys of the theta AND the Z estimator (both run in one pass)");
+  if (!c.joint && keys_theta) return fail("keys_theta given for a marginal model");
+  if (want_lik && !c.joint && !keys_lik) return fail("keys_lik missing");
+  HIP_OK(hipSetDevice(c.device_id));
+  HIP_OK(hipStreamSynchronize(e->stream));
+  const size_t nk = (size_t)e->Mloc * 2;
+  DevBuf<uint32_t> dk;   // [3][Mloc][2]
+  DevBuf<float> zero_w;  // [Mloc][d][d] zeros: the likelihood gradient of the prior-only pass
+  HIP_OK(dk.alloc(3 * nk));
+  const uint32_t* src[3] = {keys_theta, keys_lik, keys_prior};
+  for (int i = 0; i < 3; ++i)
+    if (src[i]) HIP_OK(hipMemcpy(dk.p + i * nk, src[i], nk * 4, hipMemcpyHostToDevice));
+  const StepKeys xk{reinterpret_cast<const Key2*>(dk.p), reinterpret_cast<const Key2*>(dk.p + nk), reinterpret_cast<const Key2*>(dk.p + 2 * nk)};
+  const size_t wz = (size_t)e->D * 4, wt = (size_t)e->P * 4;
+  const float* rows = e->pack + (size_t)e->m0 * e->E;
+  if (want_lik) {
+    if (step_local(e, t, packed_rows(e, e->pack), &xk, TERMS_LIK)) return 1;
+    HIP_OK(hipStreamSynchronize(e->stream));
+    if (grad_z_lik) HIP_OK(hipMemcpy2D(grad_z_lik, wz, rows + e->D, (size_t)e->E * 4, wz, e->Mloc, hipMemcpyDeviceToHost));
+    if (grad_theta && e->P) HIP_OK(hipMemcpy2D(grad_theta, wt, rows + 2 * e->D + e->P, (size_t)e->E * 4, wt, e->Mloc, hipMemcpyDeviceToHost));
+    if (baseline_out) HIP_OK(hipMemcpy(baseline_out, e->baseline, (size_t)e->Mloc * 4, hipMemcpyDeviceToHost));
+  }
+  if (want_prior) {
+    HIP_OK(zero_w.alloc((size_t)e->Mloc * e->d * e->d));
+    if (step_local(e, t, packed_rows(e, e->pack), &xk, TERMS_PRIOR, zero_w.p)) return 1;
+    HIP_OK(hipStreamSynchronize(e->stream));
+    if (grad_z_prior) HIP_OK(hipMemcpy2D(grad_z_prior, wz, rows + e->D, (size_t)e->E * 4, wz, e->Mloc, hipMemcpyDeviceToHost));
+  }
+  if (e->profiling) drain_timers(e);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int64_t dibs_engine_gather_elems_per_rank(const dibs_engine* e) { return e ? (int64_t)e->Mloc * e->E : 0; }
 
 extern "C" int dibs_engine_sync(dibs_engine* e) {
@@ -1097,15 +1197,6 @@ extern "C" int dibs_engine_get_counters(dibs_engine* e, double* out, int32_t n) 
 }
 
 
-// device buffer that frees itself (error paths of dibs_score_graphs)
-template <typename T>
-struct DevBuf {
-  T* p = nullptr;
-  ~DevBuf() {
-    if (p) hipFree(p);
-  }
-  hipError_t alloc(size_t n) { return dalloc(&p, n); }
-};
 struct JointWorkGuard {
   JointWork jw;
   JointWorkGuard() { memset(&jw, 0, sizeof jw); }
@@ -1123,9 +1214,16 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
   const size_t dd = (size_t)d * d;
   DevBuf<float> d_out;
   HIP_OK(d_out.alloc((size_t)n));
+  dibs_engine::ScoreCache& sc = e->score_cache;
+  const size_t n_x = (size_t)n_ho * d;
+  const bool cached = sc.matches(x_ho, mask_ho, n_x);
+  if (!cached) sc.valid = false;
   if (c.likelihood == DIBS_LIK_BGE) {
-    BgeStats st;  // statistics of (x_ho, mask_ho)
-    if (bge_prepare(&st, c, d, n_ho, x_ho, mask_ho, e->has_mean_obs ? e->mean_obs.data() : nullptr)) return 1;
+    BgeStats& st = sc.st;  // statistics of (x_ho, mask_ho)
+    if (!cached) {
+      if (bge_prepare(&st, c, d, n_ho, x_ho, mask_ho, e->has_mean_obs ? e->mean_obs.data() : nullptr)) return 1;
+      sc.remember(x_ho, mask_ho, n_x);
+    }
     const int W = e->W, CH = 512;
     DevBuf<uint64_t> d_masks;
     DevBuf<double> d_ns;
@@ -1156,9 +1254,12 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
   } else if (c.likelihood == DIBS_LIK_LINGAUSS || c.likelihood == DIBS_LIK_DENSENN) {
     if (!theta) return fail("theta required");
     const bool nn = c.likelihood == DIBS_LIK_DENSENN;
-    JointWorkGuard jg;
-    if (joint_set_data(&jg.jw, x_ho, mask_ho, n_ho, d)) return fail("joint_set_data failed");
-    if (!nn && !joint_lin_fast_path(d, n_ho) && joint_lin_set_gram(&jg.jw, x_ho, mask_ho, n_ho, d)) return fail("LinearGaussian: Gram matrices: hipMalloc failed");
+    struct { JointWork& jw; } jg{sc.jw};
+    if (!cached) {
+      if (joint_set_data(&jg.jw, x_ho, mask_ho, n_ho, d)) return fail("joint_set_data failed");
+      if (!nn && !joint_lin_fast_path(d, n_ho) && joint_lin_set_gram(&jg.jw, x_ho, mask_ho, n_ho, d)) return fail("LinearGaussian: Gram matrices: hipMalloc failed");
+      sc.remember(x_ho, mask_ho, n_x);
+    }
     const size_t P = nn ? (size_t)e->P : dd;
     DevBuf<float> d_th;
     DevBuf<int32_t> d_g;

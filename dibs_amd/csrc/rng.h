@@ -143,9 +143,20 @@ DIBS_HD void rng_bits_pair(Key2 key, uint64_t n, uint64_t c, int layout, uint32_
   }
 }
 
+// Explicit per-particle keys (dibs_engine_eval_gradients: the reference's eltwise_grad_* methods take `subkeys` [n_particles, 2] instead of
+// deriving them from a loop-carry key).  Every kernel derives a particle's key as row 1 + m of split(carry, M + 1); with M = -1 (num == 0,
+// never a real split) the carry slot holds the DEVICE ADDRESS of a Key2 array indexed by the global particle id, and "row r" is entry r - 1.
+__device__ __forceinline__ Key2 rng_explicit_row(Key2 key, uint32_t r) {
+  const Key2* p = reinterpret_cast<const Key2*>(((uint64_t)key.b << 32) | (uint64_t)key.a);
+  return p[r - 1u];
+}
+
 // row r of jax.random.split(key, num)
 DIBS_HD Key2 rng_split_row(Key2 key, uint32_t num, uint32_t r, int layout) {
   Key2 o;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (num == 0u) return rng_explicit_row(key, r);
+#endif
   if (layout == 1) {
     threefry2x32(key.a, key.b, 0u, r, o.a, o.b);
     return o;
@@ -244,6 +255,12 @@ __device__ __forceinline__ Key2 rng_split_row_uniform(Key2 key, uint32_t num, ui
   num = __builtin_amdgcn_readfirstlane(num);
   r = __builtin_amdgcn_readfirstlane(r);
   Key2 o;
+  if (num == 0u) {  // explicit per-particle keys (see rng_explicit_row)
+    const Key2 x = rng_explicit_row(Key2{k0, k1}, r);
+    o.a = __builtin_amdgcn_readfirstlane(x.a);
+    o.b = __builtin_amdgcn_readfirstlane(x.b);
+    return o;
+  }
   if (layout == 1) {
     threefry2x32_scalar(k0, k1, 0u, r, o.a, o.b);
     return o;

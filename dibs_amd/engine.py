@@ -101,6 +101,19 @@ class Engine:
         _lib.check(self.lib.dibs_engine_step_update_planes(self._h, int(t), C.c_void_p(planes_ptr),
                                                            C.c_void_p(vals_send_ptr) if vals_send_ptr else None))
 
+    def eval_gradients(self, t, keys_theta=None, keys_lik=None, keys_prior=None):
+        """Gradient estimators of one step for the current particles with explicit per-particle keys (include/dibs_hip.h,
+        dibs_engine_eval_gradients).  keys_*: uint32 [Mloc, 2] or None.  Returns a dict with the outputs that were computed."""
+        k = lambda a: None if a is None else np.ascontiguousarray(np.asarray(a, np.uint32).reshape(self.Mloc, 2))
+        kt, kl, kp = k(keys_theta), k(keys_lik), k(keys_prior)
+        lik, prior = kl is not None or kt is not None, kp is not None
+        gz = np.empty((self.Mloc, self.d, self.k, 2), np.float32) if lik else None
+        bl = np.empty(self.Mloc, np.float32) if lik else None
+        gt = np.empty((self.Mloc, self.P), np.float32) if lik and self.P else None
+        gp = np.empty((self.Mloc, self.d, self.k, 2), np.float32) if prior else None
+        _lib.check(self.lib.dibs_engine_eval_gradients(self._h, int(t), _ptr(kt), _ptr(kl), _ptr(kp), _ptr(gz), _ptr(bl), _ptr(gt), _ptr(gp)))
+        return dict(grad_z_lik=gz, baseline=bl, grad_theta=gt, grad_z_prior=gp)
+
     def sync(self):
         _lib.check(self.lib.dibs_engine_sync(self._h))
 

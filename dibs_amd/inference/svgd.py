@@ -13,6 +13,14 @@ from ..metrics import ParticleDistribution
 from .dibs import DiBS
 
 
+def _tree_add_axis(theta):
+    """a single particle's parameters with a leading particle axis of length one (array or the DenseNN pytree)"""
+    from ..utils.tree import tree_map
+    if isinstance(theta, np.ndarray) or not isinstance(theta, (list, tuple)):
+        return np.asarray(theta)[None]
+    return tree_map(lambda a: np.asarray(a)[None], theta)
+
+
 def _logsumexp(a):
     a = np.asarray(a, np.float64)
     m = a.max()
@@ -82,6 +90,67 @@ class _SVGDBase(DiBS):
         eng.set_data(self.x, self.interv_mask if self.interv_mask.any() else None,
                      getattr(self.likelihood_model, "mean_obs", None))
         return eng
+
+    # ---- estimators of the reference's DiBS base, on the device (dibs.py:255-269, 295-321, 467-485, 626-658) ----
+    def _flat_thetas(self, thetas):
+        if not self._joint or thetas is None:
+            return None
+        lm = self.likelihood_model
+        if lm._dibs_likelihood == "densenn":
+            return np.ascontiguousarray(lm.tree_to_flat(thetas), np.float32)
+        th = np.asarray(thetas, np.float32)
+        return np.ascontiguousarray(th.reshape(th.shape[0], -1))
+
+    def _eval(self, zs, thetas, baselines, t, **keys):
+        zs = np.ascontiguousarray(zs, np.float32)
+        n_particles, d, k = zs.shape[0], zs.shape[1], zs.shape[2]
+        eng = self._new_engine(n_particles, k)
+        try:
+            eng.set_state(z=zs, theta=self._flat_thetas(thetas),
+                          baseline=None if baselines is None else np.ascontiguousarray(baselines, np.float32))
+            return eng.eval_gradients(int(t), **keys)
+        finally:
+            eng.close()
+
+    def eltwise_log_joint_prob(self, gs, single_theta, rng=None):
+        """log p(theta, D | G) (marginal model: log p(D | G)) for a batch of hard graphs ``[n, d, d]`` on the training data (dibs.py:255-269)."""
+        from .scoring import score_graphs
+        gs = np.asarray(gs)
+        th = None
+        if self._joint:
+            flat = self._flat_thetas(_tree_add_axis(single_theta))
+            th = np.repeat(flat, gs.shape[0], axis=0)
+        return score_graphs(self.likelihood_model, gs, th, self.x, self.interv_mask if self.interv_mask.any() else None)
+
+    def eltwise_grad_z_likelihood(self, zs, thetas, baselines, t, subkeys):
+        """Estimator of grad_Z log p(theta, D | Z) for every particle -> (``[n_particles, d, k, 2]``, baselines ``[n_particles]``)
+        (dibs.py:295-321): the score-function or the Gumbel-softmax estimator, as ``grad_estimator_z`` says, with particle m's graphs drawn
+        from ``subkeys[m]`` exactly as in one SVGD step (svgd.py:245-249, 699-701)."""
+        if self.grad_estimator_z not in ("score", "reparam"):
+            raise ValueError(f"Unknown gradient estimator `{self.grad_estimator_z}`")
+        subkeys = np.asarray(subkeys, np.uint32)
+        r = self._eval(zs, thetas, baselines, t, keys_lik=subkeys, keys_theta=subkeys if self._joint else None)
+        return r["grad_z_lik"], r["baseline"]
+
+    def eltwise_grad_theta_likelihood(self, zs, thetas, t, subkeys):
+        """Estimator of grad_theta log p(theta, D | Z) for every particle, theta-shaped (dibs.py:467-551; joint models only)."""
+        if not self._joint:
+            raise NotImplementedError("the marginal model has no parameters")
+        subkeys = np.asarray(subkeys, np.uint32)
+        r = self._eval(zs, thetas, None, t, keys_lik=subkeys, keys_theta=subkeys)
+        return self._theta_out(r["grad_theta"])
+
+    def eltwise_grad_latent_prior(self, zs, subkeys, t):
+        """grad_Z log p(Z) = -beta(t) E[grad h(G~)] - Z / sigma_z^2 + grad log p(G_alpha(Z)) for every particle (dibs.py:626-658); the
+        acyclicity noise of particle m is drawn from ``subkeys[m]`` (used directly, dibs.py:595)."""
+        zs = np.ascontiguousarray(zs, np.float32)
+        eng = self._new_engine(zs.shape[0], zs.shape[2])
+        try:
+            # (the prior terms do not read theta; a joint engine's state still needs a well-formed one)
+            eng.set_state(z=zs, theta=np.zeros((zs.shape[0], eng.P), np.float32) if eng.P else None)
+            return eng.eval_gradients(int(t), keys_prior=np.asarray(subkeys, np.uint32))["grad_z_prior"]
+        finally:
+            eng.close()
 
     def _theta_out(self, flat):
         lm = self.likelihood_model

@@ -178,6 +178,19 @@ int64_t dibs_engine_theta_size(const dibs_engine* e);
  * (the main stream waits for the acyclicity kernel before it continues: each duration is the kernel alone on the GPU); enable=2 keeps the production schedule -- the acyclicity kernel on the engine's second
  * stream beside the likelihood kernels -- and times it with events on that stream (durations of overlapping kernels include the sharing). */
 int dibs_engine_set_profiling(dibs_engine* e, int32_t enable);
+/* Gradient estimators of ONE step for the engine's current particles (dibs_engine_set_state) with EXPLICIT per-particle PRNG keys --
+ * what the reference exposes as DiBS.eltwise_grad_z_likelihood(zs, thetas, baselines, t, subkeys) -> (grads, baselines)
+ * (dibs/inference/dibs.py:295-321), DiBS.eltwise_grad_theta_likelihood(zs, thetas, t, subkeys) (:467-485) and
+ * DiBS.eltwise_grad_latent_prior(zs, subkeys, t) (:626-658).  Same kernels as a step of dibs_engine_run, only the key of particle m
+ * is keys_*[m] instead of row 1 + m of split(loop-carry key, M + 1); the loop-carry key does not advance.
+ *   keys_theta / keys_lik / keys_prior : uint32 [Mloc][2] host arrays or NULL (NULL, NULL -> no likelihood pass; keys_prior NULL -> no
+ *                                        prior pass).  Joint models run the theta and the Z estimator in one pass: pass both or neither.
+ *   grad_z_lik  [Mloc][d][k][2] : estimator of grad_Z log p(theta, D | Z);  baseline_out [Mloc]: the updated score-function baselines
+ *                                 (input baselines = the engine's state);  grad_theta [Mloc][P]: estimator of grad_theta (joint only)
+ *   grad_z_prior [Mloc][d][k][2]: -beta(t) E[grad h] - Z / sigma_z^2 + grad log p(G_alpha(Z))
+ * Any output may be NULL.  Blocking. */
+int dibs_engine_eval_gradients(dibs_engine* e, int32_t t, const uint32_t* keys_theta, const uint32_t* keys_lik, const uint32_t* keys_prior,
+                               float* grad_z_lik, float* baseline_out, float* grad_theta, float* grad_z_prior);
 int dibs_engine_get_timers(dibs_engine* e, double* total_ms, int64_t* launches, int32_t n); /* arrays of DIBS_K_COUNT */
 int dibs_engine_reset_timers(dibs_engine* e);
 /* effective (executed) flop / problem-size counters of the BGe node kernel for the roofline */

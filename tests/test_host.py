@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import make_data
+from conftest import make_data, rel_err
 from dibs_amd import random
 from dibs_amd.graph_utils import acyclic_constr_nograd, mat_is_dag
 from dibs_amd.inference import JointDiBS, MarginalDiBS
@@ -153,3 +153,51 @@ def test_model_log_prob_helpers_match_oracle():
     ref = float(O.densenn_log_joint(t64(g), tht, t64(x), t64(it), O.DenseNNParams(hidden_layers=(4,), activation="tanh")))
     got = nn.log_prob_parameters(theta=theta, g=g) + nn.log_likelihood(x=x, theta=theta, g=g, interv_targets=it)
     assert abs(got - ref) < 1e-6 * abs(ref)
+
+
+def test_dibs_base_host_helpers_match_autograd_oracle():
+    """public helpers of the reference's DiBS base that live on the host (dibs/inference/dibs.py:102-247, 557-623): graph samples from given
+    keys / noise, edge log-probabilities, log p(G | Z) and its Z-gradient (closed form here, autograd in the oracle), soft graph prior,
+    acyclicity value of a Gumbel-soft graph"""
+    import torch
+    from oracle import dibs_oracle as O, prng
+    from dibs_amd import random
+    from dibs_amd.inference import MarginalDiBS
+    d, k, t = 6, 4, 3
+    data, gm, lm = make_data(d, seed=2)
+    dibs = MarginalDiBS(x=data.x, graph_model=gm, likelihood_model=lm, alpha_linear=0.7, tau=1.3)
+    rng = np.random.default_rng(0)
+    z = rng.normal(size=(d, k, 2)).astype(np.float32)
+    zt = torch.as_tensor(z.astype(np.float64))
+    alpha = 0.7 * t
+    key = random.PRNGKey(5)
+    # sample_g: same stream as the oracle's (jax.random.bernoulli layering), int32, zero diagonal
+    p = dibs.edge_probs(z, t)
+    g = dibs.sample_g(p, key, 7)
+    assert g.dtype == np.int32 and g.shape == (7, d, d) and not g[:, np.arange(d), np.arange(d)].any()
+    assert np.array_equal(g, O.sample_g(torch.as_tensor(p.astype(np.float64)), prng.PRNGKey(5), 7, "legacy").numpy().astype(np.int32))
+    eps = random.logistic(key, (d, d))
+    soft = dibs.particle_to_soft_graph(z, eps, t)
+    ref = O.particle_to_soft_graph(zt, torch.as_tensor(eps.astype(np.float64)), alpha, 1.3).numpy()
+    assert rel_err(soft, ref) < 1e-6 and not np.diag(soft).any()
+    hard = dibs.particle_to_hard_graph(z, eps, t)
+    assert hard.dtype == np.float32 and np.array_equal(hard, dibs._zero_diag(((eps + np.float32(alpha) * dibs._scores(z)) > 0).astype(np.float32)))
+    lp, l1p = dibs.edge_log_probs(z, t)
+    s = dibs._scores(z).astype(np.float64)
+    off = ~np.eye(d, dtype=bool)
+    assert rel_err(lp[off], -np.log1p(np.exp(-alpha * s))[off]) < 1e-6 and rel_err(l1p[off], -np.log1p(np.exp(alpha * s))[off]) < 1e-6
+    assert not np.diag(lp).any() and not np.diag(l1p).any()
+    # latent log-probability and its gradient (the reference differentiates latent_log_prob; here the closed form)
+    llp = dibs.latent_log_prob(g[0], z, t)
+    assert abs(float(llp) - float(O.latent_log_prob(torch.as_tensor(g[0].astype(np.float64)), zt, alpha))) < 1e-4
+    grads = dibs.eltwise_grad_latent_log_prob(g, z, t)
+    assert grads.shape == (7, d, k, 2)
+    for q in range(7):
+        zz = zt.clone().requires_grad_(True)
+        (gr,) = torch.autograd.grad(O.latent_log_prob(torch.as_tensor(g[q].astype(np.float64)), zz, alpha), zz)
+        assert rel_err(grads[q], gr.numpy()) < 1e-5
+    # graph prior on the edge probabilities, acyclicity value of the soft graph
+    assert abs(float(dibs.log_graph_prior_particle(z, t)) -
+               float(O.log_graph_prior_soft(O.edge_probs(zt, alpha), O.GraphPrior("er", gm.n_edges_per_node), d))) < 1e-4
+    h = dibs.constraint_gumbel(z, eps, t)
+    assert abs(float(h) - float(O.acyclic_constr(torch.as_tensor(ref), d))) < 1e-4 * max(1.0, abs(float(h)))
