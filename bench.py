@@ -205,12 +205,34 @@ def main():
     def measure(cfgname, M_, reps_min, min_seconds):
         """Engine + runner for one workload; returns (engine, run, snapshot at t = W, per-repetition seconds)."""
         cfg, x, mask = make_workload(cfgname, M_, rank, N, local_rank)
-        # N > 1: engine kernels and the RCCL all-gather share one dedicated (non-default) torch stream
+        # N > 1: the step loop runs INSIDE the engine (dibs_engine_run_sharded): RCCL communicators created by libdibs_hip.so from unique
+        # ids (torch.distributed only carries those bytes and provides the barrier / max-over-ranks of this harness), ncclAllGather issued
+        # on the engine's own streams.  DIBS_BENCH_TORCH_LOOP=1: the Python-driven loop over torch collectives (the test harness).
+        torch_loop = sharded and bool(os.environ.get("DIBS_BENCH_TORCH_LOOP"))
+        # exchange protocol: ONE all-gather of the packed rows per step while the payload is small (128 particles: 0.6 - 2.5 MB per rank, the
+        # collective is latency-bound and the fused kernel matrix of the packed protocol is cheaper than a side stream); the overlapped
+        # exchange (values beside phase A, only gradients between the phases) from 512 particles on, where it takes 20 MB and the
+        # 128 x 1024 kernel slab off the critical path.  DIBS_BENCH_EXCHANGE=packed|overlapped overrides.
+        ex = os.environ.get("DIBS_BENCH_EXCHANGE", "overlapped" if M_ >= 512 else "packed")
+        overlapped = ex == "overlapped"
         tstream = torch.cuda.Stream() if sharded else None
-        eng = Engine(cfg, stream=tstream.cuda_stream if tstream is not None else None)
+        eng = Engine(cfg, stream=tstream.cuda_stream if torch_loop else None)
         eng.set_data(x, mask)
         eng.init_particles(random.PRNGKey(1))
-        if sharded:
+        if sharded and not torch_loop:
+            from dibs_amd.distributed import init_native_comm
+            init_native_comm(eng, None, 2 if overlapped else 1)
+            n_el = eng.plane_elems_per_rank() if overlapped else eng.gather_elems_per_rank()
+            send = torch.zeros(n_el, device="cuda")            # (only for the stand-alone timing of the collective below)
+            recv = torch.zeros(n_el * N, device="cuda")
+
+            def run(t0, n):
+                eng.run_sharded(t0, n, overlapped)
+
+            def restore(snap_):
+                eng.set_state(**snap_)
+                eng.run_sharded(W, 0, overlapped)   # untimed: gathers the values of the restored state (in a run they travel during the step before)
+        elif sharded:
             from dibs_amd.distributed import OverlapBuffers, refresh_values, run_sharded_overlapped
             with torch.cuda.stream(tstream):
                 buf = OverlapBuffers(eng, N, torch.device("cuda", local_rank), torch.float32)
@@ -267,7 +289,9 @@ def main():
         "config": {"workload": c["label"], "name": args.config, "n_vars": d, "n_particles": M, "n_observations": N_OBS,
                    "n_grad_mc_samples": S_MC, "n_acyclicity_mc_samples": SA_MC,
                    "timed_steps": f"t={W}..{W + K - 1} of one trajectory from PRNGKey(1)",
-                   "parallelism": f"particles sharded over {N} rank(s); gradients all-gathered between the phases, values beside phase A" if sharded else "single GPU"},
+                   "parallelism": (f"particles sharded over {N} rank(s), step loop and RCCL all-gathers inside the engine (dibs_engine_run_sharded); "
+                                   + ("ONE all-gather of the packed rows [z | grad_z | theta | grad_theta] per step" if M < 512 and os.environ.get("DIBS_BENCH_EXCHANGE") != "overlapped" else
+                                      "gradients all-gathered between the phases, values beside phase A")) if sharded else "single GPU"},
         "reps": len(rep_s), "timed_seconds_total": float(np.sum(rep_s)),
         "rep_ms_per_step": {"median": 1e3 * elapsed / K, "min": 1e3 * min(rep_s) / K, "max": 1e3 * max(rep_s) / K,
                             "first5": [1e3 * r / K for r in rep_s[:5]]},
@@ -297,9 +321,9 @@ def main():
         ag_us = e0.elapsed_time(e1) / 50 * 1e3
         out["sharded"] = {
             "kernel_us_per_step_by_rank": allk, "allgather_us": ag_us, "allgather_bytes_per_rank": int(send.numel() * 4),
-            "exchange": "overlapped: the values [z | theta] are all-gathered on a side stream right after the optimizer step (beside the next "
-                        "phase A) and the kernel-matrix slab is computed from them on that stream, behind the gather; between phase A and phase B "
-                        "only the gradient rows travel (allgather_us / allgather_bytes_per_rank are THAT collective)",
+            "exchange": "allgather_us / allgather_bytes_per_rank: the collective on the critical path of a step, timed alone through torch.distributed "
+                        "(packed protocol: the rows [z | grad_z | theta | grad_theta]; overlapped protocol: the gradient rows -- the values travel on a "
+                        "side stream beside phase A)",
             "strong_scaling_bound": "128 particles: a rank's step is five dependent launches of 10-24 us that do not shrink with the shard "
                                     "(profiles/round3_shard_scaling.txt: 223 / 173 / 118 / 100 us per rank-step at 1/2/4/8 ranks on one GPU, "
                                     "before the collective) => <= 2.2x at 8 GPUs; the >= 6x of north_star needs per-rank work >> launch "

@@ -13,6 +13,8 @@
 #include "launch.h"
 #include <map>
 #include <mutex>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // declarations only: librccl is bound at run time (dibs_rccl below), libdibs_hip.so does not link it
 #include "kernels_marginal.h"
 #include "kernels_tail.h"
 #include "kernels_joint.h"
@@ -98,6 +100,14 @@ struct dibs_engine {
   std::vector<float> mean_obs;
   // dibs_score_graphs: statistics / device copies of the last (x_ho, mask_ho) scored against (held-out evaluators and mixture weights
   // call it repeatedly with the same data: svgd.py:110-113, 370-372)
+  // in-engine exchange (dibs_engine_comm_init / dibs_engine_run_sharded): RCCL communicators of this rank -- comm[0] on the engine stream,
+  // comm[1] on the side stream of the overlapped protocol -- and the buffers of that protocol
+  ncclComm_t comm[2] = {nullptr, nullptr};
+  int n_comms = 0;
+  float *planes = nullptr, *vsend = nullptr;  // [2][M][Ev] values | gradients of all particles, [Mloc][Ev] this rank's new values
+  hipStream_t side = nullptr;
+  hipEvent_t ev_exported = nullptr, ev_vals = nullptr;
+  bool vals_fresh = false;  // plane 0 (and the kernel slab computed from it) belongs to the engine's current particles
   struct ScoreCache {
     std::vector<float> x;
     std::vector<int32_t> mask;
@@ -154,6 +164,7 @@ static hipError_t dalloc(T** p, size_t n) {
 }
 
 extern "C" int dibs_engine_destroy(dibs_engine* e);
+extern "C" int dibs_engine_comm_destroy(dibs_engine* e);
 // sizes, stream, events and every device buffer of a new engine; on failure the caller destroys the half-built engine
 static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   e->cfg = c;
@@ -376,6 +387,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   for (void* p : ptrs)
     if (p) hipFree(p);
   joint_free(&e->jw);
+  dibs_engine_comm_destroy(e);
   if (e->stream2) hipStreamDestroy(e->stream2);
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
   if (e->ev_join) hipEventDestroy(e->ev_join);
@@ -550,6 +562,7 @@ extern "C" int dibs_engine_init_particles(dibs_engine* e, const uint32_t key[2])
     }
   }
   e->kmat_ext = false;  // (a kernel slab computed by dibs_engine_kmat_values belonged to the particles that were just replaced)
+  e->vals_fresh = false;
   HIP_OK(hipMemsetAsync(e->vz, 0, (size_t)e->Mloc * e->D * 4, e->stream));
   if (e->P) HIP_OK(hipMemsetAsync(e->vtheta, 0, (size_t)e->Mloc * e->P * 4, e->stream));
   HIP_OK(hipMemsetAsync(e->baseline, 0, (size_t)e->Mloc * 4, e->stream));
@@ -564,6 +577,7 @@ extern "C" int dibs_engine_set_state(dibs_engine* e, const float* z, const float
   HIP_OK(hipSetDevice(e->cfg.device_id));
   HIP_OK(hipStreamSynchronize(e->stream));
   const size_t nz = (size_t)e->Mloc * e->D * 4, nt = (size_t)e->Mloc * e->P * 4;
+  if (z || theta) e->vals_fresh = false;
   if (z || theta) e->kmat_ext = false;  // (an externally computed kernel slab belonged to the old values: phase B computes its own unless
                                         //  dibs_engine_kmat_values is called again for the new ones)
   if (z) HIP_OK(hipMemcpy(e->z, z, nz, hipMemcpyHostToDevice));
@@ -1084,6 +1098,180 @@ extern "C" int dibs_engine_eval_gradients(dibs_engine* e, int32_t t, const uint3
   }
   if (e->profiling) drain_timers(e);
   HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// ---- in-engine exchange: RCCL bound at run time, the step loop of a sharded run in C (include/dibs_hip.h) ---------------------------------
+// librccl.so.1 is dlopen'ed on first use: in a process that has imported torch this is torch's bundled copy (same SONAME, already
+// mapped), otherwise ROCm's -- one RCCL per process either way, and libdibs_hip.so loads on machines without it.
+struct dibs_rccl {
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclAllGather) all_gather = nullptr;
+  decltype(&ncclGetErrorString) error_string = nullptr;
+  bool ok = false;
+  std::string why;
+};
+static const dibs_rccl& rccl() {
+  static const dibs_rccl r = [] {
+    dibs_rccl q;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+      q.why = std::string("librccl not found: ") + dlerror();
+      return q;
+    }
+    q.get_unique_id = (decltype(q.get_unique_id))dlsym(h, "ncclGetUniqueId");
+    q.comm_init_rank = (decltype(q.comm_init_rank))dlsym(h, "ncclCommInitRank");
+    q.comm_destroy = (decltype(q.comm_destroy))dlsym(h, "ncclCommDestroy");
+    q.all_gather = (decltype(q.all_gather))dlsym(h, "ncclAllGather");
+    q.error_string = (decltype(q.error_string))dlsym(h, "ncclGetErrorString");
+    q.ok = q.get_unique_id && q.comm_init_rank && q.comm_destroy && q.all_gather && q.error_string;
+    if (!q.ok) q.why = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather / ncclGetErrorString";
+    return q;
+  }();
+  return r;
+}
+#define RCCL_OK(expr)                                                                                    \
+  do {                                                                                                   \
+    ncclResult_t _r = (expr);                                                                            \
+    if (_r != ncclSuccess) return fail(std::string(#expr) + ": " + rccl().error_string(_r));             \
+  } while (0)
+
+static_assert(DIBS_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "include/dibs_hip.h: DIBS_COMM_ID_BYTES");
+
+extern "C" int dibs_comm_unique_id(void* id_out) {
+  if (!id_out) return fail("null argument");
+  if (!rccl().ok) return fail(rccl().why);
+  ncclUniqueId id;
+  RCCL_OK(rccl().get_unique_id(&id));
+  memcpy(id_out, id.internal, NCCL_UNIQUE_ID_BYTES);
+  return 0;
+}
+
+extern "C" int dibs_engine_comm_destroy(dibs_engine* e) {
+  if (!e) return 0;
+  for (int i = 0; i < 2; ++i)
+    if (e->comm[i]) {
+      rccl().comm_destroy(e->comm[i]);
+      e->comm[i] = nullptr;
+    }
+  e->n_comms = 0;
+  if (e->planes) hipFree(e->planes);
+  if (e->vsend) hipFree(e->vsend);
+  e->planes = e->vsend = nullptr;
+  if (e->side) hipStreamDestroy(e->side);
+  if (e->ev_exported) hipEventDestroy(e->ev_exported);
+  if (e->ev_vals) hipEventDestroy(e->ev_vals);
+  e->side = nullptr;
+  e->ev_exported = e->ev_vals = nullptr;
+  return 0;
+}
+
+extern "C" int dibs_engine_comm_init(dibs_engine* e, const void* ids, int32_t n_ids) {
+  if (!e || !ids) return fail("null argument");
+  if (n_ids < 1 || n_ids > 2) return fail("n_ids must be 1 (one all-gather per step) or 2 (overlapped exchange as well)");
+  if (!rccl().ok) return fail(rccl().why);
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  dibs_engine_comm_destroy(e);
+  for (int i = 0; i < n_ids; ++i) {
+    ncclUniqueId id;
+    memcpy(id.internal, (const char*)ids + (size_t)i * NCCL_UNIQUE_ID_BYTES, NCCL_UNIQUE_ID_BYTES);
+    RCCL_OK(rccl().comm_init_rank(&e->comm[i], e->cfg.n_ranks, id, e->cfg.rank));
+  }
+  e->n_comms = n_ids;
+  if (n_ids == 2) {
+    HIP_OK(dalloc(&e->planes, (size_t)2 * e->M * e->Ev));
+    HIP_OK(dalloc(&e->vsend, (size_t)e->Mloc * e->Ev));
+    HIP_OK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&e->ev_exported, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&e->ev_vals, hipEventDisableTiming));
+    HIP_OK(hipDeviceSynchronize());
+  }
+  e->vals_fresh = false;
+  return 0;
+}
+
+extern "C" int dibs_engine_kmat_values(dibs_engine* e, const void* vals_all_dev, void* stream);
+// values of this rank (already in vsend unless `exported`) -> plane 0 of every rank on the side stream, kernel slab behind the gather
+static int exchange_values(dibs_engine* e, bool exported) {
+  if (!exported) {
+    HIP_OK(hipMemcpy2DAsync(e->vsend, (size_t)e->Ev * 4, e->z, (size_t)e->D * 4, (size_t)e->D * 4, (size_t)e->Mloc, hipMemcpyDeviceToDevice, e->stream));
+    if (e->P)
+      HIP_OK(hipMemcpy2DAsync(e->vsend + e->D, (size_t)e->Ev * 4, e->theta, (size_t)e->P * 4, (size_t)e->P * 4, (size_t)e->Mloc,
+                              hipMemcpyDeviceToDevice, e->stream));
+  }
+  HIP_OK(hipEventRecord(e->ev_exported, e->stream));
+  HIP_OK(hipStreamWaitEvent(e->side, e->ev_exported, 0));
+  RCCL_OK(rccl().all_gather(e->vsend, e->planes, (size_t)e->Mloc * e->Ev, ncclFloat, e->comm[1], e->side));
+  if (dibs_engine_kmat_values(e, e->planes, e->side)) return 1;
+  HIP_OK(hipEventRecord(e->ev_vals, e->side));
+  e->vals_fresh = true;
+  return 0;
+}
+
+// replaces _svgd_loop for a particle-sharded run: every rank calls it with the same (t_start, n_steps).  overlapped = 0: phase A -> ONE
+// ncclAllGather of the packed rows [z | grad_z | theta | grad_theta] (in place in the engine's row buffer, on the engine stream) ->
+// phase B.  overlapped = 1: values gathered on the side stream beside phase A, only the gradient rows between the phases.
+extern "C" int dibs_engine_run_sharded(dibs_engine* e, int32_t t_start, int32_t n_steps, int32_t overlapped) {
+  if (!e) return fail("null engine");
+  if (!e->has_data) return fail("dibs_engine_set_data has not been called");
+  if (e->n_comms < 1) return fail("dibs_engine_comm_init has not been called");
+  if (overlapped && e->n_comms < 2) return fail("the overlapped exchange needs two communicators (dibs_engine_comm_init with n_ids = 2)");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  const size_t grad_plane = (size_t)e->M * e->Ev;
+  if (overlapped && !e->vals_fresh && exchange_values(e, false)) return 1;
+  for (int t = t_start; t < t_start + n_steps; ++t) {
+    if (!overlapped) {
+      if (step_local(e, t, packed_rows(e, e->pack))) return 1;
+      RCCL_OK(rccl().all_gather(e->pack + (size_t)e->m0 * e->E, e->pack, (size_t)e->Mloc * e->E, ncclFloat, e->comm[0], e->stream));
+      if (step_update(e, t, packed_source(e, e->pack))) return 1;
+    } else {
+      float* const gplane = e->planes + grad_plane;  // rows [grad_z | grad_theta], indexed by global particle id
+      if (step_local(e, t, RowTarget{gplane, (size_t)e->Ev, 0, 0, (size_t)e->D, 0})) return 1;
+      RCCL_OK(rccl().all_gather(gplane + (size_t)e->m0 * e->Ev, gplane, (size_t)e->Mloc * e->Ev, ncclFloat, e->comm[0], e->stream));
+      HIP_OK(hipStreamWaitEvent(e->stream, e->ev_vals, 0));  // values + kernel slab of this step (gathered during the step before)
+      if (step_update(e, t, plane_source(e, e->planes), e->vsend)) return 1;
+      if (exchange_values(e, true)) return 1;  // values of step t + 1, beside its phase A
+    }
+    if (e->profiling && e->pending.size() > 4096) drain_timers(e);
+  }
+  HIP_OK(hipStreamSynchronize(e->stream));
+  if (overlapped) HIP_OK(hipStreamSynchronize(e->side));
+  if (e->profiling) drain_timers(e);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// z (and theta) of ALL ranks' particles after a sharded run, on every rank: [M][d][k][2] and [M][P] host buffers (either may be NULL).
+// overlapped runs already hold them in plane 0; otherwise one all-gather of the values.
+extern "C" int dibs_engine_gather_particles(dibs_engine* e, float* z_all, float* theta_all) {
+  if (!e) return fail("null engine");
+  if (e->n_comms < 1) return fail("dibs_engine_comm_init has not been called");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  DevBuf<float> tmp_all, tmp_send;
+  const float* vals = nullptr;
+  if (e->n_comms == 2) {
+    if (!e->vals_fresh && exchange_values(e, false)) return 1;
+    HIP_OK(hipStreamSynchronize(e->stream));
+    HIP_OK(hipStreamSynchronize(e->side));
+    vals = e->planes;
+  } else {
+    HIP_OK(tmp_all.alloc((size_t)e->M * e->Ev));
+    HIP_OK(tmp_send.alloc((size_t)e->Mloc * e->Ev));
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy2DAsync(tmp_send.p, (size_t)e->Ev * 4, e->z, (size_t)e->D * 4, (size_t)e->D * 4, (size_t)e->Mloc, hipMemcpyDeviceToDevice, e->stream));
+    if (e->P)
+      HIP_OK(hipMemcpy2DAsync(tmp_send.p + e->D, (size_t)e->Ev * 4, e->theta, (size_t)e->P * 4, (size_t)e->P * 4, (size_t)e->Mloc,
+                              hipMemcpyDeviceToDevice, e->stream));
+    RCCL_OK(rccl().all_gather(tmp_send.p, tmp_all.p, (size_t)e->Mloc * e->Ev, ncclFloat, e->comm[0], e->stream));
+    HIP_OK(hipStreamSynchronize(e->stream));
+    vals = tmp_all.p;
+  }
+  if (z_all) HIP_OK(hipMemcpy2D(z_all, (size_t)e->D * 4, vals, (size_t)e->Ev * 4, (size_t)e->D * 4, (size_t)e->M, hipMemcpyDeviceToHost));
+  if (theta_all && e->P)
+    HIP_OK(hipMemcpy2D(theta_all, (size_t)e->P * 4, vals + e->D, (size_t)e->Ev * 4, (size_t)e->P * 4, (size_t)e->M, hipMemcpyDeviceToHost));
   return 0;
 }
 

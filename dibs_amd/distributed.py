@@ -154,8 +154,53 @@ def _all_particles(eng, buf, n_particles, group):
     return np.ascontiguousarray(v[:, :D]).reshape(n_particles, eng.d, eng.k, 2), (np.ascontiguousarray(v[:, D:D + P]) if P else None)
 
 
+def init_native_comm(engine, group=None, n_comms=2):
+    """RCCL communicator(s) INSIDE the engine (dibs_engine_comm_init): rank 0 draws the unique ids, torch.distributed carries the bytes
+    to the other ranks (control plane only -- the data path of ``engine.run_sharded`` never touches torch)."""
+    import torch.distributed as dist
+    box = [engine.comm_unique_ids(n_comms) if dist.get_rank(group) == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    engine.comm_init(box[0])
+
+
+def sample_sharded_native(dibs, *, key, n_particles, steps, n_dim_particles=None, callback_every=None, callback=None, group=None,
+                          overlapped=True):
+    """``sample`` with the particles sharded over the ranks of ``group`` and the whole step loop, collectives included, inside the engine
+    (``dibs_engine_run_sharded``: ncclAllGather on the engine's own streams).  Every rank calls it with the same arguments and gets
+    the full result (all particles)."""
+    import torch
+    import torch.distributed as dist
+    from . import random
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if n_particles % world:
+        raise ValueError("n_particles must be divisible by the number of ranks")
+    n_dim = n_dim_particles or dibs.n_vars
+    eng = dibs._new_engine(n_particles, n_dim, rank=rank, n_ranks=world, device_id=torch.cuda.current_device())
+    try:
+        init_native_comm(eng, group, 2 if overlapped else 1)
+        eng.init_particles(random.as_key(key))
+        if dibs.latent_prior_std is None:
+            dibs.latent_prior_std = float(np.float32(1.0) / np.sqrt(np.float32(n_dim)))
+        callback_every = callback_every or steps
+        for t in (range(0, steps, callback_every) if steps else range(0)):
+            eng.run_sharded(t, callback_every, overlapped)
+            if callback:
+                zs_all, th_all = eng.gather_particles()
+                kw = dict(dibs=dibs, t=t + callback_every, zs=zs_all)
+                if dibs._joint:
+                    kw["thetas"] = dibs._theta_out(th_all)
+                callback(**kw)
+        out_z, th_all = eng.gather_particles()
+        if dibs._joint:
+            return dibs.particle_to_g_lim(out_z), dibs._theta_out(th_all)
+        return dibs.particle_to_g_lim(out_z)
+    finally:
+        eng.close()
+
+
 def sample_sharded(dibs, *, key, n_particles, steps, n_dim_particles=None, callback_every=None, callback=None, group=None):
-    """``MarginalDiBS.sample`` / ``JointDiBS.sample`` with the particles sharded over the ranks of ``group``.
+    """``MarginalDiBS.sample`` / ``JointDiBS.sample`` with the particles sharded over the ranks of ``group``, the step loop driven from
+    Python with torch.distributed collectives (the harness the in-engine loop of ``sample_sharded_native`` is checked against).
     Every rank calls it with the same arguments and gets the full result (all particles)."""
     import torch
     import torch.distributed as dist

@@ -101,6 +101,34 @@ class Engine:
         _lib.check(self.lib.dibs_engine_step_update_planes(self._h, int(t), C.c_void_p(planes_ptr),
                                                            C.c_void_p(vals_send_ptr) if vals_send_ptr else None))
 
+    # in-engine exchange (include/dibs_hip.h): RCCL communicator(s) of this rank and the sharded step loop in C
+    COMM_ID_BYTES = 128
+
+    def comm_unique_ids(self, n=1):
+        """n fresh RCCL unique ids (bytes of n * 128): call on ONE rank and hand the bytes to every rank"""
+        buf = (C.c_char * (self.COMM_ID_BYTES * n))()
+        for i in range(n):
+            _lib.check(self.lib.dibs_comm_unique_id(C.byref(buf, i * self.COMM_ID_BYTES)))
+        return bytes(buf)
+
+    def comm_init(self, ids):
+        ids = bytes(ids)
+        assert len(ids) in (self.COMM_ID_BYTES, 2 * self.COMM_ID_BYTES)
+        _lib.check(self.lib.dibs_engine_comm_init(self._h, ids, len(ids) // self.COMM_ID_BYTES))
+
+    def comm_destroy(self):
+        _lib.check(self.lib.dibs_engine_comm_destroy(self._h))
+
+    def run_sharded(self, t_start, n_steps, overlapped=False):
+        _lib.check(self.lib.dibs_engine_run_sharded(self._h, int(t_start), int(n_steps), int(bool(overlapped))))
+
+    def gather_particles(self):
+        """z [M, d, k, 2] (and theta [M, P]) of all ranks' particles, on every rank"""
+        z = np.empty((self.M, self.d, self.k, 2), np.float32)
+        th = np.empty((self.M, self.P), np.float32) if self.P else None
+        _lib.check(self.lib.dibs_engine_gather_particles(self._h, _ptr(z), _ptr(th)))
+        return z, th
+
     def eval_gradients(self, t, keys_theta=None, keys_lik=None, keys_prior=None):
         """Gradient estimators of one step for the current particles with explicit per-particle keys (include/dibs_hip.h,
         dibs_engine_eval_gradients).  keys_*: uint32 [Mloc, 2] or None.  Returns a dict with the outputs that were computed."""

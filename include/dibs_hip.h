@@ -169,6 +169,26 @@ int dibs_engine_step_local_grads(dibs_engine* e, int32_t t, void* grads_send_dev
 int dibs_engine_kmat_values(dibs_engine* e, const void* vals_all_dev, void* stream);
 int dibs_engine_step_update_planes(dibs_engine* e, int32_t t, const void* planes_dev, void* vals_send_dev);
 
+/* The exchange INSIDE the engine (north_star: "a single RCCL all-gather over xGMI per step"; no reference counterpart -- the reference has
+ * no multi-device code): the step loop of a particle-sharded run in C, the collective issued by the engine on its own
+ * stream through RCCL (bound at run time: librccl.so.1, in a torch process torch's copy).  One process per GPU:
+ *   rank 0:      dibs_comm_unique_id(id)            once per communicator (DIBS_COMM_ID_BYTES each); the bytes go to every rank by any
+ *                                                   means (MPI, a file, torch.distributed.broadcast_object_list ...)
+ *   every rank:  dibs_engine_comm_init(e, ids, n)   ncclCommInitRank with rank = cfg.rank of cfg.n_ranks on the engine's device;
+ *                                                   n = 1: one communicator; n = 2: a second one for the side stream of the overlapped exchange
+ *                dibs_engine_run_sharded(e, t_start, n_steps, overlapped)   replaces _svgd_loop (svgd.py:269-272 / 724-727), blocking:
+ *                   overlapped = 0:  phase A -> ncclAllGather of the packed rows [z | grad_z | theta | grad_theta] -> phase B   (per step)
+ *                   overlapped = 1:  values [z | theta] all-gathered on a side stream beside phase A (kernel-matrix slab behind the gather),
+ *                                    only the gradient rows between the phases (see the step_update_planes protocol above)
+ *                dibs_engine_gather_particles(e, z_all, theta_all)          all ranks' particles on every rank (sample()'s return value)
+ * Results are bit-identical to dibs_engine_run of a single-rank engine, for any number of ranks. */
+#define DIBS_COMM_ID_BYTES 128
+int dibs_comm_unique_id(void* id_out);
+int dibs_engine_comm_init(dibs_engine* e, const void* ids, int32_t n_ids);
+int dibs_engine_comm_destroy(dibs_engine* e);
+int dibs_engine_run_sharded(dibs_engine* e, int32_t t_start, int32_t n_steps, int32_t overlapped);
+int dibs_engine_gather_particles(dibs_engine* e, float* z_all, float* theta_all);
+
 /* debugging / parity: copy a device buffer to the host (nbytes must match); theta size query */
 int dibs_engine_read_buffer(dibs_engine* e, int32_t which, void* host, int64_t nbytes);
 int64_t dibs_engine_buffer_bytes(const dibs_engine* e, int32_t which);

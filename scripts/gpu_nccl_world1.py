@@ -42,6 +42,14 @@ with torch.cuda.stream(ts):
 zc = c.get_state()["z"]
 print(f"overlapped protocol, RCCL(world 1): {K/dt2:.0f} steps/s; bit-identical: {np.array_equal(zc, b.get_state()['z'])}")
 assert np.array_equal(zc, b.get_state()["z"])
+# the step loop inside the engine (dibs_engine_run_sharded): RCCL bound by libdibs_hip.so itself, no Python between the steps
+for ov in (False, True):
+    n_ = Engine(cfg); n_.set_data(data.x); n_.comm_init(n_.comm_unique_ids(2 if ov else 1)); n_.init_particles(random.PRNGKey(1))
+    n_.run_sharded(0, 20, ov); t0 = time.perf_counter(); n_.run_sharded(20, K, ov); dtn = time.perf_counter() - t0
+    same = np.array_equal(n_.get_state()["z"], b.get_state()["z"])
+    print(f"in-engine loop ({'overlapped' if ov else 'one all-gather per step'}), RCCL(world 1): {K/dtn:.0f} steps/s; bit-identical: {same}")
+    assert same
+    n_.close()
 za, zb = a.get_state()["z"], b.get_state()["z"]
 print(f"per-step python+RCCL(world 1) path: {K/dt:.0f} steps/s; Engine.run: {K/dt1:.0f} steps/s; bit-identical: {np.array_equal(za, zb)}")
 assert np.array_equal(za, zb)

@@ -104,3 +104,43 @@ def test_explicit_keys_reproduce_the_engines_own_step():
     gz, _ = dibs.eltwise_grad_z_likelihood(st["z"], None, st["baseline"], t, k1[1:])
     gp = dibs.eltwise_grad_latent_prior(st["z"], k2[1:], t)
     assert rel_err(gz + gp, total) < 2e-6
+
+
+@pytest.mark.parametrize("joint,overlapped", [(False, False), (False, True), (True, False), (True, True)])
+def test_native_sharded_loop_world1_is_bit_identical_to_engine_run(joint, overlapped):
+    """dibs_engine_run_sharded: the step loop of a sharded run in C with the collective issued by the engine itself through RCCL
+    (ncclCommInitRank from a unique id, ncclAllGather in place on the engine's streams).  One GPU = a communicator of one rank: the whole
+    RCCL call path runs and the result must equal dibs_engine_run bit for bit, for both exchange protocols, including a chunk boundary
+    and a state replaced between chunks (checkpoint restore: the gathered values are stale)."""
+    from dibs_amd.engine import Engine
+    d, M = (12, 8) if joint else (50, 16)
+    data, gm, lm = make_data(d, seed=1, joint=joint)
+    dibs = (JointDiBS if joint else MarginalDiBS)(x=data.x, graph_model=gm, likelihood_model=lm, n_grad_mc_samples=32, n_acyclicity_mc_samples=8)
+    a, b = dibs._new_engine(M, d), dibs._new_engine(M, d)
+    try:
+        b.comm_init(b.comm_unique_ids(2 if overlapped else 1))
+        for e in (a, b):
+            e.init_particles(random.PRNGKey(3))
+        a.run(0, 5)
+        b.run_sharded(0, 3, overlapped)
+        b.run_sharded(3, 2, overlapped)
+        sa, sb = a.get_state(), b.get_state()
+        assert np.array_equal(sa["z"], sb["z"]) and (sa["key"] == sb["key"]).all()
+        if joint:
+            assert np.array_equal(sa["theta"], sb["theta"])
+        z_all, th_all = b.gather_particles()
+        assert np.array_equal(z_all, sa["z"]) and (not joint or np.array_equal(th_all, sa["theta"]))
+        # replaced state between chunks
+        c = dibs._new_engine(M, d)
+        c.init_particles(random.PRNGKey(8))
+        c.run(0, 2)
+        sc = {k: v for k, v in c.get_state().items() if v is not None}
+        c.close()
+        a.set_state(**sc)
+        b.set_state(**sc)
+        a.run(2, 3)
+        b.run_sharded(2, 3, overlapped)
+        assert np.array_equal(a.get_state()["z"], b.get_state()["z"])
+    finally:
+        a.close()
+        b.close()
