@@ -629,6 +629,60 @@ void joint_nn_init_theta(float* theta, size_t P, Key2 key, int m0, int Mloc, int
 
 #ifdef DIBS_TU_NN
 #include "kernels_nn_generic.h"
+#include "kernels_nn_f16.h"
+void dibs_allow_lds(const void* kernel, size_t bytes);  // (engine.hip)
+
+// first layer on the f16 matrix pipe (kernels_nn_f16.h): 33 <= d <= 112, Threefry-paired samples, tables allocated; DIBS_NN_F32=1 keeps
+// the f32-MFMA kernel (A/B runs).  Returns false when the f32 kernel has to run.
+template <int NT>
+static bool joint_nn_logprobs_hf(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P, float* lp) {
+  if constexpr (NT < 3) {
+    return false;
+  } else {
+    static const bool off = getenv("DIBS_NN_F32") != nullptr;
+    const bool paired = jl.layout == 0 && (jl.S & 1) == 0 && (uint64_t)jl.S * jl.d * jl.d < 0xFFFFFFFFull;
+    const bool soft = mode == LIN_MODE_Z_REPARAM;
+    const size_t lds = nhf_lds_bytes(jl.d, NT, np_.H, soft);
+    if (off || !paired || jl.N > 128 || !w->ln_tab || lds > (size_t)160 * 1024 - 512) return false;
+    const size_t pairs = (size_t)jl.Mloc * np_.H * jl.d * (nhf_dp2(jl.d) / 2);
+    if (w->nhf_pairs < pairs) {
+      if (w->nhf_w1s) hipFree(w->nhf_w1s);
+      if (w->nhf_w1p) hipFree(w->nhf_w1p);
+      if (w->nhf_ew) hipFree(w->nhf_ew);
+      w->nhf_w1s = w->nhf_w1p = nullptr;
+      w->nhf_ew = nullptr;
+      w->nhf_pairs = 0;
+      if (hipMalloc(&w->nhf_w1s, pairs * 8) != hipSuccess || hipMalloc(&w->nhf_w1p, pairs * 8) != hipSuccess ||
+          hipMalloc((void**)&w->nhf_ew, (size_t)jl.Mloc * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+      }
+      w->nhf_pairs = pairs;
+    }
+    if (mode == LIN_MODE_THETA) {  // theta is the same for both estimators of a step: the tables are built once (theta runs first)
+      hipLaunchKernelGGL(k_nn_w1_exp, dim3(jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->nhf_ew, jl.d, np_.H);
+      const int npr = jl.d * (nhf_dp2(jl.d) / 2);
+      hipLaunchKernelGGL(k_nn_tables_hf, dim3((npr + 255) / 256, np_.H, jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->nhf_ew,
+                         (float2*)w->nhf_w1s, (uint2*)w->nhf_w1p, jl.d, np_.H);
+    }
+    static const int ppb_env = getenv("DIBS_NN_PPB") ? atoi(getenv("DIBS_NN_PPB")) : 0;
+    const int hS = jl.S / 2, ppb = ppb_env > 0 ? ppb_env : ((hS / 4) * jl.Mloc >= 1024 ? 4 : (hS >= 2 ? 2 : 1));
+#define NHF_LAUNCH(ACT_, SOFT_)                                                                                                               \
+    {                                                                                                                                         \
+      dibs_allow_lds((const void*)k_nn_logprobs_hf<NT, ACT_, SOFT_>, lds);                                                                    \
+      hipLaunchKernelGGL((k_nn_logprobs_hf<NT, ACT_, SOFT_>), dim3((hS + ppb - 1) / ppb, jl.Mloc), dim3(NHF_NTHR), lds, jl.stream, w->x,       \
+                         w->mask, jl.theta, P, jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, ppb, jl.alpha, jl.tau,      \
+                         jl.layout, jl.tiny, np_, w->any_mask, w->ln_tab, (const float2*)w->nhf_w1s, (const uint2*)w->nhf_w1p, w->nhf_ew);    \
+    }
+    if (soft) {
+      if (np_.act == 0) NHF_LAUNCH(0, true) else NHF_LAUNCH(-1, true)
+    } else {
+      if (np_.act == 0) NHF_LAUNCH(0, false) else NHF_LAUNCH(-1, false)
+    }
+#undef NHF_LAUNCH
+    return true;
+  }
+}
 
 template <int NT>
 static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P) {
@@ -659,7 +713,9 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
                        jl.theta, P, jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, spb, jl.alpha, jl.tau, jl.layout,    \
                        jl.tiny, np_, w->any_mask, w->ln_tab, w->w1t);                                                                       \
   }
-  if (lds1 > 80 * 1024) {  // one block per CU: run it with 16 waves
+  if (joint_nn_logprobs_hf<NT>(w, jl, carry, mode, np_, P, lp)) {
+    // (log-probs done on the f16 matrix pipe)
+  } else if (lds1 > 80 * 1024) {  // one block per CU: run it with 16 waves
     if (np_.act == 0) NN_LP_LAUNCH(16, 0) else NN_LP_LAUNCH(16, -1)
   } else {
     if (np_.act == 0) NN_LP_LAUNCH(4, 0) else NN_LP_LAUNCH(4, -1)
