@@ -76,7 +76,7 @@ struct dibs_engine {
   // work
   float* w_tot;     // [Mloc][d][d] total score-space gradient when a particle's W, U, V do not fit in one block's LDS (kernels_tail.h)
   float* acyc_big;  // n_vars > 112: buffers of the global-memory matrix powers (kernels_acyc_big.h)
-  float* eas;       // [Mloc][d][d] exp(-alpha s) of this step (k_edge_scores -> k_acyc_hf); n_vars in 33 .. 64 only
+  float* eas;       // [Mloc][d][d] exp(-alpha s) of this step (k_edge_scores -> k_acyc_hf / k_acyc_hfw); n_vars <= 112 only
   float *scores, *probs, *w_lik, *acyc_part, *w_acyc, *logprobs_z, *logprobs_th, *pack, *kz, *kt, *phi_z, *phi_th;
   uint32_t* thr;
   uint64_t* masks;
@@ -252,7 +252,7 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   HIP_OK(dalloc(&e->baseline2, Ml));
   HIP_OK(dalloc(&e->scores, Ml * dd));
   HIP_OK(dalloc(&e->probs, Ml * dd));
-  if (e->d > 32 && e->d <= 64) HIP_OK(dalloc(&e->eas, Ml * dd));
+  if (e->d <= 112) HIP_OK(dalloc(&e->eas, Ml * dd));
   HIP_OK(dalloc(&e->thr, Ml * dd));
   HIP_OK(dalloc(&e->w_lik, Ml * dd));
   if (e->d > 112) {

@@ -26,14 +26,25 @@ static void launch_nt(const AcycLaunch& a) {
 }
 
 // 33 <= d <= 64 with paired chains: split-bf16 MFMA kernel (kernels_acyc_bf16.h); DIBS_ACYC_F32=1 keeps the f32-MFMA kernel (A/B runs)
+// (d <= 32 as well: the work is tiny there and a launch is pure latency -- k_acyc_hf draws the graph in element order, 2 draws per thread at
+//  d = 20 where the owner-lane order of k_acyc<2> needs up to 16 in a row; DIBS_ACYC_SMALL_F32=1 keeps k_acyc<NT> below 33)
 static bool acyc_use_bf16(const AcycLaunch& a) {
-  static const bool off = getenv("DIBS_ACYC_F32") != nullptr;
-  return !off && a.units != a.Sa && a.d > 32 && a.d <= 64;
+  static const bool off = getenv("DIBS_ACYC_F32") != nullptr, small_f32 = getenv("DIBS_ACYC_SMALL_F32") != nullptr;
+  return !off && a.units != a.Sa && a.d >= (small_f32 ? 33 : 4) && a.d <= 64;
 }
 // 65 <= d <= 112 with paired chains: the same scheme with NT = 5 .. 7 tiles and waves (k_acyc_bfw)
 static bool acyc_use_bfw(const AcycLaunch& a) {
   static const bool off = getenv("DIBS_ACYC_F32") != nullptr;
   return !off && a.units != a.Sa && a.d > 64 && a.d <= 112;
+}
+// two-piece f16 operands for 65 <= d <= 112 (k_acyc_hfw, kernels_acyc_f16.h); DIBS_ACYC_BF16=1 keeps k_acyc_bfw (A/B runs)
+template <int NT>
+static void launch_hfw(const AcycLaunch& a) {
+  const size_t lds = ahfw_lds_bytes(NT);
+  const dim3 grid(a.nblk, (a.Mloc + 7) & ~7);
+  dibs_allow_lds((const void*)k_acyc_hfw<NT>, lds);
+  hipLaunchKernelGGL(k_acyc_hfw<NT>, grid, dim3(64 * NT), lds, a.stream, a.scores, a.eas, a.part, a.carry, a.m0, a.M, a.Mloc, a.d, a.Sa, a.cpb, a.alpha,
+                     a.tau, a.layout, a.tiny, a.nblk);
 }
 template <int NT>
 static void launch_bfw(const AcycLaunch& a) {
@@ -89,7 +100,8 @@ void acyc_launch_power(const AcycLaunch& a) {
   }
   if (acyc_use_bf16(a)) {
     // two-piece f16 operands (kernels_acyc_f16.h: half the matrix instructions); DIBS_ACYC_BF16=1 keeps the three-piece bf16 kernel (A/B runs)
-    static const bool bf16 = getenv("DIBS_ACYC_BF16") != nullptr;
+    static const bool bf16_env = getenv("DIBS_ACYC_BF16") != nullptr;
+    const bool bf16 = bf16_env && a.d > 32;
     const size_t lds = bf16 ? (size_t)2 * ABF_IMG_BYTES : (size_t)AHF_LDS_BYTES;
     const dim3 grid(a.nblk, (a.Mloc + 7) & ~7);
 #define ACYC_BF_LAUNCH(KERNEL_)                                                                                                            \
@@ -120,6 +132,15 @@ void acyc_launch_power(const AcycLaunch& a) {
     return;
   }
   if (acyc_use_bfw(a)) {
+    static const bool bf16w = getenv("DIBS_ACYC_BF16") != nullptr;
+    if (!bf16w) {
+      switch ((a.d + 15) / 16) {
+        case 5: launch_hfw<5>(a); break;
+        case 6: launch_hfw<6>(a); break;
+        default: launch_hfw<7>(a); break;
+      }
+      return;
+    }
     switch ((a.d + 15) / 16) {
       case 5: launch_bfw<5>(a); break;
       case 6: launch_bfw<6>(a); break;

@@ -110,3 +110,60 @@ def test_headline_posterior_400_steps():
     fx, d, cps, eshd, graphs = _device_posterior("headline")
     same64 = _report("headline", fx, cps, eshd, graphs)
     _check("headline", fx, d, cps, eshd, same64)
+
+
+# ---- joint models at BASELINE's step counts: config 3 (JointDiBS + LinearGaussian, d=50, 128 particles, 2000 steps, 8 seeds) and config 5
+# ---- (JointDiBS + DenseNN (5,), d=100, 256 particles, interv_mask, 100 steps, 4 seeds).  Oracle trajectories (float64 build; float32 build
+# ---- for a subset of the seeds as the yardstick) from tests/golden/make_joint_golden.py, run on the GPU box's host cores.
+def _device_joint(name):
+    import importlib.util
+    from dibs_amd.engine import Engine
+    spec = importlib.util.spec_from_file_location("make_joint_golden", os.path.join(GOLDEN, "make_joint_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    fx = np.load(os.path.join(GOLDEN, f"posterior_{name}.npz"))
+    d, M, cps = int(fx["d"]), int(fx["M"]), [int(c) for c in fx["checkpoints"]]
+    seeds = [int(v) for v in fx["seeds_f64"]]
+    out = dict(eshd=np.zeros((len(seeds), len(cps))), graphs=np.zeros_like(fx["graphs_f64"]), z_keep=np.zeros_like(fx["z_keep_f64"]),
+               t_keep=np.zeros_like(fx["t_keep_f64"]), edges=np.zeros((len(seeds), len(cps))))
+    for si, s in enumerate(seeds):
+        dibs, x, mask, g_true = gen.workload(name, s)
+        eng = Engine(dibs._make_config(M, d))
+        eng.set_data(x, mask)
+        eng.init_particles(random.PRNGKey(s + 1))
+        t = 0
+        for ci, cp in enumerate(cps):
+            eng.run(t, cp - t)
+            t = cp
+            st = eng.get_state()
+            sm = gen.summarise(dibs, g_true, st["z"], st["theta"], d, M)
+            out["eshd"][si, ci], out["edges"][si, ci], out["graphs"][si, ci] = sm["eshd"], sm["edges"], sm["graphs"]
+            out["z_keep"][si, ci], out["t_keep"][si, ci] = sm["z_keep"], sm["t_keep"]
+        eng.close()
+    return fx, d, M, cps, seeds, out
+
+
+def _joint_report(name, fx, cps, seeds, out):
+    """per checkpoint: share of particles whose graph equals the f64 oracle's, E-SHD difference, Z / theta deviation of the stored particles
+    (relative to max |.| of the f64 oracle's whole state) -- for the device and, where a float32 oracle trajectory exists, for that"""
+    rows = {}
+    s32 = {int(v): i for i, v in enumerate(fx["seeds_f32"])} if "seeds_f32" in fx else {}
+    for ci, cp in enumerate(cps):
+        same = (out["graphs"][:, ci] == fx["graphs_f64"][:, ci]).all(axis=2).mean(axis=1)
+        de = out["eshd"][:, ci] - fx["eshd_f64"][:, ci]
+        ez = np.abs(out["z_keep"][:, ci] - fx["z_keep_f64"][:, ci]).reshape(len(seeds), -1).max(axis=1) / fx["zmax_f64"][:, ci]
+        et = np.abs(out["t_keep"][:, ci] - fx["t_keep_f64"][:, ci]).reshape(len(seeds), -1).max(axis=1) / fx["tmax_f64"][:, ci]
+        rows[cp] = dict(same=same, de=de, ez=ez, et=et)
+        line = (f"{name} step {cp}: identical graphs gpu/f64 {np.round(same, 3)}  dE-SHD {np.round(de, 3)}  "
+                f"rel dZ {np.array2string(ez, precision=1)}  rel dtheta {np.array2string(et, precision=1)}")
+        if s32:
+            idx = [seeds.index(s) for s in s32 if s in seeds]
+            j32 = [s32[seeds[i]] for i in idx]
+            same32 = (fx["graphs_f32"][j32, ci] == fx["graphs_f64"][idx, ci]).all(axis=2).mean(axis=1)
+            de32 = fx["eshd_f32"][j32, ci] - fx["eshd_f64"][idx, ci]
+            ez32 = np.abs(fx["z_keep_f32"][j32, ci] - fx["z_keep_f64"][idx, ci]).reshape(len(idx), -1).max(axis=1) / fx["zmax_f64"][idx, ci]
+            et32 = np.abs(fx["t_keep_f32"][j32, ci] - fx["t_keep_f64"][idx, ci]).reshape(len(idx), -1).max(axis=1) / fx["tmax_f64"][idx, ci]
+            line += (f"   |   f32 oracle (seeds {[seeds[i] for i in idx]}): identical {np.round(same32, 3)}  dE-SHD {np.round(de32, 3)}  "
+                     f"rel dZ {np.array2string(ez32, precision=1)}  rel dtheta {np.array2string(et32, precision=1)}")
+        print(line)
+    return rows
