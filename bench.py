@@ -91,15 +91,18 @@ def roofline_of(dom, avg_s, cfgname, M, K, eng_counters):
         flops = M * SA_MC * n_mm * 2 * d ** 3
         roof.update(flops_per_launch=flops, achieved=flops / avg_s / 1e12,
                     flops_model=f"M*Sa*c(d-1)*2*d^3, c({d - 1})={n_mm} matmuls of binary powering (SURVEY 8(d) F_acyc)")
-        if 32 < d <= 64:
-            # float products evaluated on the bf16 matrix pipe with three-way split operands (6 bf16 MFMAs per float product block,
-            # kernels_acyc_bf16.h).  `achieved` / `frac` price the ALGORITHMIC float flops against the FP32 peak; the bf16 flops the
-            # kernel actually issues (64-padded tiles, 6 products) are priced against the dense bf16 peak next to it.
-            bf16_flops = M * SA_MC * n_mm * 6 * 2 * 64 ** 3
-            roof.update(rocprof_kernel="k_acyc_bf<true>" if d > 48 else "k_acyc_bf<false>",
-                        pipe="mfma_bf16 (3-way split operands: 6 bf16 products per f32 product)",
-                        executed_bf16_tflops=bf16_flops / avg_s / 1e12, peak_bf16_tflops=PEAK_BF16_TFLOPS,
-                        frac_of_bf16_peak=bf16_flops / avg_s / 1e12 / PEAK_BF16_TFLOPS)
+        if d <= 112 and not os.environ.get("DIBS_ACYC_F32"):
+            # float products evaluated on the f16 matrix pipe with two block-scaled pieces per operand (3 f16 MFMAs of 16 cycles per
+            # 16 x 16 x 32 block, kernels_acyc_f16.h).  `achieved` / `frac` price the ALGORITHMIC float flops against the FP32 peak; the f16
+            # flops the kernel actually issues (16-padded tiles, 32-padded contraction, 3 products) against the dense 16-bit peak next to it.
+            nt = 4 if d <= 64 else (d + 15) // 16
+            rows = (64 if d > 48 else 48) if d <= 64 else 16 * nt
+            kdim = 64 if d <= 64 else 32 * ((nt + 1) // 2)
+            f16_flops = M * SA_MC * n_mm * 3 * 2 * rows * rows * kdim
+            roof.update(rocprof_kernel=(f"k_acyc_hf<{'true' if d > 48 else 'false'}, 3>" if d <= 64 else f"k_acyc_hfw<{nt}>"),
+                        pipe="mfma_f16 (2 block-scaled pieces per operand: 3 f16 products per f32 product)",
+                        executed_f16_tflops=f16_flops / avg_s / 1e12, peak_f16_tflops=PEAK_BF16_TFLOPS,
+                        frac_of_f16_peak=f16_flops / avg_s / 1e12 / PEAK_BF16_TFLOPS)
         else:
             roof.update(rocprof_kernel=f"k_acyc<{(d + 15) // 16}, true>", pipe="mfma_f32")
     elif dom == "bge_big":
@@ -123,13 +126,14 @@ def roofline_of(dom, avg_s, cfgname, M, K, eng_counters):
             # k_lin_logprobs_bf: the float products run on the bf16 matrix pipe with three-way split operands (as k_acyc_bf above):
             # `achieved` / `frac` price the algorithmic float flops against the FP32 peak, the bf16 flops actually issued (row tiles of 16
             # observations, 64-padded contraction, 16-wide column tiles, 6 products) against the dense bf16 peak next to it.
-            bf16_flops = 2 * M * S_MC * 6 * 2 * (16 * ((N_OBS + 15) // 16)) * 64 * (64 if d > 48 else 48)
-            roof.update(rocprof_kernel="k_lin_logprobs_bf", pipe="mfma_bf16 (3-way split operands: 6 bf16 products per f32 product)",
-                        executed_bf16_tflops=bf16_flops / avg_s / 1e12, peak_bf16_tflops=PEAK_BF16_TFLOPS,
-                        frac_of_bf16_peak=bf16_flops / avg_s / 1e12 / PEAK_BF16_TFLOPS)
+            f16_flops = 2 * M * S_MC * 3 * 2 * (16 * ((N_OBS + 15) // 16)) * 64 * (64 if d > 48 else 48)
+            roof.update(rocprof_kernel="k_lin_logprobs_hf", pipe="mfma_f16 (2 block-scaled pieces per operand: 3 f16 products per f32 product)",
+                        executed_f16_tflops=f16_flops / avg_s / 1e12, peak_f16_tflops=PEAK_BF16_TFLOPS,
+                        frac_of_f16_peak=f16_flops / avg_s / 1e12 / PEAK_BF16_TFLOPS)
     elif dom in ("nn_theta", "nn_z"):
         flops = M * S_MC * d * (2 * N_OBS * d * H + 2 * N_OBS * H)
-        roof.update(rocprof_kernel="k_nn_logprobs + k_nn_grad", pipe="mfma_f32", flops_per_launch=flops, achieved=flops / avg_s / 1e12,
+        roof.update(rocprof_kernel="k_nn_logprobs_hf + k_nn_grad", pipe="mfma_f16 (log-probs: 2 block-scaled pieces per operand) + mfma_f32 (gradients of the samples with non-zero weight)",
+                    flops_per_launch=flops, achieved=flops / avg_s / 1e12,
                     flops_model="M*S*d*(2NdH + 2NH): forward pass of one estimator (a third of SURVEY 8(d) F_lik(NN) per estimator)")
     elif dom in ("phi_update", "kmat"):
         # particle-coupling kernels (dominant only with many particles on one GPU): vector-ALU kernels on packed f32
@@ -352,7 +356,7 @@ def main():
         roof.update(launches=dom_n, share_of_step=dom_ms / total_ms,
                     duration="kernel alone on the GPU (the step is serialised while timing); in the timed region the acyclicity kernel runs on "
                              "its second stream beside the likelihood kernels, see kernel_us_per_step_concurrent / frac_concurrent")
-        for tag in ("round3", "round2"):   # separate rocprofv3 --pmc passes of this command (scripts/collect_profiles.sh)
+        for tag in ("round4", "round3", "round2"):   # separate rocprofv3 --pmc passes of this command (scripts/collect_profiles.sh)
             suffix = "" if args.config == "headline" else f"_cfg{args.config}"
             pmc = os.path.join(ROOT, "profiles", f"{tag}{suffix}_pmc_hbm.json")
             if os.path.exists(pmc):
