@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   for (int c = 0; c < cpb; ++c) {
     const int unit = blk * cpb + c;
     if (unit >= n_units) break;
+    uint32_t live_pair = 3u;
     // Soft graphs of BOTH chains of the pair, drawn in ELEMENT order -- thread tid takes elements e = tid, tid + 256, ... of the d x d
     // matrix: every lane busy (10 wave-draws per wave at d = 50 where the owner-lane order needs 14, the fourth wave's and the fourth
     // column tile's mostly for idle lanes), the Threefry counter is base + e, the score loads are coalesced and requested together --
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       const int qa = 256 / d, qb = 256 - qa * d;
       int ea_ = tid / d, eb_ = tid - ea_ * d;
       float s_next = tid < ndd ? sm[tid] : 0.f;  // (the next draw's score is requested one draw ahead)
+      bool lv0 = false, lv1 = false;
       const uint32_t cbase = (uint32_t)((uint64_t)sa * dd), chalf = (uint32_t)(nbits >> 1);
       for (int k = 0; k < ndraw; ++k) {
         const int e = tid + 256 * k;
@@ -220,6 +222,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
               gv1 = 1.0f / (1.0f + expf(-tau * (rng_logistic(y1, tiny) + ea)));
             }
           }
+          lv0 |= gv0 != 0.f && gv0 != 1.0f;
+          lv1 |= gv1 != 0.f && gv1 != 1.0f;
           G0[ea_ * AHF_LDT + eb_] = gv0;
           G1[ea_ * AHF_LDT + eb_] = gv1;
         }
@@ -229,6 +233,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
           eb_ -= d;
           ++ea_;
         }
+      }
+      {
+        // A chain whose soft graph is saturated everywhere (every g exactly 0 or 1, i.e. g (1 - g) = 0 on all edges -- the normal case once
+        // alpha s has grown past ~17 on every edge, a few hundred steps into a run) contributes exactly zero (the matrix power is finite:
+        // entries < 2^d): its seven products are skipped.  Bit 0 / 1: chain 0 / 1 of the pair has a live edge; one word per wave and pair
+        // parity, written before the barrier below and read behind it (no atomics, nothing to reset).
+        const uint32_t wl = (__builtin_amdgcn_ballot_w64(lv0) != 0ull ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(lv1) != 0ull ? 2u : 0u);
+        if (lane == 0) slots[8 + 4 * (c & 1) + wave] = wl;
       }
       __syncthreads();
 #pragma unroll
@@ -249,6 +261,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         g[tj] = v0;
         gnext[tj] = v1;
       }
+      {  // flags of the pair's two chains (see the draw loop): OR over the waves
+        const abf_u32x4 lw = *reinterpret_cast<const abf_u32x4*>(slots + 8 + 4 * (c & 1));
+        live_pair = lw.x | lw.y | lw.z | lw.w;
+      }
       __syncthreads();  // the images are written next
     }
     for (int hf = 0; hf < 2; ++hf) {
@@ -256,6 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
         for (int tj = 0; tj < AHF_NT; ++tj) g[tj] = gnext[tj];
       }
+      if (!((live_pair >> hf) & 1u)) continue;  // (block-uniform)
       AhfFrag A;
       f32x4 acc[AHF_NT];
       abf_m0(g, acc, a, b0, d, inv_d);
