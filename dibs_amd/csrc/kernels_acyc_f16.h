@@ -101,8 +101,40 @@ __device__ __forceinline__ void ahf_group(f32x4 (&acc)[AHF_NT], const AhfFrag& A
 #pragma unroll
   for (int u = 0; u < NU; ++u) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[u][0], ah, acc[tp + u], 0, 0, 0);
 }
+// AHF_ORDER (experiment switch, default 0): 0 = per k-step small terms then the large one, all in one accumulator; 1 = the small terms of BOTH
+// k-steps first, then the large ones (fragments of the large term read again); 2 = small terms in an accumulator of their own, added at the end
+#ifndef AHF_ORDER
+#define AHF_ORDER 0
+#endif
+template <int NU, bool SMALL, bool BIG>
+__device__ __forceinline__ void ahf_group_part(f32x4 (&acc)[AHF_NT], const AhfFrag& A, const unsigned char* img, int rd_off, int ks, int tp, bool first) {
+  ahf_f16x8 b[NU][2];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    b[u][0] = ahf_tr_pair(img + rd_off + (tp + u) * AHF_TILE_BYTES + ks * 32 * 32);
+    if (SMALL) b[u][1] = ahf_tr_pair(img + rd_off + AHF_PIECE_BYTES + (tp + u) * AHF_TILE_BYTES + ks * 32 * 32);
+  }
+  const ahf_f16x8 ah = __builtin_bit_cast(ahf_f16x8, A.a[ks][0]), am = __builtin_bit_cast(ahf_f16x8, A.a[ks][1]);
+  if (SMALL) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (first) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[u][1], ah, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      else acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[u][1], ah, acc[tp + u], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[u][0], am, acc[tp + u], 0, 0, 0);
+  }
+  if (BIG) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (first && !SMALL) acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[u][0], ah, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      else acc[tp + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[u][0], ah, acc[tp + u], 0, 0, 0);
+    }
+  }
+}
 template <bool FOUR>
 __device__ __forceinline__ void ahf_matmul(f32x4 (&acc)[AHF_NT], const AhfFrag& A, const unsigned char* img, int rd_off) {
+#if AHF_ORDER == 0
   ahf_group<2>(acc, A, img, rd_off, 0, 0);
   if constexpr (FOUR) {
     ahf_group<2>(acc, A, img, rd_off, 0, 2);
@@ -114,6 +146,32 @@ __device__ __forceinline__ void ahf_matmul(f32x4 (&acc)[AHF_NT], const AhfFrag& 
     ahf_group<1>(acc, A, img, rd_off, 1, 2);
     acc[3] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+#elif AHF_ORDER == 1
+  constexpr int N2 = FOUR ? 2 : 1;
+  ahf_group_part<2, true, false>(acc, A, img, rd_off, 0, 0, true);
+  ahf_group_part<N2, true, false>(acc, A, img, rd_off, 0, 2, true);
+  ahf_group_part<2, true, false>(acc, A, img, rd_off, 1, 0, false);
+  ahf_group_part<N2, true, false>(acc, A, img, rd_off, 1, 2, false);
+  ahf_group_part<2, false, true>(acc, A, img, rd_off, 0, 0, false);
+  ahf_group_part<N2, false, true>(acc, A, img, rd_off, 0, 2, false);
+  ahf_group_part<2, false, true>(acc, A, img, rd_off, 1, 0, false);
+  ahf_group_part<N2, false, true>(acc, A, img, rd_off, 1, 2, false);
+  if (!FOUR) acc[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
+  constexpr int N2 = FOUR ? 2 : 1;
+  f32x4 sm_[AHF_NT];
+  ahf_group_part<2, true, false>(sm_, A, img, rd_off, 0, 0, true);
+  ahf_group_part<2, false, true>(acc, A, img, rd_off, 0, 0, true);
+  ahf_group_part<N2, true, false>(sm_, A, img, rd_off, 0, 2, true);
+  ahf_group_part<N2, false, true>(acc, A, img, rd_off, 0, 2, true);
+  ahf_group_part<2, true, false>(sm_, A, img, rd_off, 1, 0, false);
+  ahf_group_part<2, false, true>(acc, A, img, rd_off, 1, 0, false);
+  ahf_group_part<N2, true, false>(sm_, A, img, rd_off, 1, 2, false);
+  ahf_group_part<N2, false, true>(acc, A, img, rd_off, 1, 2, false);
+#pragma unroll
+  for (int tj = 0; tj < (FOUR ? 4 : 3); ++tj) acc[tj] += sm_[tj];
+  if (!FOUR) acc[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
 }
 
 // largest of the wave's 16 x 64 accumulator values (all >= 0: bit patterns compare as integers), in every lane's SGPR copy
@@ -392,7 +450,7 @@ struct Ahfw {
 };
 __host__ __device__ inline size_t ahfw_lds_bytes(int nt) {
   const size_t nks = (size_t)(nt + 1) / 2, img = 2 * (size_t)nt * 32 * nks * 32, t = (size_t)16 * nt * (16 * nt + 4) * 4;
-  return 2 * (img > t ? img : t) + 64;
+  return 2 * (img > t ? img : t) + 128;
 }
 template <int NT>
 struct AhfwFrag {
@@ -502,6 +560,7 @@ __global__ __launch_bounds__(64 * NT) void k_acyc_hfw(const float* __restrict__ 
   for (int c = 0; c < cpb; ++c) {
     const int unit = blk * cpb + c;
     if (unit >= n_units) break;
+    uint32_t live_pair = 3u;
     // soft graphs of both chains of the pair in element order, handed to the owning lanes through LDS (see k_acyc_hf)
     {
       const int sa = unit;
@@ -511,6 +570,7 @@ __global__ __launch_bounds__(64 * NT) void k_acyc_hfw(const float* __restrict__ 
       const int qa = G::NTHR / d, qb = G::NTHR - qa * d;
       int ea_ = tid / d, eb_ = tid - ea_ * d;
       float s_next = tid < ndd ? sm[tid] : 0.f;
+      bool lv0 = false, lv1 = false;  // chain 0 / 1 of the pair has an edge that is not saturated (see k_acyc_hf)
       const uint32_t cbase = (uint32_t)((uint64_t)sa * dd), chalf = (uint32_t)(nbits >> 1);
       for (int k = 0; k < ndraw; ++k) {
         const int e = tid + G::NTHR * k;
@@ -533,6 +593,8 @@ __global__ __launch_bounds__(64 * NT) void k_acyc_hfw(const float* __restrict__ 
               gv1 = 1.0f / (1.0f + expf(-tau * (rng_logistic(y1, tiny) + ea)));
             }
           }
+          lv0 |= gv0 != 0.f && gv0 != 1.0f;
+          lv1 |= gv1 != 0.f && gv1 != 1.0f;
           G0[ea_ * G::LDT + eb_] = gv0;
           G1[ea_ * G::LDT + eb_] = gv1;
         }
@@ -543,7 +605,14 @@ __global__ __launch_bounds__(64 * NT) void k_acyc_hfw(const float* __restrict__ 
           ++ea_;
         }
       }
+      {
+        const uint32_t wl = (__builtin_amdgcn_ballot_w64(lv0) != 0ull ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(lv1) != 0ull ? 2u : 0u);
+        if (lane == 0) slots[16 + 8 * (c & 1) + wave] = wl;
+      }
       __syncthreads();
+      live_pair = 0u;
+#pragma unroll
+      for (int w8 = 0; w8 < NT; ++w8) live_pair |= slots[16 + 8 * (c & 1) + w8];
 #pragma unroll
       for (int tj = 0; tj < NT; ++tj) {
         f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
@@ -577,6 +646,7 @@ __global__ __launch_bounds__(64 * NT) void k_acyc_hfw(const float* __restrict__ 
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj) g[tj] = gnext[tj];
       }
+      if (!((live_pair >> hf) & 1u)) continue;  // (block-uniform: a chain saturated everywhere contributes exactly zero)
       AhfwFrag<NT> A;
       f32x4 acc[NT];
       abfw_m0<NT>(g, acc, a, b0, d, inv_d);

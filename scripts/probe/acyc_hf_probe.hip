@@ -78,6 +78,19 @@ static void run(int d, int Mloc, int Sa, float alpha, float sscale, int cpb, boo
       e[v] = fmax(e[v], fabs(acc[i] - s));
       if (fabs(acc[i]) > 1e-30 * maxref && fabs(acc[i]) > 0) eel[v] = fmax(eel[v], fabs(acc[i] - s) / fabs(acc[i]));
     }
+  {  // signed statistics of the relative error on the entries that matter (|ref| > 1e-3 max): a bias shows as mean != 0
+    for (int v = 0; v < 2; ++v) {
+      double sum = 0, sum2 = 0; int n = 0;
+      for (int i = 0; i < d*d; ++i) {
+        if (fabs(acc[i]) < 1e-3 * maxref) continue;
+        double s = 0;
+        for (int b = 0; b < nblk; ++b) s += p[v][(size_t)b*d*d + i];
+        const double r = (s - acc[i]) / acc[i];
+        sum += r; sum2 += r * r; ++n;
+      }
+      if (n) printf("   %s signed rel err: mean %+.3e  sd %.3e  (n=%d)\n", v ? "f16x2 " : "bf16x3", sum / n, sqrt(sum2 / n - (sum / n) * (sum / n)), n);
+    }
+  }
   printf("d=%d Mloc=%d Sa=%d alpha=%g sscale=%g cpb=%d sync=%s max|ref|=%.3g\n   vs double, relative to max (elementwise): bf16x3 %.3g (%.3g) nan %d | f16x2 wpe3 %.3g (%.3g) nan %d | f16x2 wpe4 %.3g (%.3g) nan %d\n",
          d, Mloc, Sa, alpha, sscale, cpb, hipGetErrorName(e2), maxref, e[0] / maxref, eel[0], nan[0], e[1] / maxref, eel[1], nan[1], e[2] / maxref, eel[2], nan[2]);
   if (timing) {
