@@ -25,6 +25,9 @@
 // Layout, lane mapping, swapped-operand MFMA, transposing reads and the chunk rotation of the image are those of k_acyc_bf
 // (kernels_acyc_bf16.h); an image has two pieces (16 KiB), two images + the float staging rows of the epilogue 34 KiB per block:
 // four blocks per CU at 128 registers.
+// Measured and dropped: skipping the seven products of a chain whose soft graph is saturated everywhere (g (1 - g) = 0 on all edges, the
+// contribution is exactly zero) -- a flag per chain from the draw loop costs 2-3 us per launch and never fires: at t = 100 ... 1 000 of the
+// headline trajectory every chain keeps live edges (74.9 us per launch throughout, scripts/gpu_steady_bench.py).
 // grid = (ceil(Sa / 2 / cpb), Mloc rounded up to 8; re-indexed XCD-aware inside), block = 256, dynamic LDS = AHF_LDS_BYTES
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 ahf_f16x8 __attribute__((ext_vector_type(8)));
@@ -242,7 +245,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   for (int c = 0; c < cpb; ++c) {
     const int unit = blk * cpb + c;
     if (unit >= n_units) break;
-    uint32_t live_pair = 3u;
     // Soft graphs of BOTH chains of the pair, drawn in ELEMENT order -- thread tid takes elements e = tid, tid + 256, ... of the d x d
     // matrix: every lane busy (10 wave-draws per wave at d = 50 where the owner-lane order needs 14, the fourth wave's and the fourth
     // column tile's mostly for idle lanes), the Threefry counter is base + e, the score loads are coalesced and requested together --
@@ -256,7 +258,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       const int qa = 256 / d, qb = 256 - qa * d;
       int ea_ = tid / d, eb_ = tid - ea_ * d;
       float s_next = tid < ndd ? sm[tid] : 0.f;  // (the next draw's score is requested one draw ahead)
-      bool lv0 = false, lv1 = false;
       const uint32_t cbase = (uint32_t)((uint64_t)sa * dd), chalf = (uint32_t)(nbits >> 1);
       for (int k = 0; k < ndraw; ++k) {
         const int e = tid + 256 * k;
@@ -280,8 +281,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
               gv1 = 1.0f / (1.0f + expf(-tau * (rng_logistic(y1, tiny) + ea)));
             }
           }
-          lv0 |= gv0 != 0.f && gv0 != 1.0f;
-          lv1 |= gv1 != 0.f && gv1 != 1.0f;
           G0[ea_ * AHF_LDT + eb_] = gv0;
           G1[ea_ * AHF_LDT + eb_] = gv1;
         }
@@ -291,14 +290,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
           eb_ -= d;
           ++ea_;
         }
-      }
-      {
-        // A chain whose soft graph is saturated everywhere (every g exactly 0 or 1, i.e. g (1 - g) = 0 on all edges -- the normal case once
-        // alpha s has grown past ~17 on every edge, a few hundred steps into a run) contributes exactly zero (the matrix power is finite:
-        // entries < 2^d): its seven products are skipped.  Bit 0 / 1: chain 0 / 1 of the pair has a live edge; one word per wave and pair
-        // parity, written before the barrier below and read behind it (no atomics, nothing to reset).
-        const uint32_t wl = (__builtin_amdgcn_ballot_w64(lv0) != 0ull ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(lv1) != 0ull ? 2u : 0u);
-        if (lane == 0) slots[8 + 4 * (c & 1) + wave] = wl;
       }
       __syncthreads();
 #pragma unroll
@@ -319,10 +310,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         g[tj] = v0;
         gnext[tj] = v1;
       }
-      {  // flags of the pair's two chains (see the draw loop): OR over the waves
-        const abf_u32x4 lw = *reinterpret_cast<const abf_u32x4*>(slots + 8 + 4 * (c & 1));
-        live_pair = lw.x | lw.y | lw.z | lw.w;
-      }
       __syncthreads();  // the images are written next
     }
     for (int hf = 0; hf < 2; ++hf) {
@@ -330,7 +317,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
         for (int tj = 0; tj < AHF_NT; ++tj) g[tj] = gnext[tj];
       }
-      if (!((live_pair >> hf) & 1u)) continue;  // (block-uniform)
       AhfFrag A;
       f32x4 acc[AHF_NT];
       abf_m0(g, acc, a, b0, d, inv_d);
@@ -560,7 +546,6 @@ __global__ __launch_bounds__(64 * NT) void k_acyc_hfw(const float* __restrict__ 
   for (int c = 0; c < cpb; ++c) {
     const int unit = blk * cpb + c;
     if (unit >= n_units) break;
-    uint32_t live_pair = 3u;
     // soft graphs of both chains of the pair in element order, handed to the owning lanes through LDS (see k_acyc_hf)
     {
       const int sa = unit;
@@ -570,7 +555,6 @@ __global__ __launch_bounds__(64 * NT) void k_acyc_hfw(const float* __restrict__ 
       const int qa = G::NTHR / d, qb = G::NTHR - qa * d;
       int ea_ = tid / d, eb_ = tid - ea_ * d;
       float s_next = tid < ndd ? sm[tid] : 0.f;
-      bool lv0 = false, lv1 = false;  // chain 0 / 1 of the pair has an edge that is not saturated (see k_acyc_hf)
       const uint32_t cbase = (uint32_t)((uint64_t)sa * dd), chalf = (uint32_t)(nbits >> 1);
       for (int k = 0; k < ndraw; ++k) {
         const int e = tid + G::NTHR * k;
@@ -593,8 +577,6 @@ __global__ __launch_bounds__(64 * NT) void k_acyc_hfw(const float* __restrict__ 
               gv1 = 1.0f / (1.0f + expf(-tau * (rng_logistic(y1, tiny) + ea)));
             }
           }
-          lv0 |= gv0 != 0.f && gv0 != 1.0f;
-          lv1 |= gv1 != 0.f && gv1 != 1.0f;
           G0[ea_ * G::LDT + eb_] = gv0;
           G1[ea_ * G::LDT + eb_] = gv1;
         }
@@ -605,14 +587,7 @@ __global__ __launch_bounds__(64 * NT) void k_acyc_hfw(const float* __restrict__ 
           ++ea_;
         }
       }
-      {
-        const uint32_t wl = (__builtin_amdgcn_ballot_w64(lv0) != 0ull ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(lv1) != 0ull ? 2u : 0u);
-        if (lane == 0) slots[16 + 8 * (c & 1) + wave] = wl;
-      }
       __syncthreads();
-      live_pair = 0u;
-#pragma unroll
-      for (int w8 = 0; w8 < NT; ++w8) live_pair |= slots[16 + 8 * (c & 1) + w8];
 #pragma unroll
       for (int tj = 0; tj < NT; ++tj) {
         f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
@@ -646,7 +621,6 @@ __global__ __launch_bounds__(64 * NT) void k_acyc_hfw(const float* __restrict__ 
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj) g[tj] = gnext[tj];
       }
-      if (!((live_pair >> hf) & 1u)) continue;  // (block-uniform: a chain saturated everywhere contributes exactly zero)
       AhfwFrag<NT> A;
       f32x4 acc[NT];
       abfw_m0<NT>(g, acc, a, b0, d, inv_d);

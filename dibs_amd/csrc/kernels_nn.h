@@ -670,8 +670,8 @@ static bool joint_nn_logprobs_hf(JointWork* w, const JointLaunch& jl, Key2 carry
 #define NHF_LAUNCH(ACT_, SOFT_)                                                                                                               \
     {                                                                                                                                         \
       dibs_allow_lds((const void*)k_nn_logprobs_hf<NT, ACT_, SOFT_>, lds);                                                                    \
-      hipLaunchKernelGGL((k_nn_logprobs_hf<NT, ACT_, SOFT_>), dim3((hS + ppb - 1) / ppb, jl.Mloc), dim3(NHF_NTHR), lds, jl.stream, w->x,       \
-                         w->mask, jl.theta, P, jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, ppb, jl.alpha, jl.tau,      \
+      hipLaunchKernelGGL((k_nn_logprobs_hf<NT, ACT_, SOFT_>), dim3((hS + ppb - 1) / ppb, (jl.Mloc + 7) & ~7), dim3(NHF_NTHR), lds, jl.stream, \
+                         w->x, w->mask, jl.theta, P, jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.Mloc, jl.d, jl.N, jl.S, ppb, jl.alpha, jl.tau, \
                          jl.layout, jl.tiny, np_, w->any_mask, w->ln_tab, (const float2*)w->nhf_w1s, (const uint2*)w->nhf_w1p, w->nhf_ew);    \
     }
     if (soft) {

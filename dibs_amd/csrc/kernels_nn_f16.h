@@ -2,6 +2,7 @@
 #pragma once
 #include "kernels_nn.h"
 #include "kernels_acyc_f16.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
 // K-NN-hf  k_nn_logprobs (kernels_nn.h; reference: nonlinearGaussian.py:35-81, 248-326) with the per-hidden-unit product
@@ -23,13 +24,15 @@
 // ------------------------------------------------------------------------------------------------
 template <int NT>
 struct Nhf {
-  static constexpr int NKS = (NT + 1) / 2, KROWS = 32 * NKS, TILE_BYTES = KROWS * 32, PIECE_BYTES = NT * TILE_BYTES, IMG_BYTES = 2 * PIECE_BYTES;
+  // (a column tile is KROWS rows of 32 bytes + 32 bytes of padding: the operand is written in element order -- the lanes of one store
+  //  instruction cover a whole row a, i.e. all NT tiles -- and tiles 4 096 bytes apart would put them on the same 8 banks: 7-way conflicts)
+  static constexpr int NKS = (NT + 1) / 2, KROWS = 32 * NKS, TILE_BYTES = KROWS * 32 + 32, PIECE_BYTES = NT * TILE_BYTES, IMG_BYTES = 2 * PIECE_BYTES;
 };
 constexpr int NHF_NW = 8, NHF_NTHR = 64 * NHF_NW;
 __host__ __device__ inline int nhf_dp2(int d) { return (d + 1) & ~1; }          // row pitch of the pair tables (pairs of columns)
 __host__ __device__ inline int nhf_dp4(int d) { return (d + 3) & ~3; }
 __host__ __device__ inline size_t nhf_lds_bytes(int d, int NT, int H, bool soft) {
-  const size_t nks = (size_t)(NT + 1) / 2, img = 2 * (size_t)NT * (32 * nks) * 32;
+  const size_t nks = (size_t)(NT + 1) / 2, img = 2 * (size_t)NT * ((32 * nks) * 32 + 32);
   const size_t graphs = 2 * ((((size_t)d * (nhf_dp2(d) / 2) * (soft ? 8 : 4)) + 15) & ~(size_t)15);
   const size_t lvt = ((size_t)2 * H + 1) * nhf_dp4(d) * 4;
   return img + graphs + lvt + 64 * 8 + 64;
@@ -137,7 +140,7 @@ struct NhfSteps<NT, (NT + 1) / 2> {
 template <int NT, int ACT, bool SOFT>
 __global__ __launch_bounds__(NHF_NTHR) void k_nn_logprobs_hf(const float* __restrict__ x, const int32_t* __restrict__ mask, const float* __restrict__ theta,
                                                             size_t P, const float* __restrict__ scores, const uint32_t* __restrict__ thr,
-                                                            float* __restrict__ logprobs, Key2 carry, int mode, int m0, int M_global, int d, int N,
+                                                            float* __restrict__ logprobs, Key2 carry, int mode, int m0, int M_global, int Mloc, int d, int N,
                                                             int S, int ppb, float alpha, float tau, int layout, int tiny, NNParams np_, int any_mask,
                                                             const float* __restrict__ ln_tab, const float2* __restrict__ w1s,
                                                             const uint2* __restrict__ w1p, const int* __restrict__ ew) {
@@ -151,7 +154,12 @@ __global__ __launch_bounds__(NHF_NTHR) void k_nn_logprobs_hf(const float* __rest
   unsigned char* const gs1 = gs0 + gbytes;
   float* const LVT = reinterpret_cast<float*>(gs1 + gbytes);
   double* const red = reinterpret_cast<double*>(LVT + ((size_t)2 * H + 1) * dp4);
-  const int m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, r = lane & 15;
+  // XCD-aware block order (grid.y = particles rounded up to 8; see k_acyc_bf): all blocks of a particle run on one XCD, whose L2 then
+  // holds that particle's tables (200 KB at config 5, re-read by each of its 64 sample pairs) instead of every XCD holding everyone's
+  const int Lb = blockIdx.x + gridDim.x * blockIdx.y, p_lo = Lb & 7, tq = Lb >> 3;
+  const int bx = tq % (int)gridDim.x, m = (tq / (int)gridDim.x) * 8 + p_lo;
+  if (m >= Mloc) return;  // (block-uniform)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, r = lane & 15;
   const size_t dd = (size_t)d * d;
   const NNOff off = nn_offsets(d, H, np_.bias);
   const float* th_m = theta + (size_t)m * P;
@@ -223,10 +231,31 @@ __global__ __launch_bounds__(NHF_NTHR) void k_nn_logprobs_hf(const float* __rest
   const float* sc_m = scores ? scores + (size_t)m * dd : nullptr;
   const float* ln_m = ln_tab + (size_t)m * dd;
   const int npairs = d * npr;
+  // the thread's column pairs q = tid + 512 k (k < NPQ): image byte offset of the pair, computed once per block
+  constexpr int NPQ = (16 * NT * 8 * NT + NHF_NTHR - 1) / NHF_NTHR;
+  int woff[NPQ];
+#pragma unroll
+  for (int k = 0; k < NPQ; ++k) {
+    const int q = tid + NHF_NTHR * k;
+    const int a = (int)(((float)q + 0.5f) * inv_npr), j0 = 2 * (q - a * npr);
+    woff[k] = q < npairs ? (j0 >> 4) * G::TILE_BYTES + a * 32 + ((((j0 & 15) >> 2) + (a >> 2)) & 3) * 8 + (j0 & 3) * 2 : -1;
+  }
+  typedef typename std::conditional<SOFT, float2, uint2>::type TabT;
+  const TabT* const tab_m = (SOFT ? reinterpret_cast<const TabT*>(w1s) : reinterpret_cast<const TabT*>(w1p)) + (size_t)m * H * npairs;
+  TabT wnext[NPQ];  // table entries of the NEXT hidden unit's operand, requested before the current unit's products
+  auto fetch = [&](int h) {
+    const TabT* t = tab_m + (size_t)h * npairs;
+#pragma unroll
+    for (int k = 0; k < NPQ; ++k) {
+      const int q = tid + NHF_NTHR * k;
+      wnext[k] = t[q < npairs ? q : 0];
+    }
+  };
+  fetch(0);
   __syncthreads();
 
   for (int c = 0; c < ppb; ++c) {
-    const int s0 = blockIdx.x * ppb + c;
+    const int s0 = bx * ppb + c;
     if (s0 >= hS) break;
     // ---- graphs of the pair (s0, s0 + S/2): one Threefry call per element ----
     float pg[2] = {0.f, 0.f};
@@ -279,26 +308,25 @@ __global__ __launch_bounds__(NHF_NTHR) void k_nn_logprobs_hf(const float* __rest
       for (int h = 0; h < H; ++h) {
         __syncthreads();  // graphs written (h = 0) / the image's last reader is done
         // ---- operand image of hidden unit h: (g o W1T_h) 2^ew as two f16 pieces, one 4-byte store per column pair and piece ----
-        {
-          const size_t tb = ((size_t)m * H + h) * npairs;
-          for (int q = tid; q < npairs; q += NHF_NTHR) {
-            const int a = (int)(((float)q + 0.5f) * inv_npr), j0 = 2 * (q - a * npr);
+#pragma unroll
+        for (int k = 0; k < NPQ; ++k) {
+          const int q = tid + NHF_NTHR * k;
+          if (woff[k] >= 0) {
             uint32_t ph, pm;
             if constexpr (SOFT) {
-              const float2 w = w1s[tb + q];
               const float2 gg = reinterpret_cast<const float2*>(gsel)[q];
-              ahf_split(gg.x * w.x, gg.y * w.y, 1.0f, ph, pm);
+              ahf_split(gg.x * wnext[k].x, gg.y * wnext[k].y, 1.0f, ph, pm);
             } else {
-              const uint2 w = w1p[tb + q];
               const uint32_t msk = reinterpret_cast<const uint32_t*>(gsel)[q];
-              ph = w.x & msk;
-              pm = w.y & msk;
+              ph = wnext[k].x & msk;
+              pm = wnext[k].y & msk;
             }
-            unsigned char* const w0 = sb + (j0 >> 4) * G::TILE_BYTES + a * 32 + ((((j0 & 15) >> 2) + (a >> 2)) & 3) * 8 + (j0 & 3) * 2;
+            unsigned char* const w0 = sb + woff[k];
             *reinterpret_cast<uint32_t*>(w0) = ph;
             *reinterpret_cast<uint32_t*>(w0 + G::PIECE_BYTES) = pm;
           }
         }
+        fetch(h + 1 < H ? h + 1 : 0);  // (the next unit's -- or the next sample's first unit's -- entries travel during the products below)
         __syncthreads();
         if (wave < nrt) {
           f32x4 acc[NT];

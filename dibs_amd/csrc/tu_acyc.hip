@@ -26,11 +26,11 @@ static void launch_nt(const AcycLaunch& a) {
 }
 
 // 33 <= d <= 64 with paired chains: split-bf16 MFMA kernel (kernels_acyc_bf16.h); DIBS_ACYC_F32=1 keeps the f32-MFMA kernel (A/B runs)
-// (d <= 32 as well: the work is tiny there and a launch is pure latency -- k_acyc_hf draws the graph in element order, 2 draws per thread at
-//  d = 20 where the owner-lane order of k_acyc<2> needs up to 16 in a row; DIBS_ACYC_SMALL_F32=1 keeps k_acyc<NT> below 33)
+// (d <= 32 stays on k_acyc<NT>: measured at config 2 (d = 20, 32 particles) the 64-padded k_acyc_hf takes 17.4 us against 14.3 us for
+//  k_acyc<2> -- its element-order draws do not make up for products that are 3 x 3 instead of 2 x 2 tiles; DIBS_ACYC_SMALL_HF=1 selects it)
 static bool acyc_use_bf16(const AcycLaunch& a) {
-  static const bool off = getenv("DIBS_ACYC_F32") != nullptr, small_f32 = getenv("DIBS_ACYC_SMALL_F32") != nullptr;
-  return !off && a.units != a.Sa && a.d >= (small_f32 ? 33 : 4) && a.d <= 64;
+  static const bool off = getenv("DIBS_ACYC_F32") != nullptr, small_hf = getenv("DIBS_ACYC_SMALL_HF") != nullptr;
+  return !off && a.units != a.Sa && a.d >= (small_hf ? 4 : 33) && a.d <= 64;
 }
 // 65 <= d <= 112 with paired chains: the same scheme with NT = 5 .. 7 tiles and waves (k_acyc_bfw)
 static bool acyc_use_bfw(const AcycLaunch& a) {

@@ -49,7 +49,8 @@ def rel_err(a, b):
 # equal to 1e-6).  The statement that can hold, and is asserted by every step test with the SAME constants:
 #   signal      on the coordinates that carry signal (|phi_ref| > 1e-3 max |phi_ref|): |x_dev - x_ref| <= 1e-4 max |x_ref|
 #   vs_own_phi  on ALL coordinates: x_dev equals the optimizer applied to the device's own phi to 1e-6 (the update itself is exact)
-#   signal_share the signal coordinates are a stated minimum share of all (the first criterion is not vacuous)
+#   signal_share the signal coordinates are a stated minimum share of all, unless even ALL coordinates are within 1e-4 (the first
+#               criterion is not vacuous)
 # `all` (every coordinate against the oracle) and the element-wise relative error on the signal coordinates are reported beside them.
 UPDATE_TOL = dict(signal=1e-4, vs_own_phi=1e-6)
 
@@ -74,4 +75,7 @@ def update_check(cfg, x_prev, v_prev, phi_dev, phi_ref, x_dev, x_ref):
 def assert_update_parity(u, min_share, what=""):
     assert u["signal"] < UPDATE_TOL["signal"], (what, u)
     assert u["vs_own_phi"] < UPDATE_TOL["vs_own_phi"], (what, u)
-    assert u["signal_share"] >= min_share, (what, u)
+    # non-vacuity: either EVERY coordinate is within the tolerance (the stronger statement -- then the share of signal coordinates is
+    # immaterial: e.g. theta late in a run, where most weights belong to absent edges and have no gradient), or the signal coordinates
+    # are at least the stated share of all
+    assert u["all"] < UPDATE_TOL["signal"] or u["signal_share"] >= min_share, (what, u)
