@@ -430,8 +430,9 @@ def test_headline_free_run_divergence(c_oracle64, c_oracle32):
 
 def test_bench_sharded_path_on_one_gpu():
     """`bench.py --gpus N` (N > 1) cannot run here, but everything it executes can: `--dist-smoke` drives the same code -- process group
-    (one rank), engine on a dedicated stream, overlapped exchange through real RCCL all-gathers on the side stream and between the phases,
-    per-rank diagnostics, the config-4 extra key -- and must print one valid JSON line whose trajectory equals dibs_engine_run's."""
+    (one rank) for the harness, RCCL communicators inside the engine (dibs_engine_comm_init), the in-engine step loop
+    (dibs_engine_run_sharded: one ncclAllGather of the packed rows per step at 128 particles, the overlapped exchange for the config-4 extra
+    key with its 1 024 particles), per-rank diagnostics -- and must print one valid JSON line."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -443,6 +444,7 @@ def test_bench_sharded_path_on_one_gpu():
     out = json.loads(line)
     assert out["value"] > 100 and out["n_gpus"] == 1 and out["steps"] == 4
     sh = out["sharded"]
-    assert sh["allgather_us"] > 0 and sh["allgather_bytes_per_rank"] == 128 * 5000 * 4 and len(sh["kernel_us_per_step_by_rank"]) == 1
-    assert "kmat" not in sh["kernel_us_per_step_by_rank"][0]   # (the kernel matrix runs on the side stream, outside the engine's timers)
+    # (128 particles: the packed rows [z | grad_z] travel, 2 D floats per particle)
+    assert sh["allgather_us"] > 0 and sh["allgather_bytes_per_rank"] == 128 * 10000 * 4 and len(sh["kernel_us_per_step_by_rank"]) == 1
+    assert "in-engine" in out["config"]["parallelism"] or "inside the engine" in out["config"]["parallelism"]
     assert out["config4"]["value"] > 10
