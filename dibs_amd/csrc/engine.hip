@@ -108,6 +108,7 @@ struct dibs_engine {
   hipStream_t side = nullptr;
   hipEvent_t ev_exported = nullptr, ev_vals = nullptr;
   bool vals_fresh = false;  // plane 0 (and the kernel slab computed from it) belongs to the engine's current particles
+  bool loopback = false;    // comm_init(NULL): collectives skipped (per-rank timing on one GPU)
   struct ScoreCache {
     std::vector<float> x;
     std::vector<int32_t> mask;
@@ -868,6 +869,8 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
                         e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr, e->eas};
     acyc_power_timed(e, al, e->stream);
     {
+      // (folding this reduction into k_particle_grad for small grids -- one dependent launch less -- was measured and dropped: the tail
+      //  kernel grows by more than the launch it saves: config 2 54.3 -> 55.3 us/step, a rank of an 8-way headline run 91.4 -> 99.2)
       KTimer tm(e, DIBS_K_ACYC_REDUCE);
       acyc_launch_reduce(al);
     }
@@ -1170,12 +1173,16 @@ extern "C" int dibs_engine_comm_destroy(dibs_engine* e) {
 }
 
 extern "C" int dibs_engine_comm_init(dibs_engine* e, const void* ids, int32_t n_ids) {
-  if (!e || !ids) return fail("null argument");
+  if (!e) return fail("null argument");
   if (n_ids < 1 || n_ids > 2) return fail("n_ids must be 1 (one all-gather per step) or 2 (overlapped exchange as well)");
-  if (!rccl().ok) return fail(rccl().why);
+  // ids == NULL: LOOPBACK -- no communicator, the all-gathers are skipped and the rows of the other ranks keep whatever the buffers hold.
+  // A measuring device (scripts/gpu_shard_scaling.py: what ONE rank of an N-way run costs per step in this loop, on one GPU), not a
+  // way to run a sharded job.
+  if (ids && !rccl().ok) return fail(rccl().why);
   HIP_OK(hipSetDevice(e->cfg.device_id));
   dibs_engine_comm_destroy(e);
-  for (int i = 0; i < n_ids; ++i) {
+  e->loopback = ids == nullptr;
+  for (int i = 0; ids && i < n_ids; ++i) {
     ncclUniqueId id;
     memcpy(id.internal, (const char*)ids + (size_t)i * NCCL_UNIQUE_ID_BYTES, NCCL_UNIQUE_ID_BYTES);
     RCCL_OK(rccl().comm_init_rank(&e->comm[i], e->cfg.n_ranks, id, e->cfg.rank));
@@ -1204,7 +1211,10 @@ static int exchange_values(dibs_engine* e, bool exported) {
   }
   HIP_OK(hipEventRecord(e->ev_exported, e->stream));
   HIP_OK(hipStreamWaitEvent(e->side, e->ev_exported, 0));
-  RCCL_OK(rccl().all_gather(e->vsend, e->planes, (size_t)e->Mloc * e->Ev, ncclFloat, e->comm[1], e->side));
+  if (e->loopback)  // (own rows only)
+    HIP_OK(hipMemcpyAsync(e->planes + (size_t)e->m0 * e->Ev, e->vsend, (size_t)e->Mloc * e->Ev * 4, hipMemcpyDeviceToDevice, e->side));
+  else
+    RCCL_OK(rccl().all_gather(e->vsend, e->planes, (size_t)e->Mloc * e->Ev, ncclFloat, e->comm[1], e->side));
   if (dibs_engine_kmat_values(e, e->planes, e->side)) return 1;
   HIP_OK(hipEventRecord(e->ev_vals, e->side));
   e->vals_fresh = true;
@@ -1225,12 +1235,14 @@ extern "C" int dibs_engine_run_sharded(dibs_engine* e, int32_t t_start, int32_t 
   for (int t = t_start; t < t_start + n_steps; ++t) {
     if (!overlapped) {
       if (step_local(e, t, packed_rows(e, e->pack))) return 1;
-      RCCL_OK(rccl().all_gather(e->pack + (size_t)e->m0 * e->E, e->pack, (size_t)e->Mloc * e->E, ncclFloat, e->comm[0], e->stream));
+      if (!e->loopback)
+        RCCL_OK(rccl().all_gather(e->pack + (size_t)e->m0 * e->E, e->pack, (size_t)e->Mloc * e->E, ncclFloat, e->comm[0], e->stream));
       if (step_update(e, t, packed_source(e, e->pack))) return 1;
     } else {
       float* const gplane = e->planes + grad_plane;  // rows [grad_z | grad_theta], indexed by global particle id
       if (step_local(e, t, RowTarget{gplane, (size_t)e->Ev, 0, 0, (size_t)e->D, 0})) return 1;
-      RCCL_OK(rccl().all_gather(gplane + (size_t)e->m0 * e->Ev, gplane, (size_t)e->Mloc * e->Ev, ncclFloat, e->comm[0], e->stream));
+      if (!e->loopback)
+        RCCL_OK(rccl().all_gather(gplane + (size_t)e->m0 * e->Ev, gplane, (size_t)e->Mloc * e->Ev, ncclFloat, e->comm[0], e->stream));
       HIP_OK(hipStreamWaitEvent(e->stream, e->ev_vals, 0));  // values + kernel slab of this step (gathered during the step before)
       if (step_update(e, t, plane_source(e, e->planes), e->vsend)) return 1;
       if (exchange_values(e, true)) return 1;  // values of step t + 1, beside its phase A
@@ -1249,6 +1261,7 @@ extern "C" int dibs_engine_run_sharded(dibs_engine* e, int32_t t_start, int32_t 
 extern "C" int dibs_engine_gather_particles(dibs_engine* e, float* z_all, float* theta_all) {
   if (!e) return fail("null engine");
   if (e->n_comms < 1) return fail("dibs_engine_comm_init has not been called");
+  if (e->loopback) return fail("loopback communicator (timing only): there are no other ranks to gather from");
   HIP_OK(hipSetDevice(e->cfg.device_id));
   DevBuf<float> tmp_all, tmp_send;
   const float* vals = nullptr;

@@ -111,7 +111,12 @@ class Engine:
             _lib.check(self.lib.dibs_comm_unique_id(C.byref(buf, i * self.COMM_ID_BYTES)))
         return bytes(buf)
 
-    def comm_init(self, ids):
+    def comm_init(self, ids, n_loopback=2):
+        """ids: the bytes of 1 or 2 unique ids (comm_unique_ids on one rank, handed to all).  ids=None: loopback (collectives skipped;
+        what ONE rank of an N-way run costs per step, measured on one GPU -- scripts/gpu_shard_scaling.py)."""
+        if ids is None:
+            _lib.check(self.lib.dibs_engine_comm_init(self._h, None, int(n_loopback)))
+            return
         ids = bytes(ids)
         assert len(ids) in (self.COMM_ID_BYTES, 2 * self.COMM_ID_BYTES)
         _lib.check(self.lib.dibs_engine_comm_init(self._h, ids, len(ids) // self.COMM_ID_BYTES))

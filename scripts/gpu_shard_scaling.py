@@ -61,7 +61,16 @@ for R in (1, 2, 4, 8):
                     side.wait_event(exported); planes[:nv].copy_(vs); e.kmat_values(planes.data_ptr(), side.cuda_stream); ready.record(side)
         go2(T0 + 270, 20); torch.cuda.synchronize()
         t0 = time.perf_counter(); go2(T0 + 290, 200); torch.cuda.synchronize(); dt2 = (time.perf_counter() - t0) / 200
+    # the same rank in the IN-ENGINE loop (dibs_engine_run_sharded, no Python between the steps) with a loopback communicator: the
+    # collectives are skipped, the rows of the other ranks stay frozen -- the compute + launch side of a rank's step in the production loop
+    st0 = {k: v for k, v in e.get_state().items() if v is not None}
+    nat = {}
+    for ov in (False, True):
+        n_ = Engine(make_config(n_vars=50, n_particles=128, n_observations=100, rank=0, n_ranks=R))
+        n_.set_data(data.x); n_.set_state(**st0); n_.comm_init(None, 2)
+        n_.run_sharded(T0 + 500, 20, ov); t0 = time.perf_counter(); n_.run_sharded(T0 + 520, 200, ov); nat[ov] = (time.perf_counter() - t0) / 200
+        n_.close()
     ks = {k: v[0] / 50 * 1e3 for k, v in tm.items()}
-    print(f"R={R} Mloc={128 // R}: wall {dt * 1e6:7.1f} us/step (overlapped protocol {dt2 * 1e6:7.1f})   kernels sum {sum(ks.values()):7.1f} us   " +
+    print(f"R={R} Mloc={128 // R}: in-engine loop {nat[False] * 1e6:6.1f} us/step packed, {nat[True] * 1e6:6.1f} overlapped | Python-driven: wall {dt * 1e6:7.1f} us/step (overlapped protocol {dt2 * 1e6:7.1f})   kernels sum {sum(ks.values()):7.1f} us   " +
           " ".join(f"{k}={v:.1f}" for k, v in ks.items()), flush=True)
     engs[0].close()
