@@ -30,6 +30,8 @@ struct JointWork {
   void* nhf_w1p;   // ... and their packed f16 pieces {h pair, m pair} (uint2), same shape
   int* nhf_ew;     // [Mloc] exponent of the per-particle scale
   size_t nhf_pairs;  // allocated pairs (0: not allocated)
+  void *nhx_w1s, *nhx_w1p;  // the same per a-QUAD and node (float4 / uint4) [Mloc][H][ceil(d/4)][d]: k_nn_logprobs_hx (kernels_nn_f16x.h)
+  size_t nhx_quads;
   float* nng_scratch;         // general DenseNN path (kernels_nn_generic.h): activation records, grown on first use
   size_t nng_scratch_floats;
 };
@@ -982,6 +984,8 @@ int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) {
   w->nhf_w1s = w->nhf_w1p = nullptr;
   w->nhf_ew = nullptr;
   w->nhf_pairs = 0;
+  w->nhx_w1s = w->nhx_w1p = nullptr;
+  w->nhx_quads = 0;
   w->gram = nullptr;
   w->ncnt = nullptr;
   w->n_gram = 0;
@@ -1001,6 +1005,10 @@ void joint_free(JointWork* w) {
   if (w->nhf_w1s) hipFree(w->nhf_w1s);
   if (w->nhf_w1p) hipFree(w->nhf_w1p);
   if (w->nhf_ew) hipFree(w->nhf_ew);
+  if (w->nhx_w1s) hipFree(w->nhx_w1s);
+  if (w->nhx_w1p) hipFree(w->nhx_w1p);
+  w->nhx_w1s = w->nhx_w1p = nullptr;
+  w->nhx_quads = 0;
   w->nhf_w1s = w->nhf_w1p = nullptr;
   w->nhf_ew = nullptr;
   w->nhf_pairs = 0;

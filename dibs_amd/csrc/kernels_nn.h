@@ -630,6 +630,7 @@ void joint_nn_init_theta(float* theta, size_t P, Key2 key, int m0, int Mloc, int
 #ifdef DIBS_TU_NN
 #include "kernels_nn_generic.h"
 #include "kernels_nn_f16.h"
+#include "kernels_nn_f16x.h"
 void dibs_allow_lds(const void* kernel, size_t bytes);  // (engine.hip)
 
 // first layer on the f16 matrix pipe (kernels_nn_f16.h): 33 <= d <= 112, Threefry-paired samples, tables allocated; DIBS_NN_F32=1 keeps
@@ -643,17 +644,66 @@ static bool joint_nn_logprobs_hf(JointWork* w, const JointLaunch& jl, Key2 carry
     const bool paired = jl.layout == 0 && (jl.S & 1) == 0 && (uint64_t)jl.S * jl.d * jl.d < 0xFFFFFFFFull;
     const bool soft = mode == LIN_MODE_Z_REPARAM;
     const size_t lds = nhf_lds_bytes(jl.d, NT, np_.H, soft);
-    if (off || !paired || jl.N > 128 || !w->ln_tab || lds > (size_t)160 * 1024 - 512) return false;
+    if (off || !paired || jl.N > 128 || !w->ln_tab) return false;
+    static const int ppb_env = getenv("DIBS_NN_PPB") ? atoi(getenv("DIBS_NN_PPB")) : 0;
+    const int hS = jl.S / 2, ppb = ppb_env > 0 ? ppb_env : ((hS / 4) * jl.Mloc >= 1024 ? 4 : (hS >= 2 ? 2 : 1));
+    if (!w->nhf_ew && hipMalloc((void**)&w->nhf_ew, (size_t)jl.Mloc * 4) != hipSuccess) {
+      (void)hipGetLastError();
+      w->nhf_ew = nullptr;
+      return false;
+    }
+    // d >= 65: the per-sample operand in REGISTERS against an x^T image (k_nn_logprobs_hx: no block barrier per hidden unit); below, and
+    // with DIBS_NN_HF_IMG=1, the image variant (k_nn_logprobs_hf: smaller blocks, several per CU)
+    static const bool img_env = getenv("DIBS_NN_HF_IMG") != nullptr;
+    if constexpr (NT >= 5) {
+      const size_t ldsx = nhx_lds_bytes(jl.d, NT, jl.N, np_.H, soft);
+      if (!img_env && ldsx <= (size_t)160 * 1024 - 512) {
+        const size_t quads = (size_t)jl.Mloc * np_.H * ((jl.d + 3) / 4) * jl.d;
+        if (w->nhx_quads < quads) {
+          if (w->nhx_w1s) hipFree(w->nhx_w1s);
+          if (w->nhx_w1p) hipFree(w->nhx_w1p);
+          w->nhx_w1s = w->nhx_w1p = nullptr;
+          w->nhx_quads = 0;
+          if (hipMalloc(&w->nhx_w1s, quads * 16) != hipSuccess || hipMalloc(&w->nhx_w1p, quads * 16) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+          }
+          w->nhx_quads = quads;
+        }
+        if (mode == LIN_MODE_THETA) {  // theta is the same for both estimators of a step: the tables are built once (theta runs first)
+          hipLaunchKernelGGL(k_nn_w1_exp, dim3(jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->nhf_ew, jl.d, np_.H);
+          const int nq = ((jl.d + 3) / 4) * jl.d;
+          hipLaunchKernelGGL(k_nn_tables_hx, dim3((nq + 255) / 256, np_.H, jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->nhf_ew,
+                             (float4*)w->nhx_w1s, (uint4*)w->nhx_w1p, jl.d, np_.H);
+        }
+#define NHX_LAUNCH(NTN_, ACT_, SOFT_)                                                                                                        \
+        {                                                                                                                                    \
+          dibs_allow_lds((const void*)k_nn_logprobs_hx<NT, NTN_, ACT_, SOFT_>, ldsx);                                                        \
+          hipLaunchKernelGGL((k_nn_logprobs_hx<NT, NTN_, ACT_, SOFT_>), dim3((hS + ppb - 1) / ppb, (jl.Mloc + 7) & ~7), dim3(64 * NT), ldsx,  \
+                             jl.stream, w->x, w->mask, jl.theta, P, jl.scores, jl.thr, lp, carry, mode, jl.m0, jl.M, jl.Mloc, jl.d, jl.N,    \
+                             jl.S, ppb, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, w->any_mask, w->ln_tab, (const float4*)w->nhx_w1s,        \
+                             (const uint4*)w->nhx_w1p, w->nhf_ew);                                                                           \
+        }
+#define NHX_PICK(NTN_)                                                                                                                       \
+        if (soft) {                                                                                                                          \
+          if (np_.act == 0) NHX_LAUNCH(NTN_, 0, true) else NHX_LAUNCH(NTN_, -1, true)                                                         \
+        } else {                                                                                                                             \
+          if (np_.act == 0) NHX_LAUNCH(NTN_, 0, false) else NHX_LAUNCH(NTN_, -1, false)                                                       \
+        }
+        if (jl.N <= 112) { NHX_PICK(7) } else { NHX_PICK(8) }
+#undef NHX_PICK
+#undef NHX_LAUNCH
+        return true;
+      }
+    }
+    if (lds > (size_t)160 * 1024 - 512) return false;
     const size_t pairs = (size_t)jl.Mloc * np_.H * jl.d * (nhf_dp2(jl.d) / 2);
     if (w->nhf_pairs < pairs) {
       if (w->nhf_w1s) hipFree(w->nhf_w1s);
       if (w->nhf_w1p) hipFree(w->nhf_w1p);
-      if (w->nhf_ew) hipFree(w->nhf_ew);
       w->nhf_w1s = w->nhf_w1p = nullptr;
-      w->nhf_ew = nullptr;
       w->nhf_pairs = 0;
-      if (hipMalloc(&w->nhf_w1s, pairs * 8) != hipSuccess || hipMalloc(&w->nhf_w1p, pairs * 8) != hipSuccess ||
-          hipMalloc((void**)&w->nhf_ew, (size_t)jl.Mloc * 4) != hipSuccess) {
+      if (hipMalloc(&w->nhf_w1s, pairs * 8) != hipSuccess || hipMalloc(&w->nhf_w1p, pairs * 8) != hipSuccess) {
         (void)hipGetLastError();
         return false;
       }
@@ -665,8 +715,6 @@ static bool joint_nn_logprobs_hf(JointWork* w, const JointLaunch& jl, Key2 carry
       hipLaunchKernelGGL(k_nn_tables_hf, dim3((npr + 255) / 256, np_.H, jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->nhf_ew,
                          (float2*)w->nhf_w1s, (uint2*)w->nhf_w1p, jl.d, np_.H);
     }
-    static const int ppb_env = getenv("DIBS_NN_PPB") ? atoi(getenv("DIBS_NN_PPB")) : 0;
-    const int hS = jl.S / 2, ppb = ppb_env > 0 ? ppb_env : ((hS / 4) * jl.Mloc >= 1024 ? 4 : (hS >= 2 ? 2 : 1));
 #define NHF_LAUNCH(ACT_, SOFT_)                                                                                                               \
     {                                                                                                                                         \
       dibs_allow_lds((const void*)k_nn_logprobs_hf<NT, ACT_, SOFT_>, lds);                                                                    \
