@@ -22,7 +22,9 @@
 // grid = (ceil(S / 2 / ppb), Mloc rounded up to 8; re-indexed XCD-aware inside), block = 64 NT (one wave per row tile of nodes),
 // dynamic LDS = nhx_lds_bytes()
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ inline int nhx_ntn(int N) { return (N + 15) >> 4; }  // column tiles of x^T (observations), <= 8
+// column tiles of x^T (observations) of the INSTANTIATION that runs: 7 up to 112 observations, else 8 (the template parameter NTN -- the
+// image always has that many tiles, the ones beyond the data stay zero)
+__host__ __device__ inline int nhx_ntn(int N) { return N <= 112 ? 7 : 8; }
 __host__ __device__ inline size_t nhx_img_bytes(int NT, int N) { return 2 * (size_t)nhx_ntn(N) * ((size_t)32 * ((NT + 1) / 2) * 32 + 32); }
 __host__ __device__ inline size_t nhx_graph_bytes(int d, bool soft) {
   // soft: two samples of g~ [a][dp4(j)] floats; hard: two samples of [j][4 words] bits (a < 128)

@@ -574,6 +574,12 @@ def test_device_bge_scores_against_closed_forms(d):
     (20, 3, 16, 4, 5, "leakyrelu", True, "reparam", True, (3,), 60),
     (100, 2, 16, 4, 5, "tanh", True, "reparam", True, (2,), 100),   # BASELINE config 5 geometry: d=100, hidden (5,), interv_mask
     (100, 2, 8, 4, 5, "relu", True, "score", True, (1,), 100),
+    # d >= 65: the register-operand kernels of kernels_nn_f16x.h (x^T image always 7 / 8 observation tiles: with FEW observations the LDS
+    # size must still be the instantiation's -- found by tests/tools/gpu_fuzz.py FUZZ_NN); odd and even tile counts, 7- and 8-tile images
+    (80, 3, 8, 2, 5, "leakyrelu", False, "reparam", False, (2,), 20),
+    (96, 2, 8, 2, 4, "relu", True, "score", True, (1,), 120),
+    (66, 2, 6, 2, 7, "sigmoid", True, "reparam", True, (1,), 33),
+    (48, 3, 8, 2, 5, "relu", True, "reparam", False, (1,), 50),          # 33 <= d <= 64: the image variant (kernels_nn_f16.h)
 ])
 def test_joint_densenn_step_stages(c_oracle64, d, M, S, Sa, H, act, bias, est, interv, steps, N):
     rng = np.random.default_rng(1)
