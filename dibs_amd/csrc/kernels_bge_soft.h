@@ -392,6 +392,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 #ifdef DIBS_TU_BGE_SOFT
+#include "kernels_bge_soft_mf.h"
 // softmax over the samples and W = sum_s w_s dS_s (samples with w_s == 0 in float are skipped, in sample order)
 // grid = Mloc, block = 256; dynamic LDS = S * 8
 __global__ __launch_bounds__(256) void k_soft_combine(const float* __restrict__ ds, const float* __restrict__ logprobs,
@@ -438,7 +439,24 @@ void bge_soft_launch(const BgeSoftParams& sp, const float* scores, Key2 carry, i
     hipLaunchKernelGGL((k_bge_soft<RL_, RPL_>), dim3(S, Mloc), dim3(256), lds, stream, scores, sp, carry, m0, M, d, S, alpha, tau, layout, \
                        tiny, soft_ds, logprobs);                                                                                        \
   }
-  if (d <= 64 && !getenv("DIBS_SOFT_GENERIC")) {
+  if (d <= 64 && !getenv("DIBS_SOFT_GENERIC") && !getenv("DIBS_SOFT_REG")) {
+    // blocked factorisation on the matrix pipe (kernels_bge_soft_mf.h)
+    const bool rr = sp.n_mats == 1;
+    const size_t l2 = bsm_lds_bytes(d, rr);
+#define SOFTM(NB_, RL_)                                                                                                                 \
+  {                                                                                                                                     \
+    if (l2 > 48 * 1024) hipFuncSetAttribute((const void*)k_bge_soft_mf<NB_, RL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);  \
+    hipLaunchKernelGGL((k_bge_soft_mf<NB_, RL_>), dim3(S, Mloc), dim3(256), l2, stream, scores, sp, carry, m0, M, d, S, alpha, tau, layout, \
+                       tiny, soft_ds, logprobs);                                                                                        \
+  }
+    switch ((d + 15) / 16) {
+      case 1: if (rr) SOFTM(1, true) else SOFTM(1, false) break;
+      case 2: if (rr) SOFTM(2, true) else SOFTM(2, false) break;
+      case 3: if (rr) SOFTM(3, true) else SOFTM(3, false) break;
+      default: if (rr) SOFTM(4, true) else SOFTM(4, false) break;
+    }
+#undef SOFTM
+  } else if (d <= 64 && !getenv("DIBS_SOFT_GENERIC")) {
     const bool rr = sp.n_mats == 1;
 #define SOFTR(DP_)                                                                                                                     \
   {                                                                                                                                     \
