@@ -137,26 +137,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const f32x4 t4 = *reinterpret_cast<const f32x4*>(Ab + c * LDP + q);
         Sr[q] = t4[0]; Sr[q + 1] = t4[1]; Sr[q + 2] = t4[2]; Sr[q + 3] = t4[3];
       }
+      // rows of this diagonal block that are not identity padding (wave-uniform; only the last block has any): a padding step has pivot 1 and
+      // a zero column -- skipped, exactly
+      const int nreal = k == NB - 1 ? d - 16 * (NB - 1) : 16;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        const float pivm1 = bsm_bcast(Sr[t], t), piv = 1.0f + pivm1, inv = rsqrtf(piv);
-        invs[t] = inv;
-        const float lv = c > t ? Sr[t] * inv : (c == t ? piv * inv : 0.f);
-        dm1 = (c == t && g == k) ? pivm1 : dm1;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(Sr[t]) : "v"(lv));  // (column t of L, pinned in front of the statements that read it through DPP)
-        if (t < 15) {
-          asm volatile("s_nop 1");
+        invs[t] = 1.0f;
+        if (t < nreal) {
+          // (the lane tests are made on an opaque copy: hoisted out of the node loop as 16 + 16 lane masks they would live in SGPR pairs,
+          //  and past ~100 SGPRs hipcc parks those in VGPR lanes -- two v_readlane per use instead of one v_cmp)
+          int lq = lane;
+          asm volatile("" : "+v"(lq));
+          const float pivm1 = bsm_bcast(Sr[t], t), inv = __builtin_amdgcn_rsqf(1.0f + pivm1);
+          invs[t] = inv;
+          dm1 = lq == 16 * k + t ? pivm1 : dm1;
+          // column t of L below the diagonal (the diagonal entry itself and the rows above it are never read again); s_nop: a VALU read of a
+          // transcendental result needs a wait state, and the statements below read the product through DPP (two)
+          float lv;
+          asm volatile("s_nop 0\n\tv_mul_f32 %0, %1, %2\n\ts_nop 1" : "=v"(lv) : "v"(Sr[t]), "v"(inv));
+          Sr[t] = lv;
 #pragma unroll
           for (int c2 = t + 1; c2 < 16; ++c2) bsm_fmac_bc(Sr[c2], Sr[t], Sr[t], c2);
         }
       }
-      // T_kk = L_kk^-1, row c per lane: T L = I solved column by column from the right
+      // T_kk = L_kk^-1, row c per lane: T L = I solved column by column from the right (padding columns: the identity)
 #pragma unroll
       for (int q = 15; q >= 0; --q) {
-        float a = c == q ? 1.f : 0.f;
+        int cq = c;
+        asm volatile("" : "+v"(cq));
+        float a = cq == q ? 1.f : 0.f;
+        if (q < nreal) {
 #pragma unroll
-        for (int mm = q + 1; mm < 16; ++mm) bsm_fmac_bc(a, Sr[q], Tr[mm], mm);  // a -= L[mm][q] T[c][mm]
-        Tr[q] = a * invs[q];
+          for (int mm = q + 1; mm < 16; ++mm) bsm_fmac_bc(a, Sr[q], Tr[mm], mm);  // a -= L[mm][q] T[c][mm]
+          a *= invs[q];
+        }
+        Tr[q] = a;
       }
       if (g == 0) {
 #pragma unroll
@@ -247,10 +262,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     lp_wave += lj;
     if (act) {
       const float* Rrow = R + v * d;
-      float t_r = 0.f;
+      float t_r = -pyv[v] - R[j * d + v];  // (R - I) (p o y) - R_j
 #pragma unroll 8
-      for (int bb = 0; bb < d; ++bb) t_r = fmaf(Rrow[bb] - (bb == v ? 1.f : 0.f), pyv[bb], t_r);
-      t_r -= R[j * d + v];
+      for (int bb = 0; bb < d; ++bb) t_r = fmaf(Rrow[bb], pyv[bb], t_r);
       // 1 - (M_pa^-1)_vv = (L_vv^2 - 1) / L_vv^2 - |off-diagonal part of column v of L^-1|^2, each term O(p_v^2)
       const float h_r = p > 0.f ? (dm1 / (1.0f + dm1) - offd) / p : 0.f;
       const double dl = Nn > 0.0 ? gprime - 0.5 * ls - (double)h_r - (2.0 * c2 / sch) * (double)y * (double)t_r : 0.0;
