@@ -443,17 +443,18 @@ void bge_soft_launch(const BgeSoftParams& sp, const float* scores, Key2 carry, i
     // blocked factorisation on the matrix pipe (kernels_bge_soft_mf.h)
     const bool rr = sp.n_mats == 1;
     const size_t l2 = bsm_lds_bytes(d, rr);
-#define SOFTM(NB_, RL_)                                                                                                                 \
+#define SOFTM(NB_, RL_, W_)                                                                                                             \
   {                                                                                                                                     \
-    if (l2 > 48 * 1024) hipFuncSetAttribute((const void*)k_bge_soft_mf<NB_, RL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);  \
-    hipLaunchKernelGGL((k_bge_soft_mf<NB_, RL_>), dim3(S, Mloc), dim3(256), l2, stream, scores, sp, carry, m0, M, d, S, alpha, tau, layout, \
+    if (l2 > 48 * 1024) hipFuncSetAttribute((const void*)k_bge_soft_mf<NB_, RL_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2); \
+    hipLaunchKernelGGL((k_bge_soft_mf<NB_, RL_, W_>), dim3(S, Mloc), dim3(256), l2, stream, scores, sp, carry, m0, M, d, S, alpha, tau, layout, \
                        tiny, soft_ds, logprobs);                                                                                        \
   }
+    const bool w3 = getenv("DIBS_SOFT_W2") == nullptr;  // three waves per SIMD (165 registers, no scratch): 4.6 ms against 5.4 at two
     switch ((d + 15) / 16) {
-      case 1: if (rr) SOFTM(1, true) else SOFTM(1, false) break;
-      case 2: if (rr) SOFTM(2, true) else SOFTM(2, false) break;
-      case 3: if (rr) SOFTM(3, true) else SOFTM(3, false) break;
-      default: if (rr) SOFTM(4, true) else SOFTM(4, false) break;
+      case 1: if (rr) SOFTM(1, true, 3) else SOFTM(1, false, 3) break;
+      case 2: if (rr) SOFTM(2, true, 3) else SOFTM(2, false, 3) break;
+      case 3: if (rr) { if (w3) SOFTM(3, true, 3) else SOFTM(3, true, 2) } else { if (w3) SOFTM(3, false, 3) else SOFTM(3, false, 2) } break;
+      default: if (rr) { if (w3) SOFTM(4, true, 3) else SOFTM(4, true, 2) } else { if (w3) SOFTM(4, false, 3) else SOFTM(4, false, 2) } break;
     }
 #undef SOFTM
   } else if (d <= 64 && !getenv("DIBS_SOFT_GENERIC")) {

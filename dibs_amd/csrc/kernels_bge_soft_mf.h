@@ -20,9 +20,22 @@
 #include "kernels_bge_soft.h"
 
 #define BSM_LDP 20  // row stride (floats) of the 16 x 16 LDS blocks: 16-byte rows, lanes of a 16-lane group on distinct banks
-__host__ __device__ inline size_t bsm_wave_bytes() { return ((size_t)2 * 16 * BSM_LDP + 3 * 64) * 4; }  // A_kk | T_kk | p by position | p y by variable | spare
+__host__ __device__ inline size_t bsm_wave_bytes() { return ((size_t)5 * 16 * BSM_LDP + 4 * 64) * 4; }  // A_kk | T_kk, k < 4 | p by position | p y by variable | variable of a position (x d, x 1)
 __host__ __device__ inline size_t bsm_lds_bytes(int d, bool r_in_lds) { return bge_soft_shared_bytes(d, r_in_lds) + 64 * 8 + 4 * bsm_wave_bytes(); }  // R, red | c_j | waves
 
+// log(x) of a positive float with ~1e-7 ABSOLUTE error in float arithmetic (the scheme of bge_log, kernels_bge.h): x = 2^e m,
+// m in [sqrt(1/2), sqrt(2)), log m = 2 atanh((m - 1) / (m + 1))
+__device__ __forceinline__ double bsm_log(float x) {
+  int e;
+  float m = frexpf(x, &e);
+  if (m < 0.70710678f) {
+    m *= 2.0f;
+    e -= 1;
+  }
+  const float r = (m - 1.0f) / (m + 1.0f), r2 = r * r;
+  const float p = fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, 2.0f / 11.0f, 2.0f / 9.0f), 2.0f / 7.0f), 2.0f / 5.0f), 2.0f / 3.0f), 2.0f);
+  return (double)e * 0.6931471805599453 + (double)(r * p);
+}
 // Stirling tails at z >= 8: lgamma(z) = (z - 1/2) log z - z + 1/2 log 2 pi + bsm_ser_lgamma(z), digamma(z) = log z + bsm_ser_digamma(z)
 __device__ __forceinline__ double bsm_ser_lgamma(double z) {
   const double r = 1.0 / z, f = r * r;
@@ -47,22 +60,39 @@ __device__ __forceinline__ void bsm_fmac_bc(float& acc, const float& b, const fl
   }
 #undef BSM_FB
 }
-// value of `v` in lane n of this lane's row of 16 (two wait states in front: `v` may have been written by the statement before)
+// value of `v` in lane n of this lane's row of 16.  NOP: two wait states in front (`v` may have been written by the statement before)
+template <bool NOP>
 __device__ __forceinline__ float bsm_bcast(const float& v, int n) {
   float o;
-#define BSM_BC(N_) case N_: asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:" #N_ " row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v)); break;
+#define BSM_BC(N_)                                                                                                                    \
+  case N_:                                                                                                                            \
+    if (NOP) asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:" #N_ " row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));      \
+    else asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:" #N_ " row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));                     \
+    break;
   switch (n) {
     BSM_BC(0) BSM_BC(1) BSM_BC(2) BSM_BC(3) BSM_BC(4) BSM_BC(5) BSM_BC(6) BSM_BC(7)
     BSM_BC(8) BSM_BC(9) BSM_BC(10) BSM_BC(11) BSM_BC(12) BSM_BC(13) BSM_BC(14)
-    default: asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:15 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v)); break;
+    default:
+      if (NOP) asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:15 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+      else asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:15 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+      break;
   }
 #undef BSM_BC
   return o;
 }
+// x = lane in `mask` ? y : x with the lane set as a 64-bit CONSTANT in an SGPR pair (s_mov on the scalar unit): one vector instruction where
+// a test on the lane index costs v_cmp + v_cndmask -- or, hoisted out of the node loop as 64 live masks, SGPR spills
+__device__ __forceinline__ void bsm_sel(float& x, const float& y, uint64_t mask) {
+  asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(x) : "v"(y), "s"(mask));
+}
+__device__ __forceinline__ void bsm_nops(int n) {  // n wait states
+  if (n == 1) asm volatile("s_nop 0");
+  if (n == 2) asm volatile("s_nop 1");
+}
 
 // grid = (S, Mloc), block = 256 (one node per wave and pass); dynamic LDS = bsm_lds_bytes()
-template <int NB, bool R_LDS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bge_soft_mf(const float* __restrict__ scores, BgeSoftParams bp, Key2 carry, int m0, int M_global,
+template <int NB, bool R_LDS, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_bge_soft_mf(const float* __restrict__ scores, BgeSoftParams bp, Key2 carry, int m0, int M_global,
                                                      int d, int S, float alpha, float tau, int layout, int tiny,
                                                      float* __restrict__ ds_out, float* __restrict__ logprobs) {
   constexpr int LDP = BSM_LDP;
@@ -74,8 +104,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   double* cj = reinterpret_cast<double*>(smem_raw + bge_soft_shared_bytes(d, R_LDS));  // per node: the terms of the score that depend on j only
   float* Ab = reinterpret_cast<float*>(smem_raw + bge_soft_shared_bytes(d, R_LDS) + 64 * 8 + (size_t)wave * bsm_wave_bytes());
   float* Tb = Ab + 16 * LDP;
-  float* pvs = Tb + 16 * LDP;
+  float* pvs = Tb + 4 * 16 * LDP;
   float* pyv = pvs + 64;
+  int* vmd = reinterpret_cast<int*>(pyv + 64);  // variable at a position, times d (row offset into R); padding positions: j
+  int* vmc = vmd + 64;
   const float* sc_m = scores + (size_t)m * dd;
   const Key2 key = lin_mode_key(LIN_MODE_Z_REPARAM, carry, M_global, m0 + m, layout);  // dibs.py:430-431
   const uint64_t nbits = (uint64_t)S * dd;
@@ -96,6 +128,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float p = gs;  // column j of the soft graph (dibs.py:121-140); 0 for v == j and on the padding positions
     const double l = wave_sum_d((double)p);
     pvs[lane] = act ? (lane == dl1 ? 1.f : p) : 0.f;
+    vmc[lane] = act ? v : j;
+    vmd[lane] = (act ? v : j) * d;
     wave_lds_fence();
     // ---- A - I in upper blocks, accumulator layout ----------------------------------------------------------------------------------
     f32x4 acc[NB][NB];
@@ -105,26 +139,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         prow[i] = *reinterpret_cast<const f32x4*>(pvs + 16 * i + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rho = 16 * i + 4 * g + r;
-          rrow[i][r] = var_of(rho < dl1 ? rho : dl1) * d;
-        }
+        const int4 r4 = *reinterpret_cast<const int4*>(vmd + 16 * i + 4 * g);
+        rrow[i][0] = r4.x; rrow[i][1] = r4.y; rrow[i][2] = r4.z; rrow[i][3] = r4.w;
       }
 #pragma unroll
       for (int jb = 0; jb < NB; ++jb) {
-        const int kap = 16 * jb + c;
-        const float pc = pvs[kap];
-        const int vc = var_of(kap < dl1 ? kap : dl1);
+        const float pc = pvs[16 * jb + c];
+        const int vc = vmc[16 * jb + c];
 #pragma unroll
         for (int i = 0; i <= jb; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            acc[i][jb][r] = prow[i][r] * pc * (R[rrow[i][r] + vc] - ((i == jb && 4 * g + r == c) ? 1.f : 0.f));
+          for (int r = 0; r < 4; ++r) {
+            float rv = R[rrow[i][r] + vc];
+            if (i == jb) rv -= 4 * g + r == c ? 1.f : 0.f;
+            acc[i][jb][r] = prow[i][r] * pc * rv;
+          }
       }
     }
     float dm1 = 0.f;  // pivot - 1 of this lane's position
-    f32x4 T[NB][NB];  // blocks (row block, column block <= row block) of L^-1
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       // ---- diagonal block: registers -> rows (lane c of every 16-lane row: row c) ---------------------------------------------------
@@ -140,102 +172,157 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // rows of this diagonal block that are not identity padding (wave-uniform; only the last block has any): a padding step has pivot 1 and
       // a zero column -- skipped, exactly
       const int nreal = k == NB - 1 ? d - 16 * (NB - 1) : 16;
+      if (k < NB - 1) {
+        // Full block, software-pipelined: column t + 1 is final after the FIRST multiply-add of step t, so its pivot chain (broadcast, rsq,
+        // scaling) is issued between the remaining multiply-adds of step t instead of stalling the wave four dependent instructions long.
+        // Wait states: two between a write and a DPP read of the register, one after rsq; multiply-adds in between count.
+        float lv;
+        {
+          const float pm = bsm_bcast<true>(Sr[0], 0), inv = __builtin_amdgcn_rsqf(1.0f + pm);
+          invs[0] = inv;
+          bsm_sel(dm1, pm, 1ull << (16 * k));
+          asm volatile("s_nop 0\n\tv_mul_f32 %0, %1, %2\n\ts_nop 1" : "=v"(lv) : "v"(Sr[0]), "v"(inv));
+          Sr[0] = lv;
+        }
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        invs[t] = 1.0f;
-        if (t < nreal) {
-          // (the lane tests are made on an opaque copy: hoisted out of the node loop as 16 + 16 lane masks they would live in SGPR pairs,
-          //  and past ~100 SGPRs hipcc parks those in VGPR lanes -- two v_readlane per use instead of one v_cmp)
-          int lq = lane;
-          asm volatile("" : "+v"(lq));
-          const float pivm1 = bsm_bcast(Sr[t], t), inv = __builtin_amdgcn_rsqf(1.0f + pivm1);
-          invs[t] = inv;
-          dm1 = lq == 16 * k + t ? pivm1 : dm1;
-          // column t of L below the diagonal (the diagonal entry itself and the rows above it are never read again); s_nop: a VALU read of a
-          // transcendental result needs a wait state, and the statements below read the product through DPP (two)
-          float lv;
-          asm volatile("s_nop 0\n\tv_mul_f32 %0, %1, %2\n\ts_nop 1" : "=v"(lv) : "v"(Sr[t]), "v"(inv));
-          Sr[t] = lv;
+        for (int t = 0; t < 15; ++t) {
+          // multiply-adds of step t: columns t + 1 | b0 .. | c0 .. | d0 .. 15 around the pivot chain of column t + 1 (bounds are constants
+          // of the unrolled step)
+          const int eb = 14 - t < 2 ? 14 - t : 2, b0 = t + 2, c0 = b0 + eb, ec = 14 - t - eb < 6 ? 14 - t - eb : 6, d0 = c0 + ec, ed = 16 - d0;
+          bsm_fmac_bc(Sr[t + 1], Sr[t], Sr[t], t + 1);
 #pragma unroll
-          for (int c2 = t + 1; c2 < 16; ++c2) bsm_fmac_bc(Sr[c2], Sr[t], Sr[t], c2);
+          for (int c2 = b0; c2 < c0; ++c2) bsm_fmac_bc(Sr[c2], Sr[t], Sr[t], c2);
+          bsm_nops(2 - eb);
+          const float pm = bsm_bcast<false>(Sr[t + 1], t + 1), inv = __builtin_amdgcn_rsqf(1.0f + pm);
+          invs[t + 1] = inv;
+          bsm_sel(dm1, pm, 1ull << (16 * k + t + 1));
+#pragma unroll
+          for (int c2 = c0; c2 < d0; ++c2) bsm_fmac_bc(Sr[c2], Sr[t], Sr[t], c2);
+          asm volatile("s_nop 0\n\tv_mul_f32 %0, %1, %2" : "=v"(lv) : "v"(Sr[t + 1]), "v"(inv));
+#pragma unroll
+          for (int c2 = d0; c2 < 16; ++c2) bsm_fmac_bc(Sr[c2], Sr[t], Sr[t], c2);
+          bsm_nops(ed >= 2 ? 0 : 2 - ed);
+          Sr[t + 1] = lv;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          invs[t] = 1.0f;
+          if (t < nreal) {
+            const float pivm1 = bsm_bcast<true>(Sr[t], t), inv = __builtin_amdgcn_rsqf(1.0f + pivm1);
+            invs[t] = inv;
+            bsm_sel(dm1, pivm1, 1ull << (16 * k + t));
+            // column t of L below the diagonal (the diagonal entry itself and the rows above it are never read again); s_nop: a VALU read of
+            // a transcendental result needs a wait state, and the statements below read the product through DPP (two)
+            float lv;
+            asm volatile("s_nop 0\n\tv_mul_f32 %0, %1, %2\n\ts_nop 1" : "=v"(lv) : "v"(Sr[t]), "v"(inv));
+            Sr[t] = lv;
+#pragma unroll
+            for (int c2 = t + 1; c2 < 16; ++c2) bsm_fmac_bc(Sr[c2], Sr[t], Sr[t], c2);
+          }
         }
       }
-      // T_kk = L_kk^-1, row c per lane: T L = I solved column by column from the right (padding columns: the identity)
+      // T_kk = L_kk^-1, row c per lane, right-looking: T L = I; once column m of T is final (m = 15 .. 0) every earlier column receives its
+      // term -L[m][q] T[c][m] -- independent multiply-adds (the column-by-column form is one dependent chain per column).  Padding columns
+      // are the identity's.
 #pragma unroll
-      for (int q = 15; q >= 0; --q) {
-        int cq = c;
-        asm volatile("" : "+v"(cq));
-        float a = cq == q ? 1.f : 0.f;
-        if (q < nreal) {
-#pragma unroll
-          for (int mm = q + 1; mm < 16; ++mm) bsm_fmac_bc(a, Sr[q], Tr[mm], mm);  // a -= L[mm][q] T[c][mm]
-          a *= invs[q];
-        }
-        Tr[q] = a;
+      for (int q = 0; q < 16; ++q) {
+        Tr[q] = 0.f;
+        bsm_sel(Tr[q], 1.0f, 0x0001000100010001ull << q);
       }
+#pragma unroll
+      for (int mm = 15; mm >= 0; --mm) {
+        if (mm < nreal) {
+          Tr[mm] *= invs[mm];
+#pragma unroll
+          for (int q = mm - 1; q >= 0; --q) bsm_fmac_bc(Tr[q], Sr[q], Tr[mm], mm);  // T[c][q] -= L[mm][q] T[c][mm]
+        }
+      }
+      float* Tk = Tb + k * 16 * LDP;
       if (g == 0) {
 #pragma unroll
-        for (int q = 0; q < 16; q += 4) *reinterpret_cast<f32x4*>(Tb + c * LDP + q) = f32x4{Tr[q], Tr[q + 1], Tr[q + 2], Tr[q + 3]};
+        for (int q = 0; q < 16; q += 4) *reinterpret_cast<f32x4*>(Tk + c * LDP + q) = f32x4{Tr[q], Tr[q + 1], Tr[q + 2], Tr[q + 3]};
       }
       wave_lds_fence();
+      if (k + 1 < NB) {
+        const f32x4 top = *reinterpret_cast<const f32x4*>(Tk + c * LDP + 4 * g);  // A operand of T_kk: [row c][4 g + s]
+        // ---- U_ki = T_kk A_ki ----------------------------------------------------------------------------------------------------------
 #pragma unroll
-      for (int r = 0; r < 4; ++r) T[k][k][r] = Tb[(4 * g + r) * LDP + c];
-      const f32x4 top = *reinterpret_cast<const f32x4*>(Tb + c * LDP + 4 * g);  // A operand of T_kk: [row c][4 g + s]
-      // ---- U_ki = T_kk A_ki ------------------------------------------------------------------------------------------------------------
+        for (int i = k + 1; i < NB; ++i) {
+          f32x4 u = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = k + 1; i < NB; ++i) {
-        f32x4 u = {0.f, 0.f, 0.f, 0.f};
+          for (int q = 0; q < 4; ++q) u = __builtin_amdgcn_mfma_f32_16x16x4f32(top[q], acc[k][i][q], u, 0, 0, 0);
+          acc[k][i] = u;
+        }
+        // ---- A_ij -= U_ki^T U_kj -------------------------------------------------------------------------------------------------------
 #pragma unroll
-        for (int q = 0; q < 4; ++q) u = __builtin_amdgcn_mfma_f32_16x16x4f32(top[q], acc[k][i][q], u, 0, 0, 0);
-        acc[k][i] = u;
+        for (int i = k + 1; i < NB; ++i) {
+          const f32x4 nu = -acc[k][i];
+#pragma unroll
+          for (int jb = i; jb < NB; ++jb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(nu[q], acc[k][jb][q], acc[i][jb], 0, 0, 0);
+        }
       }
-      // ---- A_ij -= U_ki^T U_kj ---------------------------------------------------------------------------------------------------------
-#pragma unroll
-      for (int i = k + 1; i < NB; ++i) {
-        const f32x4 nu = -acc[k][i];
-#pragma unroll
-        for (int jb = i; jb < NB; ++jb)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc[i][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(nu[q], acc[k][jb][q], acc[i][jb], 0, 0, 0);
-      }
-      // ---- block row k of T = L^-1 -----------------------------------------------------------------------------------------------------
-#pragma unroll
-      for (int i = 0; i < k; ++i) {
-        f32x4 sa = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int l2 = i; l2 < k; ++l2)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) sa = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[l2][k][q], T[l2][i][q], sa, 0, 0, 0);
-        f32x4 tn = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) tn = __builtin_amdgcn_mfma_f32_16x16x4f32(-top[q], sa[q], tn, 0, 0, 0);
-        T[k][i] = tn;
-      }
-      wave_lds_fence();  // (Ab / Tb are rewritten by the next panel)
     }
+    // ---- T = L^-1 block row by block row (after the factorisation: its blocks and the trailing matrix are not live together, which is what
+    // ---- lets three waves per SIMD hold their registers): T_ki = -T_kk sum_{l = i .. k-1} U_lk^T T_li ------------------------------------
+    f32x4 T[NB][NB];  // blocks (row block, column block <= row block)
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const float* Tk = Tb + k * 16 * LDP;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[k][k][r] = Tk[(4 * g + r) * LDP + c];
+      if (k > 0) {
+        const f32x4 top = *reinterpret_cast<const f32x4*>(Tk + c * LDP + 4 * g);
+#pragma unroll
+        for (int i = 0; i < k; ++i) {
+          f32x4 sa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int l2 = i; l2 < k; ++l2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sa = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[l2][k][q], T[l2][i][q], sa, 0, 0, 0);
+          f32x4 tn = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) tn = __builtin_amdgcn_mfma_f32_16x16x4f32(-top[q], sa[q], tn, 0, 0, 0);
+          T[k][i] = tn;
+        }
+      }
+    }
+    wave_lds_fence();  // (Ab / Tb are rewritten by the next node)
     // ---- per position: log-pivots, off-diagonal column norms of T without the row of j, the row of j ---------------------------------
     const float sf = 1.0f + __shfl(dm1, dl1, 64);  // s = R_jj - b^T M_pa^-1 b: the last pivot
     const double sch = (double)sf;
     float offd = 0.f, yrow = 0.f;
+    {
+      // row d-1 (node j) lives in block row jb, in the lanes / register with 4 g + r == (d-1) % 16: taken out as the y row and left out of
+      // the column norms; only that block row pays for the test (wave-uniform branch)
+      const int jb = dl1 >> 4, rl = dl1 & 15;
+      const bool mr[4] = {4 * g == rl, 4 * g + 1 == rl, 4 * g + 2 == rl, 4 * g + 3 == rl};
+      const bool lo[4] = {4 * g > c, 4 * g + 1 > c, 4 * g + 2 > c, 4 * g + 3 > c};  // below the diagonal inside a diagonal block
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      float o = 0.f, yv = 0.f;
-      const int col = 16 * i + c;
+      for (int i = 0; i < NB; ++i) {
+        float o = 0.f, yv = 0.f;
 #pragma unroll
-      for (int jr = i; jr < NB; ++jr)
+        for (int jr = i; jr < NB; ++jr) {
+          f32x4 tv = T[jr][i];
+          if (jr == jb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * jr + 4 * g + r;
-          const float tv = T[jr][i][r];
-          o = fmaf((row > col && row != dl1) ? tv : 0.f, tv, o);
-          yv = row == dl1 ? tv : yv;
+            for (int r = 0; r < 4; ++r) {
+              yv = mr[r] ? tv[r] : yv;
+              tv[r] = mr[r] ? 0.f : tv[r];
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o = fmaf((jr > i || lo[r]) ? tv[r] : 0.f, tv[r], o);
         }
-      o += __shfl_xor(o, 16, 64);
-      o += __shfl_xor(o, 32, 64);
-      yv += __shfl_xor(yv, 16, 64);
-      yv += __shfl_xor(yv, 32, 64);
-      offd = g == i ? o : offd;
-      yrow = g == i ? yv : yrow;
+        o += __shfl_xor(o, 16, 64);
+        o += __shfl_xor(o, 32, 64);
+        yv += __shfl_xor(yv, 16, 64);
+        yv += __shfl_xor(yv, 32, 64);
+        offd = g == i ? o : offd;
+        yrow = g == i ? yv : yrow;
+      }
     }
     const float y = lane < dl1 ? -yrow * sqrtf(sf) : 0.f;  // y = M_pa^-1 b by position (0 for j itself: row j of M_pa is the identity, b_j = 0)
     if (act) pyv[v] = p * y;
@@ -247,8 +334,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const double Nn = bp.Nj[j], al = bp.alpha_lambd;
     const double a1 = 0.5 * (Nn + al - d + l + 1.0), a2 = 0.5 * (al - d + l + 1.0), c2 = a1;
     const double arg = lane < 8 ? a1 + lane : lane < 16 ? a2 + (lane - 8) : lane == 16 ? a1 + 8.0 : lane == 17 ? a2 + 8.0 : lane == 18 ? sch : 1.0;
-    const double X = log(arg), Rc = 1.0 / arg;
-    const double logpiv = lane < dl1 ? log((double)(1.0f + dm1)) : 0.0;
+    // (float logarithm / reciprocal of the double argument: 1e-7 relative on terms of size <= 300 -- the factorisation's rounding is 1e3 times that)
+    const double X = bsm_log((float)arg), Rc = (double)(1.0f / (float)arg);
+    const double logpiv = lane < dl1 ? bsm_log(1.0f + dm1) : 0.0;  // (1e-7 absolute per pivot: the factorisation's own rounding is 1e3 times that)
     const double cg = lane < 8 ? -1.0 : lane < 16 ? 1.0 : lane == 16 ? a1 + 7.5 : lane == 17 ? -(a2 + 7.5) : 0.0;
     const double s1 = wave_sum_d(cg * X - 0.5 * logpiv);  // lgamma(a1) - lgamma(a2) - 1/2 logdet M_pa without the series and the linear term
     const double s2 = wave_sum_d(lane < 8 ? -Rc : lane < 16 ? Rc : lane == 16 ? X : lane == 17 ? -X : 0.0);
@@ -263,8 +351,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (act) {
       const float* Rrow = R + v * d;
       float t_r = -pyv[v] - R[j * d + v];  // (R - I) (p o y) - R_j
+      if ((d & 1) == 0) {  // (rows of R are 8-byte aligned)
+        float t_2 = 0.f;
+#pragma unroll 4
+        for (int bb = 0; bb < d; bb += 2) {
+          const float2 r2 = *reinterpret_cast<const float2*>(Rrow + bb), y2 = *reinterpret_cast<const float2*>(pyv + bb);
+          t_r = fmaf(r2.x, y2.x, t_r);
+          t_2 = fmaf(r2.y, y2.y, t_2);
+        }
+        t_r += t_2;
+      } else {
 #pragma unroll 8
-      for (int bb = 0; bb < d; ++bb) t_r = fmaf(Rrow[bb], pyv[bb], t_r);
+        for (int bb = 0; bb < d; ++bb) t_r = fmaf(Rrow[bb], pyv[bb], t_r);
+      }
       // 1 - (M_pa^-1)_vv = (L_vv^2 - 1) / L_vv^2 - |off-diagonal part of column v of L^-1|^2, each term O(p_v^2)
       const float h_r = p > 0.f ? (dm1 / (1.0f + dm1) - offd) / p : 0.f;
       const double dl = Nn > 0.0 ? gprime - 0.5 * ls - (double)h_r - (2.0 * c2 / sch) * (double)y * (double)t_r : 0.0;
