@@ -138,7 +138,7 @@ def roofline_of(dom, avg_s, cfgname, M, K, eng_counters):
                         frac_of_f16_peak=f16_flops / avg_s / 1e12 / PEAK_BF16_TFLOPS)
     elif dom in ("nn_theta", "nn_z"):
         flops = M * S_MC * d * (2 * N_OBS * d * H + 2 * N_OBS * H)
-        roof.update(rocprof_kernel="k_nn_logprobs_hf + k_nn_grad", pipe="mfma_f16 (log-probs: 2 block-scaled pieces per operand) + mfma_f32 (gradients of the samples with non-zero weight)",
+        roof.update(rocprof_kernel=("k_nn_logprobs_hx" if d > 64 else "k_nn_logprobs_hf") + " + k_nn_grad", pipe="mfma_f16 (log-probs: 2 block-scaled pieces per operand) + mfma_f32 (gradients of the samples with non-zero weight)",
                     flops_per_launch=flops, achieved=flops / avg_s / 1e12,
                     flops_model="M*S*d*(2NdH + 2NH): forward pass of one estimator (a third of SURVEY 8(d) F_lik(NN) per estimator)")
     elif dom in ("phi_update", "kmat"):
@@ -334,10 +334,10 @@ def main():
             "exchange": "allgather_us / allgather_bytes_per_rank: the collective on the critical path of a step, timed alone through torch.distributed "
                         "(packed protocol: the rows [z | grad_z | theta | grad_theta]; overlapped protocol: the gradient rows -- the values travel on a "
                         "side stream beside phase A)",
-            "strong_scaling_bound": "128 particles: a rank's step is five dependent launches of 10-24 us that do not shrink with the shard "
-                                    "(profiles/round3_shard_scaling.txt: 223 / 173 / 118 / 100 us per rank-step at 1/2/4/8 ranks on one GPU, "
-                                    "before the collective) => <= 2.2x at 8 GPUs; the >= 6x of north_star needs per-rank work >> launch "
-                                    "latency, i.e. config 4 (1024 particles, 128 per rank)"}
+            "strong_scaling_bound": "128 particles: a rank's step is a chain of dependent launches of 7-20 us that shrink little with the shard "
+                                    "(profiles/round4_shard_scaling.txt: 190 / 144 / 106 / 91 us per rank-step at 1/2/4/8 ranks on one GPU in the "
+                                    "in-engine loop, before the collective) => <= 2.1x at 8 GPUs; the >= 6x of north_star needs per-rank work >> "
+                                    "launch latency, i.e. config 4 (1024 particles, 128 per rank)"}
         if args.config == "headline":
             eng.close()
             e4, _, _, rep4, _, _ = measure("4", 1024, 3, 0.5)
