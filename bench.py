@@ -335,8 +335,8 @@ def main():
                         "(packed protocol: the rows [z | grad_z | theta | grad_theta]; overlapped protocol: the gradient rows -- the values travel on a "
                         "side stream beside phase A)",
             "strong_scaling_bound": "128 particles: a rank's step is a chain of dependent launches of 7-20 us that shrink little with the shard "
-                                    "(profiles/round4_shard_scaling.txt: 190 / 144 / 106 / 91 us per rank-step at 1/2/4/8 ranks on one GPU in the "
-                                    "in-engine loop, before the collective) => <= 2.1x at 8 GPUs; the >= 6x of north_star needs per-rank work >> "
+                                    "(profiles/round4_shard_scaling.txt: 194 / 151 / 108 / 96 us per rank-step at 1/2/4/8 ranks on one GPU in the "
+                                    "in-engine loop, before the collective) => <= 2.0x at 8 GPUs; the >= 6x of north_star needs per-rank work >> "
                                     "launch latency, i.e. config 4 (1024 particles, 128 per rank)"}
         if args.config == "headline":
             eng.close()

@@ -120,9 +120,12 @@ void acyc_launch_power(const AcycLaunch& a) {
     } else {
 #undef ACYC_SRC
 #define ACYC_SRC a.scores, a.eas
-      static const bool wpe3 = getenv("DIBS_ACYC_WPE4") == nullptr;  // three waves per SIMD (no spills, M's fragments kept); DIBS_ACYC_WPE4=1: four (A/B runs)
-      if (wpe3) {
+      // three waves per SIMD (no spills, M's fragments kept); DIBS_ACYC_WPE=2 / 4: two / four (A/B runs)
+      static const int wpe = getenv("DIBS_ACYC_WPE") ? atoi(getenv("DIBS_ACYC_WPE")) : (getenv("DIBS_ACYC_WPE4") ? 4 : 3);
+      if (wpe == 3) {
         if (a.d > 48) ACYC_BF_LAUNCH((k_acyc_hf<true, 3>)) else ACYC_BF_LAUNCH((k_acyc_hf<false, 3>))
+      } else if (wpe == 2) {
+        if (a.d > 48) ACYC_BF_LAUNCH((k_acyc_hf<true, 2>)) else ACYC_BF_LAUNCH((k_acyc_hf<false, 2>))
       } else {
         if (a.d > 48) ACYC_BF_LAUNCH((k_acyc_hf<true, 4>)) else ACYC_BF_LAUNCH((k_acyc_hf<false, 4>))
       }
