@@ -212,6 +212,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    loop_note = {}
+
     def measure(cfgname, M_, reps_min, min_seconds):
         """Engine + runner for one workload; returns (engine, run, snapshot at t = W, per-repetition seconds)."""
         cfg, x, mask = make_workload(cfgname, M_, rank, N, local_rank)
@@ -226,12 +228,35 @@ def main():
         ex = os.environ.get("DIBS_BENCH_EXCHANGE", "overlapped" if M_ >= 512 else "packed")
         overlapped = ex == "overlapped"
         tstream = torch.cuda.Stream() if sharded else None
-        eng = Engine(cfg, stream=tstream.cuda_stream if torch_loop else None)
-        eng.set_data(x, mask)
-        eng.init_particles(random.PRNGKey(1))
+
+        def new_engine(on_torch_stream):
+            e_ = Engine(cfg, stream=tstream.cuda_stream if on_torch_stream else None)
+            e_.set_data(x, mask)
+            e_.init_particles(random.PRNGKey(1))
+            return e_
+
+        eng = new_engine(torch_loop)
         if sharded and not torch_loop:
+            # the in-engine communicator has to come up on EVERY rank; if it does not on any (an RCCL build that refuses the ids, a missing
+            # symbol), all ranks agree on the Python-driven loop over torch.distributed -- the same HIP step, the collective issued by torch
             from dibs_amd.distributed import init_native_comm
-            init_native_comm(eng, None, 2 if overlapped else 1)
+            err = ""
+            try:
+                if os.environ.get("DIBS_BENCH_FAIL_NATIVE"):   # (tests: exercise the agreement + fallback below)
+                    raise RuntimeError("DIBS_BENCH_FAIL_NATIVE is set")
+                init_native_comm(eng, None, 2 if overlapped else 1)
+            except Exception as ex_:   # noqa: BLE001
+                err = f"{type(ex_).__name__}: {ex_}"
+            flag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if rank == 0:
+                    print(f"bench: in-engine RCCL communicator failed ({err or 'on another rank'}); using the torch.distributed loop", file=sys.stderr)
+                eng.close()
+                torch_loop = True
+                loop_note["loop"] = "torch.distributed (in-engine communicator failed: " + (err or "on another rank") + ")"
+                eng = new_engine(True)
+        if sharded and not torch_loop:
             n_el = eng.plane_elems_per_rank() if overlapped else eng.gather_elems_per_rank()
             send = torch.zeros(n_el, device="cuda")            # (only for the stand-alone timing of the collective below)
             recv = torch.zeros(n_el * N, device="cuda")
@@ -307,6 +332,8 @@ def main():
                             "first5": [1e3 * r / K for r in rep_s[:5]]},
         "rep_spread": (float(np.percentile(rep_s, 90)) - float(np.percentile(rep_s, 10))) / elapsed,
     }
+    if loop_note:
+        out["config"]["parallelism"] = f"particles sharded over {N} rank(s), step loop driven from Python, collectives by " + loop_note["loop"]
 
     if sharded:
         # ---- diagnosis of a sharded run: per-rank kernel timers, the collective alone, config 4 beside the strong-scaling headline ----

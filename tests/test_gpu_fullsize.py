@@ -448,3 +448,10 @@ def test_bench_sharded_path_on_one_gpu():
     assert sh["allgather_us"] > 0 and sh["allgather_bytes_per_rank"] == 128 * 10000 * 4 and len(sh["kernel_us_per_step_by_rank"]) == 1
     assert "in-engine" in out["config"]["parallelism"] or "inside the engine" in out["config"]["parallelism"]
     assert out["config4"]["value"] > 10
+    # a communicator that does not come up on some rank: every rank falls back to the Python-driven loop over torch.distributed
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dist-smoke", "--steps", "4", "--warmup", "3", "--reps", "2",
+                        "--min-seconds", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600,
+                       env=dict(env, DIBS_BENCH_FAIL_NATIVE="1"), cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out2 = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out2["value"] > 100 and "torch.distributed" in out2["config"]["parallelism"]
