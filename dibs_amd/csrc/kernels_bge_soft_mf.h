@@ -80,10 +80,17 @@ __device__ __forceinline__ float bsm_bcast(const float& v, int n) {
 #undef BSM_BC
   return o;
 }
-// x = lane in `mask` ? y : x with the lane set as a 64-bit CONSTANT in an SGPR pair (s_mov on the scalar unit): one vector instruction where
-// a test on the lane index costs v_cmp + v_cndmask -- or, hoisted out of the node loop as 64 live masks, SGPR spills
+// x = lane in `mask` ? y : x for a CONSTANT lane set: the mask is moved into vcc by two scalar instructions in front of the v_cndmask -- one
+// vector instruction where a test on the lane index costs v_cmp + v_cndmask.  (As "s" operands the 80 masks of a problem were hoisted out
+// of the node loop into 160 SGPRs, i.e. parked in VGPR lanes: a v_readlane pair per use.)
 __device__ __forceinline__ void bsm_sel(float& x, const float& y, uint64_t mask) {
-  asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(x) : "v"(y), "s"(mask));
+  asm("s_mov_b32 vcc_lo, %2\n\ts_mov_b32 vcc_hi, %3\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(y), "i"((uint32_t)mask), "i"((uint32_t)(mask >> 32)) : "vcc");
+}
+// x = lane in `mask` ? 1 : 0
+__device__ __forceinline__ float bsm_ind(uint64_t mask) {
+  float x;
+  asm("s_mov_b32 vcc_lo, %1\n\ts_mov_b32 vcc_hi, %2\n\tv_cndmask_b32 %0, 0, 1.0, vcc" : "=v"(x) : "i"((uint32_t)mask), "i"((uint32_t)(mask >> 32)) : "vcc");
+  return x;
 }
 __device__ __forceinline__ void bsm_nops(int n) {  // n wait states
   if (n == 1) asm volatile("s_nop 0");
@@ -226,10 +233,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       // term -L[m][q] T[c][m] -- independent multiply-adds (the column-by-column form is one dependent chain per column).  Padding columns
       // are the identity's.
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        Tr[q] = 0.f;
-        bsm_sel(Tr[q], 1.0f, 0x0001000100010001ull << q);
-      }
+      for (int q = 0; q < 16; ++q) Tr[q] = bsm_ind(0x0001000100010001ull << q);
 #pragma unroll
       for (int mm = 15; mm >= 0; --mm) {
         if (mm < nreal) {
