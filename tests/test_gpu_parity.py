@@ -957,6 +957,40 @@ def test_marginal_bge_reparam_estimator(d, M, S, Sa, interv):
     eng.close()
 
 
+def test_marginal_bge_reparam_free_running_30_steps():
+    """MarginalDiBS with the reparam estimator (soft-graph BGe, k_bge_soft_mf) free-running for 30 steps from PRNGKey(9) against the torch-autograd
+    oracle (float64) on the same inputs: Z within north_star's 1e-4 of max |Z|, identical keys, identical limit graphs."""
+    import torch
+    from oracle import dibs_oracle as O
+    d, M, S, Sa, steps = 12, 4, 8, 4, 30
+    data, _, _ = make_data(d, seed=4)
+    x = data.x.astype(np.float32)
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=x.shape[0], edges_per_node=2, grad_estimator_z="reparam",
+                      n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa)
+    ocfg = O.Config(likelihood="bge", grad_estimator_z="reparam", n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa, prior=O.GraphPrior("er", 2))
+    st = O.init_state(ocfg, prng.PRNGKey(9), M, d)
+    eng = _engine(cfg, x, None)
+    eng.init_particles(prng.PRNGKey(9))
+    xt = torch.as_tensor(x.astype(np.float64))
+    it = torch.zeros_like(xt)
+    for t in range(steps):
+        st = O.svgd_step(ocfg, st, xt, it, t)
+    eng.run(0, steps)
+    g = eng.get_state()
+    eng.close()
+    z_o = st.z.numpy()
+    err = rel_err(g["z"], z_o)
+    print(f"soft BGe free run, {steps} steps: Z rel {err:.2e}")
+    assert (g["key"] == st.key).all()
+    assert err < 1e-4
+
+    def lim(z):   # particle_to_g_lim (dibs.py:84-100): edge i -> j iff u_i . v_j > 0, no self loops
+        gl = np.einsum("mik,mjk->mij", z[..., 0], z[..., 1]) > 0
+        gl[:, np.arange(d), np.arange(d)] = False
+        return gl
+    assert np.array_equal(lim(g["z"].astype(np.float64)), lim(z_o))
+
+
 def test_config2_free_running_200_steps(c_oracle64):
     """north_star's criterion on BASELINE.json configs[1] (MarginalDiBS + BGe, d=20, 32 particles): Z within 1e-4 relative of
     the (float64) oracle after N free-running steps on identical PRNG-seeded inputs, and the same posterior graphs / E-SHD.
