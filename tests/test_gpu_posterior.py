@@ -140,7 +140,7 @@ def _device_joint(name):
             st = eng.get_state()
             sm = gen.summarise(dibs, g_true, st["z"], st["theta"], d, M)
             out["eshd"][si, ci], out["edges"][si, ci], out["graphs"][si, ci] = sm["eshd"], sm["edges"], sm["graphs"]
-            out["z_keep"][si, ci], out["t_keep"][si, ci] = sm["z_keep"], sm["t_keep"]
+            out["z_keep"][si, ci], out["t_keep"][si, ci] = sm["z_keep"][:out["z_keep"].shape[2]], sm["t_keep"][:out["t_keep"].shape[2]]
         eng.close()
     return fx, d, M, cps, seeds, out
 
@@ -158,7 +158,7 @@ def _joint_report(name, fx, cps, seeds, out):
         rows[cp] = dict(same=same, de=de, ez=ez, et=et)
         line = (f"{name} step {cp}: identical graphs gpu/f64 {np.round(same, 3)}  dE-SHD {np.round(de, 3)}  "
                 f"rel dZ {np.array2string(ez, precision=1)}  rel dtheta {np.array2string(et, precision=1)}")
-        if s32:
+        if s32 and ci < fx["graphs_f32"].shape[1]:   # (a float32 trajectory that was cut short holds fewer checkpoints)
             idx = [seeds.index(s) for s in s32 if s in seeds]
             j32 = [s32[seeds[i]] for i in idx]
             same32 = (fx["graphs_f32"][j32, ci] == fx["graphs_f64"][idx, ci]).all(axis=2).mean(axis=1)
@@ -177,11 +177,15 @@ def _joint_report(name, fx, cps, seeds, out):
 TOL_JOINT = {
     # config 3 (E-SHD ~ 210 of 1225; one flipped edge in one of 128 particles moves it by ~0.008).  Step 100: all 128 graphs equal the oracle's
     # (still empty: E-SHD = the 116 true edges), Z within 2e-5, theta within 2e-7 of max |.|.  From step 500 on NO particle's 2450-entry graph
-    # equals the oracle's -- for the oracle's own float32 build neither (seed 0: E-SHD f32 - f64 = -3.08 at step 500, -1.73 at step 1000;
-    # gpurun_out log of the round-4 generation run, the f32 trajectory itself was cut off by the box's time limit) -- device seed 0: +0.72 / +1.15 / +0.03.
+    # equals the oracle's -- for the oracle's own float32 build neither (seed 0: E-SHD f32 - f64 = -3.08 at step 500, -1.73 at step 1000; its Z is
+    # 0.7 of max |Z| away from the f64 build's already at step 100, where the device is at 2e-5: the device keeps the softmax / log-sum-exp
+    # stages in double, an all-float32 evaluation does not survive 100 steps of this model) -- device seed 0: +0.72 / +1.15 / +0.03.
     # Bound 4.0 = the largest float32-build difference seen x 1.3.
     "config3": {100: (1.0, 1e-3, 1e-4), 500: (0.0, 4.0, np.inf), 1000: (0.0, 4.0, np.inf), 2000: (0.0, 4.0, np.inf)},
-    "config5": {10: (1.0, 1e-3, 1e-4), 25: (1.0, 1e-3, 1e-4), 50: (0.0, np.inf, np.inf), 100: (0.0, np.inf, np.inf)},
+    # config 5 (256 particles, d = 100, 100 steps = BASELINE configs[4]): every particle's graph equals the oracle's at all four checkpoints (the
+    # limit graphs are still empty after 100 steps of this annealing schedule: E-SHD = the 197 true edges), Z within 7e-7 and theta within 1.8e-5
+    # of max |.| -- north_star's own numbers (E-SHD 1e-3, Z 1e-4) are asserted at every checkpoint
+    "config5": {10: (1.0, 1e-3, 1e-4), 25: (1.0, 1e-3, 1e-4), 50: (1.0, 1e-3, 1e-4), 100: (1.0, 1e-3, 1e-4)},
 }
 
 
