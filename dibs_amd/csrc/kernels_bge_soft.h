@@ -394,7 +394,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #ifdef DIBS_TU_BGE_SOFT
 #include "kernels_bge_soft_mf.h"
 // softmax over the samples and W = sum_s w_s dS_s (samples with w_s == 0 in float are skipped, in sample order)
-// grid = Mloc, block = 256; dynamic LDS = S * 8
+// grid = (Mloc, ceil(d*d / 256)), block = 256: every block of a particle evaluates the S weights itself (128 exponentials) and sums one
+// 256-element slice of the S x d x d gradients -- with one block per particle half of the CUs stood idle behind 164 MB of reads (126 us).
+// dynamic LDS = S * 4 + 16
 __global__ __launch_bounds__(256) void k_soft_combine(const float* __restrict__ ds, const float* __restrict__ logprobs,
                                                       float* __restrict__ w_lik, int d, int S) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(256) void k_soft_combine(const float* __restrict__ 
   for (int s = tid; s < S; s += 256) wt[s] = (float)(exp((double)lp[s] - mx) / den);
   __syncthreads();
   const int dd = d * d;
-  for (int e = tid; e < dd; e += 256) {
+  for (int e = blockIdx.y * 256 + tid; e < dd; e += 256 * gridDim.y) {
     float acc = 0.f;
     for (int s = 0; s < S; ++s) {
       const float w = wt[s];
@@ -489,7 +491,7 @@ void bge_soft_launch(const BgeSoftParams& sp, const float* scores, Key2 carry, i
     if (rl) SOFT_LAUNCH(true, 2) else SOFT_LAUNCH(false, 2)
   }
 #undef SOFT_LAUNCH
-  hipLaunchKernelGGL(k_soft_combine, dim3(Mloc), dim3(256), (size_t)S * 4 + 16, stream, soft_ds, logprobs, w_lik, d, S);
+  hipLaunchKernelGGL(k_soft_combine, dim3(Mloc, (d * d + 255) / 256), dim3(256), (size_t)S * 4 + 16, stream, soft_ds, logprobs, w_lik, d, S);
 }
 #else
 void bge_soft_launch(const BgeSoftParams& sp, const float* scores, Key2 carry, int m0, int M, int Mloc, int d, int S, float alpha,
