@@ -225,7 +225,7 @@ def section_d(rng, n):
         M, S, Sa = int(rng.choice([1, 2])), int(rng.choice([1, 2, 4])), int(rng.choice([1, 2]))
         N = int(rng.choice([5, 40]))
         if os.environ.get("FUZZ_SOFT_BIG"):   # the upper end of the soft-graph BGe kernel's range (torch-autograd oracle: slow)
-            d, M, S, Sa = int(rng.choice([20, 33, 50, 64])), 1, int(rng.choice([1, 2])), 1
+            d, M, S, Sa = int(rng.choice([16, 17, 20, 31, 32, 33, 40, 47, 48, 49, 50, 57, 63, 64])), 1, int(rng.choice([1, 2])), 1   # (block boundaries of k_bge_soft_mf)
         x = data(rng, N, d)
         interv = rng.random() < 0.3
         mask = (rng.random((N, d)) < 0.15).astype(np.int32) if interv else None
