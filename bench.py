@@ -173,7 +173,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="headline", choices=list(CONFIGS))
     ap.add_argument("--reps", type=int, default=7, help="minimum repetitions of the timed window (median reported)")
-    ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the timed window until the timed regions add up to this much")
+    ap.add_argument("--min-seconds", type=float, default=8.0, help="repeat the timed window until the timed regions add up to this much")
     ap.add_argument("--n-particles", type=int, default=None, help="override the particle count of the config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-smoke", action="store_true",
@@ -240,15 +240,26 @@ def main():
             # the in-engine communicator has to come up on EVERY rank; if it does not on any (an RCCL build that refuses the ids, a missing
             # symbol), all ranks agree on the Python-driven loop over torch.distributed -- the same HIP step, the collective issued by torch
             from dibs_amd.distributed import init_native_comm
+            # Two agreements: (1) a LOCAL probe -- librccl loads and exports every symbol the engine binds (drawing a unique id touches all of
+            # that and no other rank) -- agreed on BEFORE anybody enters the blocking ncclCommInitRank, so that a rank whose library is
+            # unusable cannot leave the others stuck inside the bring-up; (2) the bring-up itself.  A failure INSIDE ncclCommInitRank on a
+            # subset of the ranks is fatal by RCCL's own rules (the other ranks block until its timeout aborts the job) -- not recoverable here.
             err = ""
             try:
                 if os.environ.get("DIBS_BENCH_FAIL_NATIVE"):   # (tests: exercise the agreement + fallback below)
                     raise RuntimeError("DIBS_BENCH_FAIL_NATIVE is set")
-                init_native_comm(eng, None, 2 if overlapped else 1)
+                eng.comm_unique_ids(1)
             except Exception as ex_:   # noqa: BLE001
                 err = f"{type(ex_).__name__}: {ex_}"
             flag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                try:
+                    init_native_comm(eng, None, 2 if overlapped else 1)
+                except Exception as ex_:   # noqa: BLE001
+                    err = f"{type(ex_).__name__}: {ex_}"
+                flag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 if rank == 0:
                     print(f"bench: in-engine RCCL communicator failed ({err or 'on another rank'}); using the torch.distributed loop", file=sys.stderr)
@@ -421,7 +432,7 @@ def main():
             # ---- CPU baseline: the oracle's C port on this box's host cores, bounded sample of the SAME window (from t = W) ----
             from oracle.c_oracle import COracle
             from dibs_amd._abi import DibsConfig
-            cores = min(os.cpu_count() or 1, M)   # OpenMP over particles: more threads than particles are idle
+            cores = min(os.cpu_count() or 1, M)   # OpenMP THREADS used (os.cpu_count() counts hardware threads, not physical cores); over particles: more threads than particles are idle
             cfg1 = DibsConfig.from_buffer_copy(cfg)
 
             def cpu(prec, n_steps, mode):
@@ -438,7 +449,7 @@ def main():
             out["cpu_baseline"] = {"value": faithful, "unit": "steps/s", "cores": cores, "kind": "port",
                                    "sample": f"{n_cpu} steps (t={W}..{W + n_cpu - 1}) of the same workload from the same state, f32 C port of the "
                                              "reference algorithm" + (" (masked d x d LU slogdet per node, func.py:128-145)" if c["model"] == "bge" else "")
-                                             + ", OpenMP over particles"}
+                                             + f", OpenMP over particles on {cores} threads (hardware threads of the host, not physical cores)", "threads": cores}
             if c["model"] == "bge":
                 out["cpu_baseline_compact_f32"] = {"value": cpu("f32", n_cpu, 1), "unit": "steps/s", "cores": cores, "kind": "port",
                                                    "sample": f"{n_cpu} steps, same port with the GPU's compact parent-set Cholesky"}

@@ -843,7 +843,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
     {
       KTimer tm(e, DIBS_K_LIN_Z);      // ("lin_grad": the theta and the Z estimator in one launch)
       joint_lin_all_grads(&e->jw, jl, carry_theta, carry_lik);
-      std::swap(e->baseline, e->baseline2);
+      if (!xk) std::swap(e->baseline, e->baseline2);  // (explicit-key evaluation: the loop's baselines stay, the updated ones are read from baseline2)
     }
   } else if (c.likelihood == DIBS_LIK_DENSENN) {
     JointLaunch jl{e->stream, e->z, e->theta, e->scores, e->thr, e->w_lik, e->logprobs_z, e->logprobs_th, e->baseline,
@@ -859,7 +859,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
       KTimer tm(e, DIBS_K_NN_Z);
       if (joint_nn_dispatch(&e->jw, jl, carry_lik, c.grad_estimator_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM, np_, (size_t)e->P))
         return fail("DenseNonlinearGaussian: scratch area: hipMalloc failed");
-      std::swap(e->baseline, e->baseline2);
+      if (!xk) std::swap(e->baseline, e->baseline2);  // (explicit-key evaluation: the loop's baselines stay, the updated ones are read from baseline2)
     }
   }
   if (fork) {
@@ -902,7 +902,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
       hipLaunchKernelGGL(k_backproject_big, dim3(e->Mloc, (e->d + 15) / 16, (e->k + 31) / 32), dim3(256), lb, e->stream, e->w_tot, e->z, pack, rt.stride,
                          rt.copy_vals, e->m0, e->d, e->k, inv_sig2);
     }
-    if (score_lik) std::swap(e->baseline, e->baseline2);
+    if (score_lik && !xk) std::swap(e->baseline, e->baseline2);
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(err));
@@ -929,6 +929,10 @@ static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_s
   const dibs_config& c = e->cfg;
   const bool kmat_ext = e->kmat_ext;  // computed from the gathered values on the caller's side stream (dibs_engine_kmat_values)
   e->kmat_ext = false;
+  // the particles move: plane 0 of the in-engine overlapped exchange no longer holds them (run_sharded's overlapped branch gathers the new
+  // values right behind this call and sets the flag again; every other caller -- packed protocol, dibs_engine_run, step_update -- leaves
+  // it cleared, so that the next overlapped chunk / gather_particles re-gathers instead of using the stale plane)
+  e->vals_fresh = false;
   if (!kmat_ext && !e->kmat_early && (!e->kmat_fused || c.joint)) {
     KTimer tm(e, DIBS_K_KMAT);
     const int ksym = e->Mloc == e->M;  // single rank: the slab is the whole (symmetric) matrix
@@ -1091,7 +1095,7 @@ extern "C" int dibs_engine_eval_gradients(dibs_engine* e, int32_t t, const uint3
     HIP_OK(hipStreamSynchronize(e->stream));
     if (grad_z_lik) HIP_OK(hipMemcpy2D(grad_z_lik, wz, rows + e->D, (size_t)e->E * 4, wz, e->Mloc, hipMemcpyDeviceToHost));
     if (grad_theta && e->P) HIP_OK(hipMemcpy2D(grad_theta, wt, rows + 2 * e->D + e->P, (size_t)e->E * 4, wt, e->Mloc, hipMemcpyDeviceToHost));
-    if (baseline_out) HIP_OK(hipMemcpy(baseline_out, e->baseline, (size_t)e->Mloc * 4, hipMemcpyDeviceToHost));
+    if (baseline_out) HIP_OK(hipMemcpy(baseline_out, e->baseline2, (size_t)e->Mloc * 4, hipMemcpyDeviceToHost));  // (not swapped in: see step_local)
   }
   if (want_prior) {
     HIP_OK(zero_w.alloc((size_t)e->Mloc * e->d * e->d));

@@ -32,6 +32,10 @@ struct JointWork {
   size_t nhf_pairs;  // allocated pairs (0: not allocated)
   void *nhx_w1s, *nhx_w1p;  // the same per a-QUAD and node (float4 / uint4) [Mloc][H][ceil(d/4)][d]: k_nn_logprobs_hx (kernels_nn_f16x.h)
   size_t nhx_quads;
+  // which table set belongs to the CURRENT theta: both are cleared by the theta pass (first estimator of a step) and set by whichever variant
+  // builds its tables, so that an estimator pass that takes the other variant than the theta pass did (the LDS size depends on soft / hard
+  // graphs) builds its own instead of reading stale or uninitialised tables
+  bool nhf_valid, nhx_valid;
   float* nng_scratch;         // general DenseNN path (kernels_nn_generic.h): activation records, grown on first use
   size_t nng_scratch_floats;
 };
@@ -986,6 +990,7 @@ int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) {
   w->nhf_pairs = 0;
   w->nhx_w1s = w->nhx_w1p = nullptr;
   w->nhx_quads = 0;
+  w->nhf_valid = w->nhx_valid = false;
   w->gram = nullptr;
   w->ncnt = nullptr;
   w->n_gram = 0;
@@ -1012,6 +1017,7 @@ void joint_free(JointWork* w) {
   w->nhf_w1s = w->nhf_w1p = nullptr;
   w->nhf_ew = nullptr;
   w->nhf_pairs = 0;
+  w->nhf_valid = w->nhx_valid = false;
   if (w->gram) hipFree(w->gram);
   if (w->ncnt) hipFree(w->ncnt);
   w->gram = nullptr;

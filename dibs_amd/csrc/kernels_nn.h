@@ -644,6 +644,7 @@ static bool joint_nn_logprobs_hf(JointWork* w, const JointLaunch& jl, Key2 carry
     const bool paired = jl.layout == 0 && (jl.S & 1) == 0 && (uint64_t)jl.S * jl.d * jl.d < 0xFFFFFFFFull;
     const bool soft = mode == LIN_MODE_Z_REPARAM;
     const size_t lds = nhf_lds_bytes(jl.d, NT, np_.H, soft);
+    if (mode == LIN_MODE_THETA) w->nhf_valid = w->nhx_valid = false;  // (theta moved since the last step)
     if (off || !paired || jl.N > 128 || !w->ln_tab) return false;
     static const int ppb_env = getenv("DIBS_NN_PPB") ? atoi(getenv("DIBS_NN_PPB")) : 0;
     const int hS = jl.S / 2, ppb = ppb_env > 0 ? ppb_env : ((hS / 4) * jl.Mloc >= 1024 ? 4 : (hS >= 2 ? 2 : 1));
@@ -664,17 +665,19 @@ static bool joint_nn_logprobs_hf(JointWork* w, const JointLaunch& jl, Key2 carry
           if (w->nhx_w1p) hipFree(w->nhx_w1p);
           w->nhx_w1s = w->nhx_w1p = nullptr;
           w->nhx_quads = 0;
+          w->nhx_valid = false;
           if (hipMalloc(&w->nhx_w1s, quads * 16) != hipSuccess || hipMalloc(&w->nhx_w1p, quads * 16) != hipSuccess) {
             (void)hipGetLastError();
             return false;
           }
           w->nhx_quads = quads;
         }
-        if (mode == LIN_MODE_THETA) {  // theta is the same for both estimators of a step: the tables are built once (theta runs first)
+        if (!w->nhx_valid) {  // theta is the same for both estimators of a step: the tables are built once per step and variant
           hipLaunchKernelGGL(k_nn_w1_exp, dim3(jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->nhf_ew, jl.d, np_.H);
           const int nq = ((jl.d + 3) / 4) * jl.d;
           hipLaunchKernelGGL(k_nn_tables_hx, dim3((nq + 255) / 256, np_.H, jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->nhf_ew,
                              (float4*)w->nhx_w1s, (uint4*)w->nhx_w1p, jl.d, np_.H);
+          w->nhx_valid = true;
         }
 #define NHX_LAUNCH(NTN_, ACT_, SOFT_)                                                                                                        \
         {                                                                                                                                    \
@@ -703,17 +706,19 @@ static bool joint_nn_logprobs_hf(JointWork* w, const JointLaunch& jl, Key2 carry
       if (w->nhf_w1p) hipFree(w->nhf_w1p);
       w->nhf_w1s = w->nhf_w1p = nullptr;
       w->nhf_pairs = 0;
+      w->nhf_valid = false;
       if (hipMalloc(&w->nhf_w1s, pairs * 8) != hipSuccess || hipMalloc(&w->nhf_w1p, pairs * 8) != hipSuccess) {
         (void)hipGetLastError();
         return false;
       }
       w->nhf_pairs = pairs;
     }
-    if (mode == LIN_MODE_THETA) {  // theta is the same for both estimators of a step: the tables are built once (theta runs first)
+    if (!w->nhf_valid) {  // (once per step and variant, see JointWork)
       hipLaunchKernelGGL(k_nn_w1_exp, dim3(jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->nhf_ew, jl.d, np_.H);
       const int npr = jl.d * (nhf_dp2(jl.d) / 2);
       hipLaunchKernelGGL(k_nn_tables_hf, dim3((npr + 255) / 256, np_.H, jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->nhf_ew,
                          (float2*)w->nhf_w1s, (uint2*)w->nhf_w1p, jl.d, np_.H);
+      w->nhf_valid = true;
     }
 #define NHF_LAUNCH(ACT_, SOFT_)                                                                                                               \
     {                                                                                                                                         \

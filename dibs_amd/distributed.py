@@ -156,7 +156,10 @@ def _all_particles(eng, buf, n_particles, group):
 
 def init_native_comm(engine, group=None, n_comms=2):
     """RCCL communicator(s) INSIDE the engine (dibs_engine_comm_init): rank 0 draws the unique ids, torch.distributed carries the bytes
-    to the other ranks (control plane only -- the data path of ``engine.run_sharded`` never touches torch)."""
+    to the other ranks (control plane only -- the data path of ``engine.run_sharded`` never touches torch).
+    ncclCommInitRank blocks until every rank of the group has entered it: callers that want a fallback must agree on a LOCAL probe
+    (``engine.comm_unique_ids(1)`` raises when librccl or one of its symbols is missing) across the ranks BEFORE calling this
+    (bench.py does); a failure inside the bring-up on a subset of the ranks is fatal (RCCL's timeout ends the job)."""
     import torch.distributed as dist
     box = [engine.comm_unique_ids(n_comms) if dist.get_rank(group) == 0 else None]
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)

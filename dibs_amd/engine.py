@@ -72,12 +72,14 @@ class Engine:
 
     def run(self, t_start, n_steps):
         _lib.check(self.lib.dibs_engine_run(self._h, int(t_start), int(n_steps)))
+        self.state_gen += 1   # (the particles moved without the overlapped exchange: its gathered values are stale)
 
     def step_local(self, t, send_ptr):
         _lib.check(self.lib.dibs_engine_step_local(self._h, int(t), C.c_void_p(send_ptr)))
 
     def step_update(self, t, recv_ptr):
         _lib.check(self.lib.dibs_engine_step_update(self._h, int(t), C.c_void_p(recv_ptr)))
+        self.state_gen += 1   # (packed protocol: plane 0 of dibs_amd.distributed's overlapped exchange does not follow)
 
     def gather_elems_per_rank(self):
         return int(self.lib.dibs_engine_gather_elems_per_rank(self._h))
@@ -126,6 +128,7 @@ class Engine:
 
     def run_sharded(self, t_start, n_steps, overlapped=False):
         _lib.check(self.lib.dibs_engine_run_sharded(self._h, int(t_start), int(n_steps), int(bool(overlapped))))
+        self.state_gen += 1
 
     def gather_particles(self):
         """z [M, d, k, 2] (and theta [M, P]) of all ranks' particles, on every rank"""

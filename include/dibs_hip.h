@@ -208,7 +208,9 @@ int dibs_engine_set_profiling(dibs_engine* e, int32_t enable);
  *   grad_z_lik  [Mloc][d][k][2] : estimator of grad_Z log p(theta, D | Z);  baseline_out [Mloc]: the updated score-function baselines
  *                                 (input baselines = the engine's state);  grad_theta [Mloc][P]: estimator of grad_theta (joint only)
  *   grad_z_prior [Mloc][d][k][2]: -beta(t) E[grad h] - Z / sigma_z^2 + grad log p(G_alpha(Z))
- * Any output may be NULL.  Blocking. */
+ * Any output may be NULL.  Blocking.  The loop state -- particles, optimizer moments, loop-carry key, score-function baselines -- is left
+ * untouched (the updated baselines are only returned); the per-step scratch of the engine (packed rows, W_lik, log-probabilities, queues)
+ * is overwritten, as by any step. */
 int dibs_engine_eval_gradients(dibs_engine* e, int32_t t, const uint32_t* keys_theta, const uint32_t* keys_lik, const uint32_t* keys_prior,
                                float* grad_z_lik, float* baseline_out, float* grad_theta, float* grad_z_prior);
 int dibs_engine_get_timers(dibs_engine* e, double* total_ms, int64_t* launches, int32_t n); /* arrays of DIBS_K_COUNT */

@@ -46,7 +46,12 @@ class OracleShardEngine:
         self.co.step_local(self.cfg, self.x, self.mask, self.st, t, self._view(send_ptr, self.Ml * self.E), n_threads=2)
 
     def step_update(self, t, recv_ptr):
+        if self._slab is not None:   # (the engine consumes a pending external slab here too: it must belong to the current particles)
+            own = self._slab.reshape(self.cfg.n_particles, self.Ev)[self.cfg.rank * self.Ml:(self.cfg.rank + 1) * self.Ml]
+            assert np.array_equal(own[:, :self.D], self.st["z"].reshape(self.Ml, self.D)), "stale kernel slab consumed by a packed step"
+            self._slab = None
         self.co.step_update(self.cfg, self._view(recv_ptr, self.cfg.n_particles * self.E), self.st, n_threads=2)
+        self.state_gen += 1       # as Engine.step_update: the particles moved without the overlapped exchange
 
     # ---- overlapped protocol (values and gradients travel separately; include/dibs_hip.h) on top of the oracle's packed-row phases ----
     @property
@@ -208,3 +213,21 @@ def test_overlapped_protocol_notices_a_replaced_state(c_oracle64):
     assert eng.slabs_consumed == 4
     c_oracle64.run(cfg, x, None, other, 2, 2)
     assert np.array_equal(eng.st["z"], other["z"]) and np.array_equal(eng.st["theta"], other["theta"])
+
+
+def test_overlapped_then_packed_then_overlapped(c_oracle64):
+    """mixed protocols on one engine: the packed steps move the particles without refreshing plane 0; the next overlapped chunk must
+    notice (Engine.step_update bumps state_gen) and gather again.  Result == the fused run."""
+    d, M = 5, 4
+    data, _, _ = make_data(d, seed=1, joint=True)
+    x = np.ascontiguousarray(data.x, np.float64)
+    cfg = _cfg(True, 0, 1, d, M)
+    eng = OracleShardEngine(c_oracle64, cfg, x, None, prng.PRNGKey(2))
+    buf = OverlapBuffers(eng, 1, torch.device("cpu"), torch.float64)
+    send, recv = make_buffers(eng, 1, torch.device("cpu"), torch.float64)
+    run_sharded_overlapped(eng, 0, 2, buf)
+    run_sharded(eng, 2, 2, send, recv)
+    run_sharded_overlapped(eng, 4, 2, buf)     # (the adapter asserts that plane 0 holds the current particles)
+    st = c_oracle64.new_state(cfg, prng.PRNGKey(2))
+    c_oracle64.run(cfg, x, None, st, 0, 6)
+    assert np.array_equal(eng.st["z"], st["z"]) and np.array_equal(eng.st["theta"], st["theta"])

@@ -144,3 +144,39 @@ def test_native_sharded_loop_world1_is_bit_identical_to_engine_run(joint, overla
     finally:
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize("joint", [False, True])
+def test_native_sharded_loop_mixed_protocols(joint):
+    """An overlapped chunk followed by a packed chunk (and by plain dibs_engine_run) on ONE engine with two communicators: the packed /
+    single-rank steps move the particles without touching plane 0, so the values gathered at the end of the overlapped chunk are stale
+    afterwards -- gather_particles must re-gather and the next overlapped chunk must exchange again (engine.hip: step_update clears
+    vals_fresh).  Everything bit-identical to dibs_engine_run."""
+    d, M = (12, 8) if joint else (50, 16)
+    data, gm, lm = make_data(d, seed=1, joint=joint)
+    dibs = (JointDiBS if joint else MarginalDiBS)(x=data.x, graph_model=gm, likelihood_model=lm, n_grad_mc_samples=32, n_acyclicity_mc_samples=8)
+    a, b = dibs._new_engine(M, d), dibs._new_engine(M, d)
+    try:
+        b.comm_init(b.comm_unique_ids(2))
+        for e in (a, b):
+            e.init_particles(random.PRNGKey(5))
+        b.run_sharded(0, 2, True)      # overlapped: plane 0 holds the particles after step 1
+        b.run_sharded(2, 2, False)     # packed: particles move, plane 0 does not
+        a.run(0, 4)
+        z_all, th_all = b.gather_particles()
+        assert np.array_equal(z_all, a.get_state()["z"]), "gather_particles returned the stale plane of the overlapped chunk"
+        assert not joint or np.array_equal(th_all, a.get_state()["theta"])
+        b.run_sharded(4, 2, True)      # overlapped again: must not run phase B on the stale values
+        a.run(4, 2)
+        assert np.array_equal(a.get_state()["z"], b.get_state()["z"])
+        b.run_sharded(6, 1, True)
+        b.run_sharded(7, 1, False)
+        b.run_sharded(8, 1, True)
+        a.run(6, 3)
+        sa, sb = a.get_state(), b.get_state()
+        assert np.array_equal(sa["z"], sb["z"]) and (sa["key"] == sb["key"]).all()
+        z_all, _ = b.gather_particles()
+        assert np.array_equal(z_all, sa["z"])
+    finally:
+        a.close()
+        b.close()
