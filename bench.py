@@ -91,7 +91,13 @@ def roofline_of(dom, avg_s, cfgname, M, K, eng_counters):
         flops = M * SA_MC * n_mm * 2 * d ** 3
         roof.update(flops_per_launch=flops, achieved=flops / avg_s / 1e12,
                     flops_model=f"M*Sa*c(d-1)*2*d^3, c({d - 1})={n_mm} matmuls of binary powering (SURVEY 8(d) F_acyc)")
-        if 32 < d <= 80 and not os.environ.get("DIBS_ACYC_F32"):
+        if 32 < d <= 64 and os.environ.get("DIBS_ACYC_BF16") and not os.environ.get("DIBS_ACYC_F32"):
+            # A/B run: round 3's three-piece bf16 kernel (24 mantissa bits per operand)
+            bf16_flops = M * SA_MC * n_mm * 6 * 2 * 64 ** 3
+            roof.update(rocprof_kernel=f"k_acyc_bf<{'true' if d > 48 else 'false'}>", pipe="mfma_bf16 (3-way split operands: 6 bf16 products per f32 product)",
+                        pipe_mantissa_bits=24, executed_bf16_tflops=bf16_flops / avg_s / 1e12, peak_bf16_tflops=PEAK_BF16_TFLOPS,
+                        frac_of_bf16_peak=bf16_flops / avg_s / 1e12 / PEAK_BF16_TFLOPS)
+        elif 32 < d <= 80 and not os.environ.get("DIBS_ACYC_F32"):
             # float products evaluated on the f16 matrix pipe with two block-scaled pieces per operand (3 f16 MFMAs of 16 cycles per
             # 16 x 16 x 32 block, kernels_acyc_f16.h).  `achieved` / `frac` price the ALGORITHMIC float flops against the FP32 peak; the f16
             # flops the kernel actually issues (16-padded tiles, 32-padded contraction, 3 products) against the dense 16-bit peak next to it.
@@ -100,17 +106,17 @@ def roofline_of(dom, avg_s, cfgname, M, K, eng_counters):
             kdim = 64 if d <= 64 else 32 * ((nt + 1) // 2)
             f16_flops = M * SA_MC * n_mm * 3 * 2 * rows * rows * kdim
             roof.update(rocprof_kernel=(f"k_acyc_hf<{'true' if d > 48 else 'false'}, 3>" if d <= 64 else f"k_acyc_hfw<{nt}>"),
-                        pipe="mfma_f16 (2 block-scaled pieces per operand: 3 f16 products per f32 product)",
+                        pipe="mfma_f16 (2 block-scaled pieces per operand: 3 f16 products per f32 product)", pipe_mantissa_bits=22,
                         executed_f16_tflops=f16_flops / avg_s / 1e12, peak_f16_tflops=PEAK_BF16_TFLOPS,
                         frac_of_f16_peak=f16_flops / avg_s / 1e12 / PEAK_BF16_TFLOPS)
         elif 80 < d <= 112 and not os.environ.get("DIBS_ACYC_F32"):
             nt = (d + 15) // 16   # three-piece bf16 kernel (the two-piece f16 scheme's truncation bias ~ (d - 1) 1e-7 exceeds 1e-5 there)
             bf16_flops = M * SA_MC * n_mm * 6 * 2 * (16 * nt) ** 3
-            roof.update(rocprof_kernel=f"k_acyc_bfw<{nt}>", pipe="mfma_bf16 (3-way split operands: 6 bf16 products per f32 product)",
+            roof.update(rocprof_kernel=f"k_acyc_bfw<{nt}>", pipe="mfma_bf16 (3-way split operands: 6 bf16 products per f32 product)", pipe_mantissa_bits=24,
                         executed_bf16_tflops=bf16_flops / avg_s / 1e12, peak_bf16_tflops=PEAK_BF16_TFLOPS,
                         frac_of_bf16_peak=bf16_flops / avg_s / 1e12 / PEAK_BF16_TFLOPS)
         else:
-            roof.update(rocprof_kernel=f"k_acyc<{(d + 15) // 16}, true>", pipe="mfma_f32")
+            roof.update(rocprof_kernel=f"k_acyc<{(d + 15) // 16}, true>", pipe="mfma_f32", pipe_mantissa_bits=24)
     elif dom == "bge_big":
         # VALU kernel: the work actually executed (the reference's dense 2 d^3/3-per-determinant count is not what runs:
         # only R[pa + j] is factorised).  Priced against the f32 vector peak.

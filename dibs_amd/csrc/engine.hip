@@ -1,5 +1,6 @@
 // libdibs_hip.so -- engine + C ABI (include/dibs_hip.h).  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,6 +23,9 @@
 #include "kernels_bge_soft.h"
 
 #define LDS_LIMIT ((size_t)160 * 1024)
+// profiling counters (dibs_engine_get_counters): [0] executed Cholesky flops, [1..4] phases of k_particle_grad (100 MHz ticks of block 0),
+// [8..12] phases of k_edge_scores, [16..21] phases of k_phi_update, [24..] k_bge_chol
+#define DIBS_N_COUNTERS 8192  // ([64 ..]: per-block (start, end) clock stamps of the kernel under investigation)
 static thread_local std::string g_err;
 static int fail(const std::string& m) {
   g_err = m;
@@ -91,6 +95,12 @@ struct dibs_engine {
   hipStream_t stream2;      // the acyclicity kernel (needs only the edge scores) runs beside sampling -> factorisation -> weights: its bf16 MFMAs
                             // overlap with their vector work.  Same arithmetic, same results; DIBS_NO_ACYC_STREAM2 keeps one stream.
   hipEvent_t ev_fork, ev_join, ev_k0, ev_k1;
+  // round 5: the fork of a step without a record packet on the main stream -- the event IS the edge kernel's completion signal
+  // (hipExtLaunchKernel stop event; scripts/probe/stream_hop.hip: 5.7 -> 2.2 us between k_edge_scores and k_bge_sample) -- and, optionally,
+  // the join as a flag polled inside k_particle_grad instead of an event wait in front of it (DIBS_FLAG_JOIN=1)
+  unsigned int* join_flag = nullptr;   // device word: sequence number stored by the second stream's last kernel of a step (k_join_flag)
+  unsigned int* join_err = nullptr;    // pinned host word: raised by tail_join_wait when the flag did not arrive (checked after every chunk)
+  unsigned int join_seq = 0;
   bool kmat_early;  // this step's kernel matrices were launched on the second stream (behind the acyclicity kernel)
   bool kmat_ext;    // ... or by dibs_engine_kmat_values on a stream of the caller (overlapped exchange)
   double t_ms[DIBS_K_COUNT];
@@ -243,6 +253,9 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
     HIP_OK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&e->ev_k0, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&e->ev_k1, hipEventDisableTiming));
+    HIP_OK(dalloc(&e->join_flag, (size_t)4));
+    HIP_OK(hipHostMalloc((void**)&e->join_err, 4, hipHostMallocDefault));
+    *e->join_err = 0u;
   }
   const size_t Ml = e->Mloc, dd = (size_t)e->d * e->d;
   HIP_OK(dalloc(&e->z, Ml * e->D));
@@ -281,7 +294,7 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   if (c.joint) HIP_OK(dalloc(&e->kt, Ml * e->M + kpad));
   HIP_OK(dalloc(&e->phi_z, Ml * e->D));
   HIP_OK(dalloc(&e->phi_th, Ml * e->P));
-  HIP_OK(dalloc(&e->counters, (size_t)8));
+  HIP_OK(dalloc(&e->counters, (size_t)DIBS_N_COUNTERS));
   if (c.likelihood == DIBS_LIK_BGE) {
     HIP_OK(dalloc(&e->masks, Ml * e->S * e->d * e->W));
     HIP_OK(dalloc(&e->node_scores, Ml * e->S * e->d));
@@ -382,9 +395,10 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (!e) return 0;
   hipSetDevice(e->cfg.device_id);
   if (e->stream) hipStreamSynchronize(e->stream);
+  if (e->stream2) hipStreamSynchronize(e->stream2);
   void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->eas, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
-                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot};
+                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot, e->join_flag};
   for (void* p : ptrs)
     if (p) hipFree(p);
   joint_free(&e->jw);
@@ -394,6 +408,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (e->ev_join) hipEventDestroy(e->ev_join);
   if (e->ev_k0) hipEventDestroy(e->ev_k0);
   if (e->ev_k1) hipEventDestroy(e->ev_k1);
+  if (e->join_err) hipHostFree(e->join_err);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   for (auto& pe : e->pending) {
@@ -743,8 +758,18 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
   const bool do_lik = (terms & TERMS_LIK) != 0, do_prior = (terms & TERMS_PRIOR) != 0;
 
   e->kmat_early = false;
-  {
-    KTimer tm(e, DIBS_K_EDGE);
+  // While per-kernel timing is on (set_profiling(1)) the main stream joins right away, so that every duration is a kernel alone on the
+  // GPU -- but the launch still goes to the second stream: with that (high-priority) queue in existence the same kernel takes 104 us
+  // on the main stream and 96 us on its own.
+  // (a small acyclicity launch -- <= 512 blocks: config 2, or a rank of a sharded headline run -- stays on the main stream: the fork / join
+  //  events cost 6 + 6 us of the critical path, more than such a launch can hide; measured at config 2: 16 100 -> see DESIGN.md)
+  const bool fork = do_prior && do_lik && e->stream2 != nullptr && (long)e->acyc_nblk * e->Mloc > 512, join_now = e->profiling && !e->profiling_concurrent;
+  static const bool want_flag_join = getenv("DIBS_FLAG_JOIN") != nullptr, no_ext_fork = getenv("DIBS_NO_EXT_FORK") != nullptr;
+  // the join inside k_particle_grad (tail_join_wait) instead of an event wait in front of it: measured neutral to slightly slower (the
+  // acquire fence of every polling block drops its XCD's L2), kept behind DIBS_FLAG_JOIN=1; per-kernel timing always uses the event
+  const bool flag_join = fork && !join_now && want_flag_join && e->join_flag != nullptr;
+  auto launch_edge = [&](hipStream_t st, hipEvent_t stop_ev) {
+    KTimer tm(e, DIBS_K_EDGE, st);
     const size_t lds = (size_t)2 * e->dpad * e->ldk * 4;
 
     const int ntile = (e->dpad / 16) * (e->dpad / 16);
@@ -754,21 +779,22 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
 #define EDGE_LAUNCH(MAXT_)                                                                                                             \
     {                                                                                                                                    \
       allow_lds(k_edge_scores<MAXT_>, lds);                                                                                              \
-      hipLaunchKernelGGL(k_edge_scores<MAXT_>, dim3(e->Mloc, nby), dim3(256), lds, e->stream, e->z, e->scores, e->thr, e->probs, e->eas,  \
-                         alpha, e->d, e->k, e->dpad, e->ldk, e->edge_kc);                                                                       \
+      if (stop_ev)                                                                                                                       \
+        hipExtLaunchKernelGGL(k_edge_scores<MAXT_>, dim3(e->Mloc, nby), dim3(256), lds, st, nullptr, stop_ev, 0, e->z, e->scores, e->thr, \
+                              e->probs, e->eas, alpha, e->d, e->k, e->dpad, e->ldk, e->edge_kc, (unsigned long long*)nullptr);                                          \
+      else                                                                                                                               \
+        hipLaunchKernelGGL(k_edge_scores<MAXT_>, dim3(e->Mloc, nby), dim3(256), lds, st, e->z, e->scores, e->thr, e->probs, e->eas,      \
+                           alpha, e->d, e->k, e->dpad, e->ldk, e->edge_kc, e->profiling ? e->counters + 8 : (unsigned long long*)nullptr);                                                              \
     }
     if (per_wave <= 1) EDGE_LAUNCH(1) else if (per_wave <= 4) EDGE_LAUNCH(4) else EDGE_LAUNCH(EDGE_MAXT)
 #undef EDGE_LAUNCH
-  }
+  };
+  // fork without a record packet on the main stream: the event is the edge kernel's own completion signal (hipExtLaunchKernel stop event)
+  const bool ext_fork = fork && !e->profiling && !no_ext_fork;
+  launch_edge(e->stream, ext_fork ? e->ev_fork : nullptr);
   bool score_lik = false;
-  // While per-kernel timing is on (set_profiling(1)) the main stream joins right away, so that every duration is a kernel alone on the
-  // GPU -- but the launch still goes to the second stream: with that (high-priority) queue in existence the same kernel takes 104 us
-  // on the main stream and 96 us on its own.
-  // (a small acyclicity launch -- <= 512 blocks: config 2, or a rank of a sharded headline run -- stays on the main stream: the fork / join
-  //  events cost 6 + 6 us of the critical path, more than such a launch can hide; measured at config 2: 16 100 -> see DESIGN.md)
-  const bool fork = do_prior && do_lik && e->stream2 != nullptr && (long)e->acyc_nblk * e->Mloc > 512, join_now = e->profiling && !e->profiling_concurrent;
   if (fork) {
-    hipEventRecord(e->ev_fork, e->stream);
+    if (!ext_fork) hipEventRecord(e->ev_fork, e->stream);
     hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
     const AcycLaunch al{e->stream2, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, Mg, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
                         e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr, e->eas};
@@ -803,7 +829,10 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
                          (float)c.scale_theta, (float)c.h_theta, 1);
     e->kmat_early = true;
   }
-  if (fork) hipEventRecord(e->ev_join, e->stream2);
+  if (fork) {
+    if (flag_join) hipLaunchKernelGGL(k_join_flag, dim3(1), dim3(1), 0, e->stream2, e->join_flag, ++e->join_seq);
+    else hipEventRecord(e->ev_join, e->stream2);
+  }
   if (fork && join_now) hipStreamWaitEvent(e->stream, e->ev_join, 0);
   if (!do_lik) {
     // (prior terms only: no estimator runs, the tail takes a zero likelihood gradient)
@@ -863,7 +892,8 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
     }
   }
   if (fork) {
-    hipStreamWaitEvent(e->stream, e->ev_join, 0);  // (covers the kernel matrices: they precede the acyclicity kernel on that stream)
+    // (covers the kernel matrices: they precede the end of the second stream's chain.  flag_join: k_particle_grad polls the flag itself)
+    if (!flag_join) hipStreamWaitEvent(e->stream, e->ev_join, 0);
   } else if (do_prior) {
     const AcycLaunch al{e->stream, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, Mg, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
                         e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr, e->eas};
@@ -884,16 +914,16 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
       er_c = (float)(log(p) - log(1 - p));
     }
     // (w_tot != null: W, U, V of a particle do not fit in one block's LDS -- phases A, B here, the back-projection in k_backproject_big)
+    // (terms: without the prior part beta = 0, no graph prior, no Gaussian term; without the likelihood part a zero W_lik is the input)
+    const float inv_sig2 = do_prior ? 1.0f / (e->sigz * e->sigz) : 0.f;
     const int ldz = e->w_tot ? 0 : tail_ldz(e->d, e->k, e->S, score_lik, LDS_LIMIT - 2048);
     const int cap = score_lik ? tail_stage_cap(e->d, ldz, e->S, e->W, LDS_LIMIT - 2048) : 0;
     const size_t lds = tail_lds_bytes(e->d, ldz, e->S, e->W, score_lik, cap);
-    // (terms: without the prior part beta = 0, no graph prior, no Gaussian term; without the likelihood part a zero W_lik is the input)
-    const float inv_sig2 = do_prior ? 1.0f / (e->sigz * e->sigz) : 0.f;
     const TailArgs ta{score_lik ? e->node_scores : nullptr, e->masks, e->logprobs_z, e->baseline, e->baseline2, c.score_function_baseline,
                       score_lik ? e->bq.counts : nullptr, e->S, e->W, cap, e->probs, do_lik ? e->w_lik : const_cast<float*>(zero_w), e->w_acyc, alpha,
                       do_prior ? beta : 0.f, do_prior ? c.graph_prior : (int)DIBS_PRIOR_UNIFORM, er_c,
                       e->z, pack, rt.stride, rt.copy_vals, e->m0, e->d, e->k, ldz, inv_sig2, e->profiling ? e->counters : nullptr,
-                      e->w_tot};
+                      e->w_tot, flag_join ? e->join_flag : nullptr, e->join_seq, e->join_err};
     allow_lds(k_particle_grad, lds);
     hipLaunchKernelGGL(k_particle_grad, dim3(e->Mloc), dim3(TAIL_NT), lds, e->stream, ta);
     if (e->w_tot) {
@@ -949,7 +979,7 @@ static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_s
   {
     KTimer tm(e, DIBS_K_PHI_UPDATE);
     auto phi = [&](size_t val_off, size_t grad_off, size_t len, int is_theta, float* x, float* v, float* phi_out, float h) {
-      // particles per block: as many as keep >= 1024 blocks in flight and the [M][TA] tables within 48 KiB of LDS
+      // particles per block: as many as keep >= 1024 blocks in flight and the tables within the LDS budget
       // (headline size: TA = 16 / 8 / 4 measured 20.5 / 18.9 / 26.0 us)
       const long cols = (long)((len + 63) / 64);
       static const bool phi_valu = getenv("DIBS_PHI_VALU") != nullptr;  // (A/B switch for measurements)
@@ -964,16 +994,27 @@ static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_s
         return;
       }
       int ta = 16;
-      while (ta > 4 && (cols * ((e->Mloc + ta - 1) / ta) < 1024 || (size_t)2 * ta * e->M * 4 > 48 * 1024)) ta >>= 1;
-      const size_t lds = ((size_t)2 * ta * e->M + (size_t)4 * ta * 64) * 4;
+      while (ta > 4 && (cols * ((e->Mloc + ta - 1) / ta) < 1024 || phi_update_lds_bytes(ta, e->M) > 56 * 1024)) ta >>= 1;
+      static const int ta_env = getenv("DIBS_PHI_TA") ? atoi(getenv("DIBS_PHI_TA")) : 0;  // (tuning override: 4, 8 or 16)
+      if ((ta_env == 4 || ta_env == 8 || ta_env == 16) && phi_update_lds_bytes(ta_env, e->M) <= LDS_LIMIT - 2048) ta = ta_env;
+      const size_t lds = phi_update_lds_bytes(ta, e->M);
       const int ngroups = (e->Mloc + ta - 1) / ta;
       const dim3 g((unsigned)(8 * ngroups * ((cols + 7) / 8)));
-#define PHI_LAUNCH(TA_)                                                                                                        \
-      allow_lds(k_phi_update<TA_>, lds);                                                                                         \
-      hipLaunchKernelGGL(k_phi_update<TA_>, g, dim3(256), lds, e->stream, pack, rs.stride, val_off, grad_off, (int)len, e->kz, \
-                         e->kt, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize, c.optimizer == DIBS_OPT_RMSPROP, \
-                         (int)cols, ngroups, vals_send, (size_t)e->Ev, is_theta ? (size_t)e->D : (size_t)0);
-      if (ta == 16) { PHI_LAUNCH(16) } else if (ta == 8) { PHI_LAUNCH(8) } else { PHI_LAUNCH(4) }
+      // FULL: whole 8-pair batches per wave and whole particle groups (no clamps inside the kernel)
+      static const bool no_full = getenv("DIBS_PHI_NOFULL") != nullptr;  // (A/B switch)
+      const bool full = !no_full && e->M % 64 == 0 && e->Mloc % ta == 0 && (size_t)e->M * rs.stride * 4 < ((size_t)1 << 32);  // (32-bit buffer offsets)
+#define PHI_LAUNCH(TA_, F_, J_)                                                                                                \
+      {                                                                                                                          \
+        allow_lds(k_phi_update<TA_, F_, J_>, lds);                                                                               \
+        hipLaunchKernelGGL((k_phi_update<TA_, F_, J_>), g, dim3(256), lds, e->stream, pack, rs.stride, val_off, grad_off, (int)len, e->kz, \
+                           e->kt, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize, c.optimizer == DIBS_OPT_RMSPROP, \
+                           (int)cols, ngroups, vals_send, (size_t)e->Ev, is_theta ? (size_t)e->D : (size_t)0);               \
+      }
+#define PHI_PICK(TA_)                                                                                                          \
+      if (e->kt) { PHI_LAUNCH(TA_, false, true) } /* (FULL + JOINT: hipcc hoists the scalar kernel entries into 230 VGPRs) */       \
+      else { if (full) PHI_LAUNCH(TA_, true, false) else PHI_LAUNCH(TA_, false, false) }
+      if (ta == 16) { PHI_PICK(16) } else if (ta == 8) { PHI_PICK(8) } else { PHI_PICK(4) }
+#undef PHI_PICK
 #undef PHI_LAUNCH
     };
     phi(rs.z_off, rs.gz_off, (size_t)e->D, 0, e->z, e->vz, e->phi_z, (float)c.h_latent);
@@ -981,6 +1022,15 @@ static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_s
   }
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return fail(std::string("kernel launch failed: ") + hipGetErrorString(err));
+  return 0;
+}
+
+// after a chunk has been synchronised: did a k_particle_grad give up waiting for the second stream (tail_join_wait)?
+static int check_join(dibs_engine* e) {
+  if (e->join_err && *e->join_err) {
+    *e->join_err = 0u;
+    return fail("internal: the acyclicity stream's completion flag did not arrive (k_particle_grad timed out waiting; results of this chunk are invalid)");
+  }
   return 0;
 }
 
@@ -997,7 +1047,7 @@ extern "C" int dibs_engine_run(dibs_engine* e, int32_t t_start, int32_t n_steps)
   HIP_OK(hipStreamSynchronize(e->stream));
   if (e->profiling) drain_timers(e);
   HIP_OK(hipGetLastError());
-  return 0;
+  return check_join(e);
 }
 
 extern "C" int dibs_engine_step_local(dibs_engine* e, int32_t t, void* send_dev) {
@@ -1257,7 +1307,7 @@ extern "C" int dibs_engine_run_sharded(dibs_engine* e, int32_t t_start, int32_t 
   if (overlapped) HIP_OK(hipStreamSynchronize(e->side));
   if (e->profiling) drain_timers(e);
   HIP_OK(hipGetLastError());
-  return 0;
+  return check_join(e);
 }
 
 // z (and theta) of ALL ranks' particles after a sharded run, on every rank: [M][d][k][2] and [M][P] host buffers (either may be NULL).
@@ -1299,7 +1349,7 @@ extern "C" int dibs_engine_sync(dibs_engine* e) {
   HIP_OK(hipSetDevice(e->cfg.device_id));
   HIP_OK(hipStreamSynchronize(e->stream));
   if (e->profiling) drain_timers(e);
-  return 0;
+  return check_join(e);
 }
 
 extern "C" int64_t dibs_engine_theta_size(const dibs_engine* e) { return e ? e->P : 0; }
@@ -1377,7 +1427,7 @@ extern "C" int dibs_engine_reset_timers(dibs_engine* e) {
     e->t_ms[i] = 0;
     e->t_n[i] = 0;
   }
-  hipMemset(e->counters, 0, 8 * sizeof(unsigned long long));
+  hipMemset(e->counters, 0, DIBS_N_COUNTERS * sizeof(unsigned long long));
   return 0;
 }
 
@@ -1395,9 +1445,9 @@ extern "C" int dibs_engine_get_timers(dibs_engine* e, double* total_ms, int64_t*
 extern "C" int dibs_engine_get_counters(dibs_engine* e, double* out, int32_t n) {
   if (!e || !out) return fail("null argument");
   HIP_OK(hipStreamSynchronize(e->stream));
-  unsigned long long h[8];
+  unsigned long long h[DIBS_N_COUNTERS];
   HIP_OK(hipMemcpy(h, e->counters, sizeof h, hipMemcpyDeviceToHost));
-  for (int i = 0; i < n && i < 8; ++i) out[i] = (double)h[i];
+  for (int i = 0; i < n && i < DIBS_N_COUNTERS; ++i) out[i] = (double)h[i];
   return 0;
 }
 

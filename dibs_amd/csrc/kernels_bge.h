@@ -576,6 +576,21 @@ __global__ __launch_bounds__(256) void k_bge_chol(double* __restrict__ node_scor
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ unsigned int cnt_s[BGE_NQ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // R / Q -> LDS: the loads of a thread are requested together, in front of everything else, and stored once the queue entries of the
+  // block's first unit have been requested as well.  (Until round 4 this was `for (e = tid; ...) { Rs[e] = Rp[e]; Rs[msz + e] = Qp[e]; }`
+  // behind the counter load and the entry fetch: hipcc keeps such a loop rolled with a full s_waitcnt per iteration -- 2 + 10 dependent
+  // trips to the L2 at d = 50 before a block factorised anything, in each of the two rounds of blocks.)
+  constexpr int RB = 12;
+  const int ldr_ = d + 1, msz_ = ldr_ * ldr_;
+  float rpre[R_LDS ? RB : 1], qpre[R_LDS ? RB : 1];
+  if (R_LDS) {
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int e = u * 256 + tid, ec = e < msz_ ? e : msz_ - 1;
+      rpre[u] = bp.Rp[ec];
+      qpre[u] = bp.Qp[ec];
+    }
+  }
   if (tid < BGE_NQ) cnt_s[tid] = qs.counts[tid];
   __syncthreads();
   const int nwg = W2 ? bge_generic_waves(d, R_LDS) : 4;
@@ -631,9 +646,30 @@ __global__ __launch_bounds__(256) void k_bge_chol(double* __restrict__ node_scor
   float* Rs = reinterpret_cast<float*>(smem_raw);
   const size_t r_bytes = R_LDS ? (((size_t)2 * msz * 4 + 15) & ~(size_t)15) : 0;
   if (R_LDS) {
-    for (int e = tid; e < msz; e += 256) {
-      Rs[e] = bp.Rp[e];
-      Rs[msz + e] = bp.Qp[e];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int e = u * 256 + tid;
+      if (e < msz) {
+        Rs[e] = rpre[u];
+        Rs[msz + e] = qpre[u];
+      }
+    }
+    for (int e0 = RB * 256; e0 < msz; e0 += RB * 256) {  // (n_vars > 54)
+      float rr[RB], qq[RB];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int e = e0 + u * 256 + tid, ec = e < msz ? e : msz - 1;
+        rr[u] = bp.Rp[ec];
+        qq[u] = bp.Qp[ec];
+      }
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int e = e0 + u * 256 + tid;
+        if (e < msz) {
+          Rs[e] = rr[u];
+          Rs[msz + e] = qq[u];
+        }
+      }
     }
     __syncthreads();
   }

@@ -37,7 +37,19 @@ __device__ __forceinline__ void kmat_block(float* __restrict__ smem, const float
     const int clen = len - c0 < KMAT_CH ? len - c0 : KMAT_CH;
     const int len4 = clen >> 2;
     if (c0) __syncthreads();
-    for (int e = tid; e < len4; e += 256) reinterpret_cast<float4*>(smem)[e] = reinterpret_cast<const float4*>(za + c0)[e];
+    for (int e0 = 0; e0 < len4; e0 += 8 * 256) {  // (loads requested together: a rolled load -> LDS store loop makes one trip per element)
+      float4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * 256 + tid;
+        t[u] = reinterpret_cast<const float4*>(za + c0)[e < len4 ? e : len4 - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * 256 + tid;
+        if (e < len4) reinterpret_cast<float4*>(smem)[e] = t[u];
+      }
+    }
     for (int e = (len4 << 2) + tid; e < clen; e += 256) smem[e] = za[c0 + e];
     __syncthreads();
     // the wave's four b rows advance together: 8 independent 16-byte loads in flight per lane and pass (the kernel is

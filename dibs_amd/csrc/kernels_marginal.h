@@ -38,8 +38,10 @@ __global__ void k_init_theta_lin(float* __restrict__ th, Key2 key, uint64_t n_to
 template <int MAXT>   // accumulator sets per wave: 1 (up to 16 tiles per particle: n_vars <= 64 with four blocks), 4, EDGE_MAXT
 __global__ __launch_bounds__(256) void k_edge_scores(const float* __restrict__ z, float* __restrict__ scores,
                                                      uint32_t* __restrict__ thr, float* __restrict__ probs, float* __restrict__ eas,
-                                                     float alpha, int d, int k, int dpad, int ldk, int kc) {
+                                                     float alpha, int d, int k, int dpad, int ldk, int kc, unsigned long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned long long ts[5] = {0, 0, 0, 0, 0};  // (profiling only: dbg != null)
+  if (dbg) ts[0] = ts[1] = ts[2] = wall_clock64();
   float* Us = smem;
   float* Vs = smem + (size_t)dpad * ldk;
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -54,14 +56,39 @@ __global__ __launch_bounds__(256) void k_edge_scores(const float* __restrict__ z
   for (int q0 = 0; q0 < k; q0 += kc) {
     const int kn = k - q0 < kc ? k - q0 : kc, kp = (kn + 3) & ~3;
     if (q0) __syncthreads();
-    for (int e = tid; e < dpad * ldk; e += 256) {
-      const int i = e / ldk, q = e - i * ldk;
-      float2 uv = make_float2(0.f, 0.f);
-      if (i < d && q < kn) uv = zm[(size_t)i * k + q0 + q];
-      Us[e] = uv.x;
-      Vs[e] = uv.y;
+    // Z -> LDS.  The loads of a thread are requested TOGETHER (16 per batch: one batch at d = k = 50) and the padding is zero-filled while
+    // they are in flight.  (Rounds 1-4 had `for (e = tid; ...) { load; store to LDS; }`: hipcc keeps such a loop rolled with a full
+    // s_waitcnt in front of every LDS store -- 17 dependent trips to the L2 per block, 8 of the kernel's 10 us.)
+    constexpr int ZB = 16;
+    const int nval = d * kn;
+    for (int e0 = 0; e0 < nval; e0 += ZB * 256) {
+      float2 uv[ZB];
+#pragma unroll
+      for (int u = 0; u < ZB; ++u) {
+        const int e = e0 + u * 256 + tid, ec = e < nval ? e : nval - 1, i = ec / kn, q = ec - i * kn;
+        uv[u] = zm[(size_t)i * k + q0 + q];  // (past the end: the last element again, not stored)
+      }
+      if (e0 == 0) {
+        for (int e = tid; e < dpad * ldk; e += 256) {
+          const int i = e / ldk, q = e - i * ldk;
+          if (i >= d || q >= kn) {
+            Us[e] = 0.f;
+            Vs[e] = 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < ZB; ++u) {
+        const int e = e0 + u * 256 + tid, i = e / kn, q = e - i * kn;
+        if (e < nval) {
+          Us[i * ldk + q] = uv[u].x;
+          Vs[i * ldk + q] = uv[u].y;
+        }
+      }
     }
+    if (dbg) ts[1] = wall_clock64();
     __syncthreads();
+    if (dbg) ts[2] = wall_clock64();
 #pragma unroll
     for (int u = 0; u < MAXT; ++u) {
       const int t = t0 + u * tstride;
@@ -75,6 +102,7 @@ __global__ __launch_bounds__(256) void k_edge_scores(const float* __restrict__ z
       }
     }
   }
+  if (dbg) ts[3] = wall_clock64();
 #pragma unroll
   for (int u = 0; u < MAXT; ++u) {
     const int t = t0 + u * tstride;
@@ -97,6 +125,10 @@ __global__ __launch_bounds__(256) void k_edge_scores(const float* __restrict__ z
       }
     }
   }
+  if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {  // profiling: loads+stores | barrier | MFMA | epilogue (100 MHz ticks)
+    if (dbg) ts[4] = wall_clock64();
+    for (int u = 1; u < 5; ++u) atomicAdd(dbg + u, ts[u] - ts[u - 1]);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, size_t pack_stride, size_t seg_off, int len,
@@ -113,9 +145,23 @@ __global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, si
 // grid = (ceil(len / 256), ceil(Mloc / TA)), block = 256;  vout != null: the updated segment is also written to vout[a][vout_off + i]
 // ------------------------------------------------------------------------------------------------
 // block = 64 consecutive elements x TA local particles; wave w sums over the quarter b in [w Mq, (w+1) Mq) of the particles and
-// the four partial sums are added in wave order (the order is a function of M only: results do not depend on TA or the rank
-// count).  Every [z_b | grad_b] element read from L2 serves TA particles; the kernel tables sit in LDS as [b][TA].
-template <int TA>
+// the four partial sums are added in wave order.  Round 5: inside a quarter the rows are taken in PAIRS (b_lo + 2p, b_lo + 2p + 1) whose
+// two running sums are the halves of one packed register (v_pk_fma_f32 over rows instead of over particles: the loaded values pair up as
+// they arrive -- packing over particles made hipcc duplicate every loaded value into a register pair, 128 VGPRs for 64 values) and are
+// added at the end, even rows + odd rows.  The order is a function of M only: results do not depend on TA or the rank count.
+// Every [z_b | grad_b] element read from L2 serves TA particles; the kernel entries are scalar operands (s_load from kz / kt).
+// dynamic LDS = phi_update_lds_bytes(TA, M)
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__host__ __device__ inline size_t phi_update_lds_bytes(int TA, int M) {
+  (void)M;
+  return (size_t)4 * TA * 64 * 4;  // the four waves' partial sums
+}
+// FULL: M is a multiple of 64, i.e. every wave's quarter is a whole number of 8-pair batches, whole particle groups, buffer < 4 GiB -- no
+// clamps, no per-pair tests, buffer loads (the headline size, configs 3 and 4); otherwise rows past a quarter repeat its last row and meet zero
+// kernel entries.  JOINT: a second kernel matrix (theta), weights ks = kz + kt and the repulsion of the segment's own kernel.
+template <int TA, bool FULL, bool JOINT>
 __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pack, size_t pack_stride, size_t val_off,
                                                     size_t grad_off, int len, const float* __restrict__ kz,
                                                     const float* __restrict__ kt, int seg_is_theta, float* __restrict__ x,
@@ -128,106 +174,150 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
   // packed rows 16 times per launch: 82 MB of L2 misses).
   const int L = blockIdx.x, c_lo = L & 7, tq = L >> 3, grp = tq % ngroups, bx = (tq / ngroups) * 8 + c_lo;
   if (bx >= ncols) return;  // (block-uniform)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* ksum = smem;                   // [M][TA]  kz + kt
-  float* krep = smem + (size_t)TA * M;  // [M][TA]  (2 / h) * kernel whose gradient gives the repulsion
-  float* part = krep + (size_t)TA * M;  // [4][TA][64] partial sums
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* part = smem;  // [4][TA][64] partial sums of the four waves
+  const int Mq = (M + 3) >> 2;  // rows per wave
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: row offsets live in SGPRs)
+  // What bounds this kernel is not latency -- all its blocks are resident at once (latest block start 0.7 us after the first) -- but what a
+  // wave ISSUES.  Rounds 2-4: ~2 700 instructions per wave for 512 of arithmetic (a 64-bit multiply chain per load on the ONE scalar unit
+  // the four SIMDs of a CU share, integer divisions in the table index, clamps, per-row tests) = 14 M wave-instructions per launch, 19 us.
+  // A first lean version still took 21 us: its 128 broadcast ds_read_b128 of the kernel tables per wave are 8 LDS cycles each = 6.8 us per
+  // CU.  Now the kernel entries are what they are -- wave-uniform SCALARS: read with s_load straight from kz (k[a][b], k[a][b + 1] are
+  // neighbours: one 64-bit scalar operand of the packed FMA), no LDS table, no staging, no barrier in front of the arithmetic; rows arrive
+  // through buffer loads (descriptor + scalar row offset + one vector column offset: one instruction per load).
   const int a0 = grp * TA;
   const float c2h = 2.0f / h;
-  for (int e = tid; e < TA * M; e += 256) {
-    const int b = e / TA, q = e - b * TA, a = a0 + q;
-    float s = 0.f, r = 0.f;
-    if (a < Mloc) {
-      const float z1 = kz[(size_t)a * M + b];
-      const float t1 = kt ? kt[(size_t)a * M + b] : 0.f;
-      s = z1 + t1;
-      r = seg_is_theta ? t1 : z1;
-    }
-    ksum[e] = s;
-    krep[e] = c2h * r;
-  }
-  __syncthreads();
   const int i = bx * 64 + lane;
   const bool ok = i < len;
-  float xa[TA], acc[TA];
+  const uint32_t il = (uint32_t)(ok ? i : len - 1);  // (loads of lanes past the end are clamped, not predicated)
+  const int b_lo = wave * Mq, b_hi = (b_lo + Mq < M) ? b_lo + Mq : M;
+  const int nrow = FULL ? Mq : (b_hi > b_lo ? b_hi - b_lo : 0);  // (wave-uniform)
+  const int npair = (nrow + 1) >> 1;
+  const int rlast = nrow > 0 ? b_lo + nrow - 1 : 0;
+  constexpr int PFP = 8;  // row PAIRS per batch
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pack + grad_off), 0, 0xFFFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pack + val_off), 0, 0xFFFFFFFF, 0x00020000);
+  const uint32_t stride_b = (uint32_t)pack_stride * 4u;
+  // rows of batch `pb` -> registers.  FULL: consecutive rows, scalar offsets; else clamped row numbers through plain pointers
+  auto fetch = [&](int pb, f32x2 (&g)[PFP], f32x2 (&xv)[PFP]) {
+    if constexpr (FULL) {
+      // (two descriptors -- gradient and value segment -- share the row's scalar offset, which advances between the loads: one SGPR in
+      //  flight instead of one per load; the sched_barrier keeps hipcc from computing all 32 offsets first and spilling them to VGPR lanes)
+      uint32_t so = (uint32_t)(b_lo + 2 * PFP * pb) * stride_b;
+#pragma unroll
+      for (int p = 0; p < PFP; ++p) {
+        const float g_lo = buf_ld(rs_g, il * 4u, so), x_lo = buf_ld(rs_x, il * 4u, so);
+        so += stride_b;
+        __builtin_amdgcn_sched_barrier(0);
+        const float g_hi = buf_ld(rs_g, il * 4u, so), x_hi = buf_ld(rs_x, il * 4u, so);
+        so += stride_b;
+        __builtin_amdgcn_sched_barrier(0);
+        g[p] = f32x2{g_lo, g_hi};
+        xv[p] = f32x2{x_lo, x_hi};
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < PFP; ++p) {
+        const int q0 = b_lo + 2 * (PFP * pb + p), r0 = q0 < rlast ? q0 : rlast, r1 = q0 + 1 < rlast ? q0 + 1 : rlast;
+        const float* p0 = pack + (size_t)r0 * pack_stride;
+        const float* p1 = pack + (size_t)r1 * pack_stride;
+        g[p] = f32x2{(p0 + grad_off)[il], (p1 + grad_off)[il]};
+        xv[p] = f32x2{(p0 + val_off)[il], (p1 + val_off)[il]};
+      }
+    }
+  };
+  f32x2 ga[PFP], xa_[PFP], gb[PFP], xb_[PFP];
+  constexpr int KF = TA >= 8 ? 2 : 4;  // row pairs per group of scalar kernel-entry loads (TA * 2 KF SGPRs per group)
+  fetch(0, ga, xa_);
+  f32x2 xa2[TA];  // the block's own values, each in both halves of a register pair (the packed subtraction below wants them so)
 #pragma unroll
   for (int q = 0; q < TA; ++q) {
-    const int a = a0 + q;
-    xa[q] = (ok && a < Mloc) ? pack[(size_t)(m0 + a) * pack_stride + val_off + i] : 0.f;
-    acc[q] = 0.f;
+    const int a = (FULL || a0 + q < Mloc) ? a0 + q : Mloc - 1;
+    const float t = FULL ? buf_ld(rs_x, il * 4u, (uint32_t)(m0 + a) * stride_b) : (pack + (size_t)(m0 + a) * pack_stride + val_off)[il];
+    xa2[q] = f32x2{t, t};
   }
-  const int Mq = (M + 3) >> 2;
-  const int b_lo = wave * Mq, b_hi = (b_lo + Mq < M) ? b_lo + Mq : M;
-  if (ok) {
-    int b = b_lo;
-    // 16 rows (32 loads) are issued together; the FMA loop runs on packed f32 (v_pk_fma_f32: two particles per instruction --
-    // this loop is bound by VALU issue)
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 acc2[TA / 2], xa2[TA / 2];
-#pragma unroll
-    for (int q2 = 0; q2 < TA / 2; ++q2) {
-      acc2[q2] = f32x2{acc[2 * q2], acc[2 * q2 + 1]};
-      xa2[q2] = f32x2{xa[2 * q2], xa[2 * q2 + 1]};
-    }
-    for (; b + 16 <= b_hi; b += 16) {
-      float g[16], xb[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        g[u] = pack[(size_t)(b + u) * pack_stride + grad_off + i];
-        xb[u] = pack[(size_t)(b + u) * pack_stride + val_off + i];
-      }
-      asm volatile("" ::: "memory");  // keep the 32 loads ahead of the arithmetic (hipcc would interleave them to save VGPRs)
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const f32x2 g2 = f32x2{g[u], g[u]}, xb2 = f32x2{xb[u], xb[u]};
-#pragma unroll
-        for (int q4 = 0; q4 < TA / 4; ++q4) {
-          const float4 ks = *reinterpret_cast<const float4*>(ksum + (size_t)(b + u) * TA + q4 * 4);
-          const float4 kr = *reinterpret_cast<const float4*>(krep + (size_t)(b + u) * TA + q4 * 4);
-          const f32x2 ks_lo = f32x2{ks.x, ks.y}, ks_hi = f32x2{ks.z, ks.w}, kr_lo = f32x2{kr.x, kr.y}, kr_hi = f32x2{kr.z, kr.w};
-          acc2[2 * q4] = __builtin_elementwise_fma(-kr_lo, xb2 - xa2[2 * q4], __builtin_elementwise_fma(ks_lo, g2, acc2[2 * q4]));
-          acc2[2 * q4 + 1] = __builtin_elementwise_fma(-kr_hi, xb2 - xa2[2 * q4 + 1], __builtin_elementwise_fma(ks_hi, g2, acc2[2 * q4 + 1]));
-        }
-      }
-    }
-#pragma unroll
-    for (int q2 = 0; q2 < TA / 2; ++q2) {
-      acc[2 * q2] = acc2[q2].x;
-      acc[2 * q2 + 1] = acc2[q2].y;
-    }
-    for (; b < b_hi; ++b) {
-      const float g = pack[(size_t)b * pack_stride + grad_off + i];
-      const float xb = pack[(size_t)b * pack_stride + val_off + i];
-#pragma unroll
-      for (int q = 0; q < TA; ++q) acc[q] = fmaf(-krep[(size_t)b * TA + q], xb - xa[q], fmaf(ksum[(size_t)b * TA + q], g, acc[q]));
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < TA; ++q) part[(wave * TA + q) * 64 + lane] = acc[q];
-  __syncthreads();
-  if (!ok) return;
+  // optimizer state of the elements this thread finishes below (particle a0 + wave + 4 qq, element i)
+  float ve[TA / 4];
 #pragma unroll
   for (int qq = 0; qq < TA / 4; ++qq) {
-    const int q = wave + 4 * qq, a = a0 + q;
-    if (a >= Mloc) continue;
-    const float tot = ((part[(0 * TA + q) * 64 + lane] + part[(1 * TA + q) * 64 + lane]) + part[(2 * TA + q) * 64 + lane]) +
-                      part[(3 * TA + q) * 64 + lane];
-    const float phi = -tot / (float)M;
-    const float xv = pack[(size_t)(m0 + a) * pack_stride + val_off + i];
-    const size_t o = (size_t)a * len + i;
-    if (phi_out) phi_out[o] = phi;
-    float xn;
-    if (rmsprop) {
-      const float vv = v[o] * 0.9f + phi * phi * 0.1f;
-      v[o] = vv;
-      xn = xv - stepsize * phi / sqrtf(vv + 1e-8f);
-    } else {
-      xn = xv - stepsize * phi;
+    const int a = (FULL || a0 + wave + 4 * qq < Mloc) ? a0 + wave + 4 * qq : Mloc - 1;
+    ve[qq] = (v + (size_t)a * len)[il];
+  }
+  f32x2 acc2[TA];
+#pragma unroll
+  for (int q = 0; q < TA; ++q) acc2[q] = f32x2{0.f, 0.f};
+  const f32x2 mc2h = f32x2{-c2h, -c2h};
+  // rows b = b_lo + 2 pr, b + 1 against the TA particles of the block; the two halves of acc2 = even / odd rows of the quarter
+  auto pair_step = [&](int pr, f32x2 gp, f32x2 xp) {
+    const int b = b_lo + 2 * pr;
+    const bool two = FULL || 2 * pr + 1 < nrow;  // (an odd quarter's last pair has one row)
+#pragma unroll
+    for (int q = 0; q < TA; ++q) {
+      const int a = (FULL || a0 + q < Mloc) ? a0 + q : Mloc - 1;  // (groups past the end: finite values, never stored)
+      const float* kp = kz + (size_t)a * M + b;                    // wave-uniform address: s_load
+      f32x2 k1 = f32x2{kp[0], two ? kp[1] : 0.f};
+      if constexpr (!JOINT) {
+        // ks g - kr (x_b - x_a) with ks = kz, kr = (2 / h) kz:   kz (g - (2 / h) (x_b - x_a))
+        acc2[q] = __builtin_elementwise_fma(k1, __builtin_elementwise_fma(mc2h, xp - xa2[q], gp), acc2[q]);
+      } else {
+        const float* tp = kt + (size_t)a * M + b;
+        const f32x2 k2 = f32x2{tp[0], two ? tp[1] : 0.f};
+        const f32x2 ks = k1 + k2, kr = (seg_is_theta ? k2 : k1) * mc2h;  // (-(2 / h) k: the sign is folded in)
+        acc2[q] = __builtin_elementwise_fma(kr, xp - xa2[q], __builtin_elementwise_fma(ks, gp, acc2[q]));
+      }
     }
-    x[o] = xn;
-    // overlapped exchange: the new value also goes straight into this rank's send rows [Mloc][Ev] (no separate export pass)
-    if (vout) vout[(size_t)a * vout_stride + vout_off + i] = xn;
+  };
+  // batches of 8 row pairs, double-buffered: the next batch is requested before the current one is multiplied.  Order of the sums: pairs
+  // ascending -- a function of M only.
+  const int nbat = (npair + PFP - 1) / PFP;
+  for (int pb = 0; pb < nbat; pb += 2) {
+    if (pb + 1 < nbat) fetch(pb + 1, gb, xb_);
+    // (a compiler fence per KF pairs: hipcc otherwise hoists the scalar loads of the whole quarter -- 256 SGPRs -- to the top and parks
+    //  them in VGPR lanes: 235 v_writelane / v_readlane per wave)
+#pragma unroll
+    for (int p = 0; p < PFP; ++p) {
+      if ((p & (KF - 1)) == 0) asm volatile("" ::: "memory");
+      if (FULL || PFP * pb + p < npair) pair_step(PFP * pb + p, ga[p], xa_[p]);
+    }
+    if (pb + 1 < nbat) {
+      if (pb + 2 < nbat) fetch(pb + 2, ga, xa_);
+#pragma unroll
+      for (int p = 0; p < PFP; ++p) {
+        if ((p & (KF - 1)) == 0) asm volatile("" ::: "memory");
+        if (FULL || PFP * (pb + 1) + p < npair) pair_step(PFP * (pb + 1) + p, gb[p], xb_[p]);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < TA; ++q) part[(wave * TA + q) * 64 + lane] = acc2[q].x + acc2[q].y;  // even rows + odd rows of the quarter
+  __syncthreads();
+  if (ok) {
+#pragma unroll
+    for (int qq = 0; qq < TA / 4; ++qq) {
+      const int q = wave + 4 * qq, a = a0 + q;
+      if (!FULL && a >= Mloc) continue;
+      const float tot = ((part[(0 * TA + q) * 64 + lane] + part[(1 * TA + q) * 64 + lane]) + part[(2 * TA + q) * 64 + lane]) +
+                        part[(3 * TA + q) * 64 + lane];
+      const float phi = -tot / (float)M;
+      // (own value: one of the registers loaded in the prologue, picked with selects instead of a dynamically indexed register array)
+      float xv = xa2[0].x;
+#pragma unroll
+      for (int q_ = 1; q_ < TA; ++q_) xv = (q_ == q) ? xa2[q_].x : xv;
+      const size_t o = (size_t)a * len + i;
+      if (phi_out) phi_out[o] = phi;
+      float xn;
+      if (rmsprop) {
+        const float vv = ve[qq] * 0.9f + phi * phi * 0.1f;
+        v[o] = vv;
+        xn = xv - stepsize * phi / sqrtf(vv + 1e-8f);
+      } else {
+        xn = xv - stepsize * phi;
+      }
+      x[o] = xn;
+      // overlapped exchange: the new value also goes straight into this rank's send rows [Mloc][Ev] (no separate export pass)
+      if (vout) vout[(size_t)a * vout_stride + vout_off + i] = xn;
+    }
   }
 }
 

@@ -46,7 +46,34 @@ struct TailArgs {
   unsigned long long* dbg;  // profiling: phase time stamps of block 0 (100 MHz ticks, accumulated in dbg[1..5]); null in production
   float* w_tot;             // large n_vars (W, U, V do not fit in LDS): phases A and B only, W goes to w_tot [Mloc][d][d] and
                             // k_backproject_big does phase C; ldz must be 0 then.  null: everything in this kernel
+  // join with the engine's second stream INSIDE the kernel (see tail_join_wait): the acyclicity chain (edge probabilities in the split
+  // pipeline, matrix powers, reduction) ends with a one-thread kernel that stores `join_seq` to *join_flag.  null: stream order covers it.
+  const unsigned int* join_flag;
+  unsigned int join_seq;
+  unsigned int* join_err;   // set to 1 when the flag did not arrive within the time-out (the host checks it after the chunk)
 };
+
+// The main stream does not wait for the second stream with an event (a barrier packet in front of this kernel: +2.5 .. 7 us on the
+// critical path even when the awaited kernels finished long ago, scripts/probe/stream_hop.hip); the kernel itself polls a flag that the
+// second stream's last kernel stores after w_acyc (and, in the split pipeline, probs) are complete.  That kernel's end has released its
+// predecessors' stores to memory; the acquire fence here drops what this CU / XCD may hold of those lines.  Normally the flag is 14+ us
+// old when the poll happens: one uncached load.  Bounded: a flag that never arrives (a launch that failed) ends the wait after ~0.2 s
+// and raises join_err instead of hanging the GPU.
+__device__ __forceinline__ void tail_join_wait(const TailArgs& A) {
+  if (!A.join_flag) return;
+  const unsigned long long t0 = wall_clock64();
+  // (sequence numbers wrap: compare as a signed difference)
+  while ((int)(__hip_atomic_load(A.join_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.join_seq) < 0) {
+    __builtin_amdgcn_s_sleep(4);
+    if (wall_clock64() - t0 > 20000000ull) {  // 100 MHz ticks
+      if (A.join_err) *A.join_err = 1u;
+      break;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// one thread, last on the second stream
+__global__ void k_join_flag(unsigned int* flag, unsigned int seq) { __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 __host__ __device__ inline int tail_nsplit(int S, int d) {
   int n = TAIL_NT / (S > 0 ? S : 1);
@@ -100,6 +127,10 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
   uint64_t* mk = reinterpret_cast<uint64_t*>(smem_raw + tail_fixed_bytes(d, ldz, S, true));
   __shared__ double red[2 * (TAIL_NT / 64)];
   __shared__ int nnz_s;
+  if (A.join_flag) {  // (block-uniform)
+    if (tid == 0) tail_join_wait(A);
+    __syncthreads();
+  }
 
   // ---- requests that do not depend on phase A: Z (-> U / V images), this thread's first elements of mean(W_acyc), the edge
   // probabilities (and W_lik of the other estimators), the soft in-degrees of the scale-free prior
@@ -114,14 +145,54 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
     pp[u] = e < dd ? pm[e] : 0.f;
     pw[u] = (e < dd && !lik) ? wlg[e] : 0.f;
   }
+  // Z and (score estimator) the first batch of this thread's node scores are requested TOGETHER, before anything is stored to LDS: a rolled
+  // `load -> LDS store` loop waits for every load on its own, and phase A's loads used to be issued only behind it (two to four dependent
+  // trips to the far cache levels at the start of the step's most latency-bound kernel)
   const float2* zm = reinterpret_cast<const float2*>(A.z + (size_t)m * d * k * 2);
-  for (int e = tid; e < (big ? 0 : d * k); e += TAIL_NT) {
-    const int j = e / k, q = e - j * k;
-    const float2 uv = zm[e];
-    Us[j * ldz + q] = uv.x;
-    Vs[j * ldz + q] = uv.y;
+  constexpr int ZB = 4;
+  const int nz = big ? 0 : d * k;
+  float2 zpre[ZB];
+#pragma unroll
+  for (int u = 0; u < ZB; ++u) {
+    const int e = u * TAIL_NT + tid;
+    zpre[u] = zm[e < nz ? e : 0];
   }
-  for (int e = tid; e < (kp4 - d) * ldz; e += TAIL_NT) {  // k-step padding rows of the MFMA operands
+  const int nsplit_ = tail_nsplit(S, d), jw_ = (d + nsplit_ - 1) / nsplit_;
+  double nspre[8];
+  {
+    const bool has = lik && tid < nsplit_ * S;
+    const int part = has ? tid / S : 0, s_ = tid - part * S, j0 = part * jw_, j1 = (j0 + jw_ < d) ? j0 + jw_ : d;
+    const double* nsm = A.node_scores + (size_t)m * d * S;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) nspre[u] = (has && j0 + u < j1) ? nsm[(size_t)(j0 + u) * S + s_] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < ZB; ++u) {
+    const int e = u * TAIL_NT + tid;
+    if (e < nz) {
+      const int j = e / k, q = e - j * k;
+      Us[j * ldz + q] = zpre[u].x;
+      Vs[j * ldz + q] = zpre[u].y;
+    }
+  }
+  for (int e0 = ZB * TAIL_NT; e0 < nz; e0 += ZB * TAIL_NT) {  // (d k > 4096)
+    float2 zz[ZB];
+#pragma unroll
+    for (int u = 0; u < ZB; ++u) {
+      const int e = e0 + u * TAIL_NT + tid;
+      zz[u] = zm[e < nz ? e : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < ZB; ++u) {
+      const int e = e0 + u * TAIL_NT + tid;
+      if (e < nz) {
+        const int j = e / k, q = e - j * k;
+        Us[j * ldz + q] = zz[u].x;
+        Vs[j * ldz + q] = zz[u].y;
+      }
+    }
+  }
+  for (int e = tid; e < (big ? 0 : (kp4 - d) * ldz); e += TAIL_NT) {  // k-step padding rows of the MFMA operands
     Us[d * ldz + e] = 0.f;
     Vs[d * ldz + e] = 0.f;
   }
@@ -148,6 +219,11 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
       const int j0 = part * jw, j1 = (j0 + jw < d) ? j0 + jw : d;
       double t = 0.0;
       int j = j0;
+      if (idx == tid) {  // the first eight (requested in the prologue), in the same ascending order as the loops below
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += (j0 + u < j1) ? nspre[u] : 0.0;
+        j = j0 + 8 < j1 ? j0 + 8 : j1;
+      }
       for (; j + 8 <= j1; j += 8) {
         double v[8];
 #pragma unroll

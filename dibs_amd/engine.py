@@ -174,7 +174,7 @@ class Engine:
         _lib.check(self.lib.dibs_engine_get_timers(self._h, _ptr(ms), _ptr(n), K_COUNT))
         return {KERNELS[i]: (float(ms[i]), int(n[i])) for i in range(K_COUNT) if n[i]}
 
-    def counters(self):
-        out = np.zeros(8, np.float64)
-        _lib.check(self.lib.dibs_engine_get_counters(self._h, _ptr(out), 8))
+    def counters(self, n=32):
+        out = np.zeros(n, np.float64)
+        _lib.check(self.lib.dibs_engine_get_counters(self._h, _ptr(out), n))
         return out

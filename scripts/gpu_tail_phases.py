@@ -10,5 +10,9 @@ eng = Engine(cfg); eng.set_data(data.x); eng.init_particles(random.PRNGKey(1))
 eng.run(0, 5)
 eng.set_profiling(True); eng.reset_timers(); eng.run(5, 20)
 c = eng.counters(); t = eng.timers()
-print("phase ticks/launch (100 MHz -> x10 ns):", [float(x) / 20 * 10 for x in c[1:5]], "ns")
+print('after 20 steps'); 
+c = eng.counters(); t = eng.timers()
+print("k_particle_grad phase ns/launch (A, stage, B, C):", [float(x) / 20 * 10 for x in c[1:5]])
+print("k_edge_scores   phase ns/launch (load+store, barrier, MFMA, epilogue):", [float(x) / 20 * 10 for x in c[9:13]])
 print({k: v[0] / v[1] * 1e3 for k, v in t.items()})
+
