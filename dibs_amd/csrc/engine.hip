@@ -771,6 +771,17 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
   auto launch_edge = [&](hipStream_t st, hipEvent_t stop_ev) {
     KTimer tm(e, DIBS_K_EDGE, st);
     const size_t lds = (size_t)2 * e->dpad * e->ldk * 4;
+    static const bool edge_old = getenv("DIBS_EDGE_OLD") != nullptr;  // (A/B switch)
+    if (!edge_old && e->d <= 64 && e->k <= 64 && e->edge_kc >= e->k && e->ldk <= 128) {  // one 16-wave block per particle (k_edge_scores_p)
+      allow_lds(k_edge_scores_p, lds);
+      if (stop_ev)
+        hipExtLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, nullptr, stop_ev, 0, e->z, e->scores, e->thr, e->probs, e->eas,
+                              alpha, e->d, e->k, e->dpad, e->ldk);
+      else
+        hipLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, e->z, e->scores, e->thr, e->probs, e->eas, alpha, e->d, e->k,
+                           e->dpad, e->ldk);
+      return;
+    }
 
     const int ntile = (e->dpad / 16) * (e->dpad / 16);
     int nby = ntile >= 16 ? 4 : (ntile >= 8 ? 2 : 1);

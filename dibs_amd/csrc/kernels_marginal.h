@@ -131,6 +131,67 @@ __global__ __launch_bounds__(256) void k_edge_scores(const float* __restrict__ z
   }
 }
 
+// K1p (round 5)  the same for n_vars <= 64, k <= 64: ONE block of 16 waves per particle.  k_edge_scores runs four blocks per particle and
+//     each of them loads the whole particle (the score tiles of a block need 16 rows of U and all of V, but U and V are interleaved): 4 x 40
+//     KB at the headline size, and its load phase is what the kernel spends its time in (4.1 of 10 us, measured with clock stamps).  Here Z is
+//     loaded once -- wave w takes rows w, w + 16, ..., one lane per latent column, all loads of a lane in flight together, no index
+//     arithmetic beyond an add -- and wave t computes tile t.  Same MFMA sequence, same epilogue: results are bit-identical.
+// grid = Mloc, block = 1024; dynamic LDS = 2 * dpad * ldk * 4
+__global__ __launch_bounds__(1024) void k_edge_scores_p(const float* __restrict__ z, float* __restrict__ scores, uint32_t* __restrict__ thr,
+                                                        float* __restrict__ probs, float* __restrict__ eas, float alpha, int d, int k,
+                                                        int dpad, int ldk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Us = smem;
+  float* Vs = smem + (size_t)dpad * ldk;
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float2* zm = reinterpret_cast<const float2*>(z + (size_t)m * d * k * 2);
+  const int nt = dpad >> 4;
+  float2 uv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = wave + 16 * r;
+    const bool in = i < d && lane < k;
+    uv[r] = zm[in ? i * k + lane : 0];
+    if (!in) uv[r] = make_float2(0.f, 0.f);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = wave + 16 * r;
+    if (i < dpad) {
+      if (lane < ldk) {  // (ldk < 64 for small k: the row ends before the wave does)
+        Us[i * ldk + lane] = uv[r].x;
+        Vs[i * ldk + lane] = uv[r].y;
+      }
+      if (64 + lane < ldk) {  // (row padding beyond the 64 latent columns a wave covers: ldk = kp + (2 - kp) mod 32 <= 98)
+        Us[i * ldk + 64 + lane] = 0.f;
+        Vs[i * ldk + 64 + lane] = 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  const int t = wave;
+  if (t >= nt * nt) return;  // (wave-uniform; no barrier below)
+  const int ti = t / nt, tj = t - ti * nt, kp = (k + 3) & ~3;
+  const float* ua = Us + (size_t)(ti * 16 + (lane & 15)) * ldk + (lane >> 4);
+  const float* vb = Vs + (size_t)(tj * 16 + (lane & 15)) * ldk + (lane >> 4);
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < kp; k0 += 4) a = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[k0], vb[k0], a, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = ti * 16 + (lane >> 4) * 4 + r, col = tj * 16 + (lane & 15);
+    if (row < d && col < d) {
+      const float s = a[r];
+      const size_t o = ((size_t)m * d + row) * d + col;
+      scores[o] = s;
+      const double ex = exp(-(double)__fmul_rn(alpha, s));  // (the epilogue of k_edge_scores, operation for operation)
+      const float pf = (float)(1.0 / (1.0 + ex));
+      if (eas) eas[o] = (float)ex;
+      thr[o] = row == col ? 0u : (uint32_t)ceilf(pf * 8388608.0f);
+      probs[o] = row == col ? 0.f : pf;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, size_t pack_stride, size_t seg_off, int len,
                                               float* __restrict__ kout, int m0, int M, float scale, float h, int symmetric) {
   extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -19,6 +19,7 @@
 // ------------------------------------------------------------------------------------------------
 #define TAIL_NT 1024
 #define TAIL_EPT 3   // elements of W per thread and pass whose inputs are prefetched
+#define TAIL_SU 4    // samples per lane of the barrier-free softmax (S <= 256; more: the block-wide reductions)
 struct TailArgs {
   // A: score estimator
   const double* node_scores;  // [Mloc][d][S]  (null: w_lik is an input)
@@ -241,6 +242,55 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
       lp2[(size_t)part * S + s] = t;
     }
     __syncthreads();
+    double sm = 0.0;
+    if (S <= 64 * TAIL_SU) {
+      // softmax over the samples WITHOUT block barriers: every wave does all of it for itself (lane takes samples lane, lane + 64, ...), with
+      // wave-level reductions; wave 0 publishes the list of samples with non-zero weight.  (Rounds 2-4: one block-wide reduction per
+      // quantity -- seven barriers of sixteen waves and two double-precision exp per sample in a row, 5.2 us of the kernel's 18.7.)
+      double l[TAIL_SU], ex[TAIL_SU];
+      double mx = -INFINITY;
+#pragma unroll
+      for (int u = 0; u < TAIL_SU; ++u) {
+        const int s_ = lane + 64 * u;
+        l[u] = -INFINITY;
+        if (s_ < S) {
+          double t = lp2[s_];
+          for (int p = 1; p < nsplit; ++p) t += lp2[(size_t)p * S + s_];
+          l[u] = t;
+          if (wave == 0) A.logprobs[(size_t)m * S + s_] = (float)t;
+        }
+        mx = l[u] > mx ? l[u] : mx;
+      }
+      mx = wave_max_d(mx);
+      double den = 0.0;
+#pragma unroll
+      for (int u = 0; u < TAIL_SU; ++u) {
+        const bool in = lane + 64 * u < S;
+        ex[u] = in ? exp(l[u] - mx) : 0.0;
+        den += ex[u];
+        sm += in ? l[u] : 0.0;
+      }
+      den = wave_sum_d(den);
+      sm = wave_sum_d(sm);
+      if (wave == 0) {
+        int base = 0;
+#pragma unroll
+        for (int u = 0; u < TAIL_SU; ++u) {
+          if (64 * u < S) {  // (wave-uniform)
+            const float w = (float)(ex[u] / den);
+            const unsigned long long bal = __ballot(w != 0.f);
+            if (w != 0.f) {
+              const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+              nzi[pos] = lane + 64 * u;
+              nzw[pos] = w;
+            }
+            base += __popcll(bal);
+          }
+        }
+        if (lane == 0) nnz_s = base;
+      }
+      __syncthreads();
+    } else {
     for (int s = tid; s < S; s += TAIL_NT) {
       double t = lp2[s];
       for (int p = 1; p < nsplit; ++p) t += lp2[(size_t)p * S + s];
@@ -256,7 +306,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
     __syncthreads();
     mx = red[0];
     for (int w = 1; w < NW; ++w) mx = red[w] > mx ? red[w] : mx;
-    double den = 0.0, sm = 0.0;
+    double den = 0.0;
     for (int s = tid; s < S; s += TAIL_NT) {
       den += exp(lp[s] - mx);
       sm += lp[s];
@@ -295,6 +345,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
       if (lane == 0) nnz_s = base;
     }
     __syncthreads();
+    }  // (S > 64 TAIL_SU)
     ts[1] = wall_clock64();
     nnz = nnz_s;
     const float bold = A.baseline[m];
