@@ -98,6 +98,12 @@ struct dibs_engine {
   // round 5: the fork of a step without a record packet on the main stream -- the event IS the edge kernel's completion signal
   // (hipExtLaunchKernel stop event; scripts/probe/stream_hop.hip: 5.7 -> 2.2 us between k_edge_scores and k_bge_sample) -- and, optionally,
   // the join as a flag polled inside k_particle_grad instead of an event wait in front of it (DIBS_FLAG_JOIN=1)
+  // ... and, where k_edge_scores_p applies, no signal between the edge kernel and k_bge_sample at all: the second stream runs its OWN copy of
+  // the edge kernel (6.6 us on an idle machine, into scores2 / eas2) as soon as the optimizer step has finished (ev_z = completion signal of the
+  // last k_phi_update launch)
+  hipEvent_t ev_z = nullptr;
+  bool ev_z_valid = false;
+  float *scores2 = nullptr, *eas2 = nullptr;
   unsigned int* join_flag = nullptr;   // device word: sequence number stored by the second stream's last kernel of a step (k_join_flag)
   unsigned int* join_err = nullptr;    // pinned host word: raised by tail_join_wait when the flag did not arrive (checked after every chunk)
   unsigned int join_seq = 0;
@@ -253,6 +259,7 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
     HIP_OK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&e->ev_k0, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&e->ev_k1, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&e->ev_z, hipEventDisableTiming));
     HIP_OK(dalloc(&e->join_flag, (size_t)4));
     HIP_OK(hipHostMalloc((void**)&e->join_err, 4, hipHostMallocDefault));
     *e->join_err = 0u;
@@ -267,6 +274,10 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   HIP_OK(dalloc(&e->scores, Ml * dd));
   HIP_OK(dalloc(&e->probs, Ml * dd));
   if (e->d <= 112) HIP_OK(dalloc(&e->eas, Ml * dd));
+  if (e->stream2 && e->d <= 64 && e->k <= 64) {
+    HIP_OK(dalloc(&e->scores2, Ml * dd));
+    HIP_OK(dalloc(&e->eas2, Ml * dd));
+  }
   HIP_OK(dalloc(&e->thr, Ml * dd));
   HIP_OK(dalloc(&e->w_lik, Ml * dd));
   if (e->d > 112) {
@@ -398,7 +409,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (e->stream2) hipStreamSynchronize(e->stream2);
   void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->eas, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
-                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot, e->join_flag};
+                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot, e->join_flag, e->scores2, e->eas2};
   for (void* p : ptrs)
     if (p) hipFree(p);
   joint_free(&e->jw);
@@ -409,6 +420,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (e->ev_k0) hipEventDestroy(e->ev_k0);
   if (e->ev_k1) hipEventDestroy(e->ev_k1);
   if (e->join_err) hipHostFree(e->join_err);
+  if (e->ev_z) hipEventDestroy(e->ev_z);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   for (auto& pe : e->pending) {
@@ -579,6 +591,7 @@ extern "C" int dibs_engine_init_particles(dibs_engine* e, const uint32_t key[2])
   }
   e->kmat_ext = false;  // (a kernel slab computed by dibs_engine_kmat_values belonged to the particles that were just replaced)
   e->vals_fresh = false;
+  e->ev_z_valid = false;
   HIP_OK(hipMemsetAsync(e->vz, 0, (size_t)e->Mloc * e->D * 4, e->stream));
   if (e->P) HIP_OK(hipMemsetAsync(e->vtheta, 0, (size_t)e->Mloc * e->P * 4, e->stream));
   HIP_OK(hipMemsetAsync(e->baseline, 0, (size_t)e->Mloc * 4, e->stream));
@@ -594,6 +607,7 @@ extern "C" int dibs_engine_set_state(dibs_engine* e, const float* z, const float
   HIP_OK(hipStreamSynchronize(e->stream));
   const size_t nz = (size_t)e->Mloc * e->D * 4, nt = (size_t)e->Mloc * e->P * 4;
   if (z || theta) e->vals_fresh = false;
+  e->ev_z_valid = false;
   if (z || theta) e->kmat_ext = false;  // (an externally computed kernel slab belonged to the old values: phase B computes its own unless
                                         //  dibs_engine_kmat_values is called again for the new ones)
   if (z) HIP_OK(hipMemcpy(e->z, z, nz, hipMemcpyHostToDevice));
@@ -700,6 +714,11 @@ struct DevBuf {
   hipError_t alloc(size_t n) { return dalloc(&p, n); }
 };
 
+static bool edge_old_env() {
+  static const bool v = getenv("DIBS_EDGE_OLD") != nullptr;  // (A/B switch: k_edge_scores with four blocks per particle also where k_edge_scores_p applies)
+  return v;
+}
+
 // ---- one SVGD step, split at the exchange point ----------------------------------------------
 // carry keys: the loop-carry key advances by one split(key, M+1) per estimator batch (svgd.py:245, 251 / 695, 699, 703);
 // the host walks the chain (row 0), kernels derive row 1 + m.
@@ -764,17 +783,19 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
   // (a small acyclicity launch -- <= 512 blocks: config 2, or a rank of a sharded headline run -- stays on the main stream: the fork / join
   //  events cost 6 + 6 us of the critical path, more than such a launch can hide; measured at config 2: 16 100 -> see DESIGN.md)
   const bool fork = do_prior && do_lik && e->stream2 != nullptr && (long)e->acyc_nblk * e->Mloc > 512, join_now = e->profiling && !e->profiling_concurrent;
-  static const bool want_flag_join = getenv("DIBS_FLAG_JOIN") != nullptr, no_ext_fork = getenv("DIBS_NO_EXT_FORK") != nullptr;
+  static const bool want_flag_join = getenv("DIBS_NO_FLAG_JOIN") == nullptr, no_ext_fork = getenv("DIBS_NO_EXT_FORK") != nullptr;
   // the join inside k_particle_grad (tail_join_wait) instead of an event wait in front of it: measured neutral to slightly slower (the
   // acquire fence of every polling block drops its XCD's L2), kept behind DIBS_FLAG_JOIN=1; per-kernel timing always uses the event
   const bool flag_join = fork && !join_now && want_flag_join && e->join_flag != nullptr;
-  auto launch_edge = [&](hipStream_t st, hipEvent_t stop_ev) {
+  auto launch_edge = [&](hipStream_t st, hipEvent_t stop_ev, bool copy2 = false) {
     KTimer tm(e, DIBS_K_EDGE, st);
     const size_t lds = (size_t)2 * e->dpad * e->ldk * 4;
-    static const bool edge_old = getenv("DIBS_EDGE_OLD") != nullptr;  // (A/B switch)
-    if (!edge_old && e->d <= 64 && e->k <= 64 && e->edge_kc >= e->k && e->ldk <= 128) {  // one 16-wave block per particle (k_edge_scores_p)
+    if (!edge_old_env() && e->d <= 64 && e->k <= 64 && e->edge_kc >= e->k && e->ldk <= 128) {  // one 16-wave block per particle (k_edge_scores_p)
       allow_lds(k_edge_scores_p, lds);
-      if (stop_ev)
+      if (copy2)  // (the second stream's own copy: scores / eas for the acyclicity kernel)
+        hipLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, e->z, e->scores2, (uint32_t*)nullptr, (float*)nullptr, e->eas2, alpha,
+                           e->d, e->k, e->dpad, e->ldk);
+      else if (stop_ev)
         hipExtLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, nullptr, stop_ev, 0, e->z, e->scores, e->thr, e->probs, e->eas,
                               alpha, e->d, e->k, e->dpad, e->ldk);
       else
@@ -802,13 +823,23 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
   };
   // fork without a record packet on the main stream: the event is the edge kernel's own completion signal (hipExtLaunchKernel stop event)
   const bool ext_fork = fork && !e->profiling && !no_ext_fork;
-  launch_edge(e->stream, ext_fork ? e->ev_fork : nullptr);
+  // no fork signal at all: the second stream computes its own scores from Z as soon as the previous optimizer step is done (see ev_z)
+  static const bool no_dup_edge = getenv("DIBS_DUP_EDGE") == nullptr;  // (measured slower: the acyclicity kernel starts 6 us earlier and takes them from k_bge_sample; off unless DIBS_DUP_EDGE=1)
+  const bool dup_edge = ext_fork && !xk && !no_dup_edge && e->ev_z_valid && e->scores2 && !edge_old_env() && e->d <= 64 && e->k <= 64 &&
+                        e->edge_kc >= e->k && e->ldk <= 128;
+  launch_edge(e->stream, (ext_fork && !dup_edge) ? e->ev_fork : nullptr);
   bool score_lik = false;
   if (fork) {
-    if (!ext_fork) hipEventRecord(e->ev_fork, e->stream);
-    hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
-    const AcycLaunch al{e->stream2, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, Mg, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
-                        e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr, e->eas};
+    if (dup_edge) {
+      hipStreamWaitEvent(e->stream2, e->ev_z, 0);
+      launch_edge(e->stream2, nullptr, true);
+    } else {
+      if (!ext_fork) hipEventRecord(e->ev_fork, e->stream);
+      hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
+    }
+    const AcycLaunch al{e->stream2, dup_edge ? e->scores2 : e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, Mg, e->Mloc, e->d, e->Sa,
+                        e->acyc_cpb, e->acyc_units, e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr,
+                        dup_edge ? e->eas2 : e->eas};
     acyc_power_timed(e, al, e->stream2);
     {
       KTimer tm(e, DIBS_K_ACYC_REDUCE, e->stream2);
@@ -989,7 +1020,12 @@ static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_s
   }
   {
     KTimer tm(e, DIBS_K_PHI_UPDATE);
+    // the LAST optimizer launch of a step carries "the particles of the next step are final" as its own completion signal (ev_z)
+    static const bool dup_edge_on = getenv("DIBS_DUP_EDGE") != nullptr;
+    const bool mark_z = dup_edge_on && e->stream2 != nullptr && e->ev_z != nullptr && e->scores2 != nullptr && !e->profiling;
+    e->ev_z_valid = false;
     auto phi = [&](size_t val_off, size_t grad_off, size_t len, int is_theta, float* x, float* v, float* phi_out, float h) {
+      const hipEvent_t stop_ev = (mark_z && (is_theta || !c.joint)) ? e->ev_z : nullptr;
       // particles per block: as many as keep >= 1024 blocks in flight and the tables within the LDS budget
       // (headline size: TA = 16 / 8 / 4 measured 20.5 / 18.9 / 26.0 us)
       const long cols = (long)((len + 63) / 64);
@@ -1017,9 +1053,16 @@ static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_s
 #define PHI_LAUNCH(TA_, F_, J_)                                                                                                \
       {                                                                                                                          \
         allow_lds(k_phi_update<TA_, F_, J_>, lds);                                                                               \
-        hipLaunchKernelGGL((k_phi_update<TA_, F_, J_>), g, dim3(256), lds, e->stream, pack, rs.stride, val_off, grad_off, (int)len, e->kz, \
-                           e->kt, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize, c.optimizer == DIBS_OPT_RMSPROP, \
-                           (int)cols, ngroups, vals_send, (size_t)e->Ev, is_theta ? (size_t)e->D : (size_t)0);               \
+        if (stop_ev)                                                                                                             \
+          hipExtLaunchKernelGGL((k_phi_update<TA_, F_, J_>), g, dim3(256), lds, e->stream, nullptr, stop_ev, 0, pack, rs.stride, val_off, grad_off, \
+                                (int)len, e->kz, e->kt, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize,      \
+                                c.optimizer == DIBS_OPT_RMSPROP, (int)cols, ngroups, vals_send, (size_t)e->Ev,                    \
+                                is_theta ? (size_t)e->D : (size_t)0);                                                             \
+        else                                                                                                                     \
+          hipLaunchKernelGGL((k_phi_update<TA_, F_, J_>), g, dim3(256), lds, e->stream, pack, rs.stride, val_off, grad_off, (int)len, e->kz, \
+                             e->kt, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize, c.optimizer == DIBS_OPT_RMSPROP, \
+                             (int)cols, ngroups, vals_send, (size_t)e->Ev, is_theta ? (size_t)e->D : (size_t)0);             \
+        if (stop_ev) e->ev_z_valid = true;                                                                                       \
       }
 #define PHI_PICK(TA_)                                                                                                          \
       if (e->kt) { PHI_LAUNCH(TA_, false, true) } /* (FULL + JOINT: hipcc hoists the scalar kernel entries into 230 VGPRs) */       \

@@ -186,8 +186,8 @@ __global__ __launch_bounds__(1024) void k_edge_scores_p(const float* __restrict_
       const double ex = exp(-(double)__fmul_rn(alpha, s));  // (the epilogue of k_edge_scores, operation for operation)
       const float pf = (float)(1.0 / (1.0 + ex));
       if (eas) eas[o] = (float)ex;
-      thr[o] = row == col ? 0u : (uint32_t)ceilf(pf * 8388608.0f);
-      probs[o] = row == col ? 0.f : pf;
+      if (thr) thr[o] = row == col ? 0u : (uint32_t)ceilf(pf * 8388608.0f);  // (null: the copy of the second stream, scores / eas only)
+      if (probs) probs[o] = row == col ? 0.f : pf;
     }
   }
 }

@@ -56,10 +56,11 @@ struct TailArgs {
 
 // The main stream does not wait for the second stream with an event (a barrier packet in front of this kernel: +2.5 .. 7 us on the
 // critical path even when the awaited kernels finished long ago, scripts/probe/stream_hop.hip); the kernel itself polls a flag that the
-// second stream's last kernel stores after w_acyc (and, in the split pipeline, probs) are complete.  That kernel's end has released its
-// predecessors' stores to memory; the acquire fence here drops what this CU / XCD may hold of those lines.  Normally the flag is 14+ us
-// old when the poll happens: one uncached load.  Bounded: a flag that never arrives (a launch that failed) ends the wait after ~0.2 s
-// and raises join_err instead of hanging the GPU.
+// second stream's last kernel stores after w_acyc is complete.  That kernel's end has released its predecessors' stores to memory; the
+// consumer reads w_acyc with agent-scope loads (tail_ld_joined: past this XCD's L2, whose lines may be a step old) AFTER the block has met
+// the polling thread at a barrier -- no acquire fence: `buffer_inv sc1` drops the XCD's whole L2 under the other blocks' feet (measured:
+// the join gap it saves is lost again).  Normally the flag is 14+ us old when the poll happens: one uncached load.  Bounded: a flag that
+// never arrives (a launch that failed) ends the wait after ~0.2 s and raises join_err instead of hanging the GPU.
 __device__ __forceinline__ void tail_join_wait(const TailArgs& A) {
   if (!A.join_flag) return;
   const unsigned long long t0 = wall_clock64();
@@ -71,7 +72,9 @@ __device__ __forceinline__ void tail_join_wait(const TailArgs& A) {
       break;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ float tail_ld_joined(const TailArgs& A, const float* p) {
+  return A.join_flag ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
 // one thread, last on the second stream
 __global__ void k_join_flag(unsigned int* flag, unsigned int seq) { __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
@@ -128,10 +131,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
   uint64_t* mk = reinterpret_cast<uint64_t*>(smem_raw + tail_fixed_bytes(d, ldz, S, true));
   __shared__ double red[2 * (TAIL_NT / 64)];
   __shared__ int nnz_s;
-  if (A.join_flag) {  // (block-uniform)
-    if (tid == 0) tail_join_wait(A);
-    __syncthreads();
-  }
+  if (A.join_flag && tid == 0) tail_join_wait(A);  // (the block meets this thread at its first barrier; w_acyc is read behind it)
 
   // ---- requests that do not depend on phase A: Z (-> U / V images), this thread's first elements of mean(W_acyc), the edge
   // probabilities (and W_lik of the other estimators), the soft in-degrees of the scale-free prior
@@ -142,10 +142,19 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
 #pragma unroll
   for (int u = 0; u < TAIL_EPT; ++u) {
     const int e = u * TAIL_NT + tid;
-    pa[u] = e < dd ? wag[e] : 0.f;
+    pa[u] = (e < dd && !A.join_flag) ? wag[e] : 0.f;
     pp[u] = e < dd ? pm[e] : 0.f;
     pw[u] = (e < dd && !lik) ? wlg[e] : 0.f;
   }
+  auto load_pa_joined = [&]() {  // (join_flag: called right behind the first block barrier)
+    if (A.join_flag) {
+#pragma unroll
+      for (int u = 0; u < TAIL_EPT; ++u) {
+        const int e = u * TAIL_NT + tid;
+        pa[u] = e < dd ? tail_ld_joined(A, wag + e) : 0.f;
+      }
+    }
+  };
   // Z and (score estimator) the first batch of this thread's node scores are requested TOGETHER, before anything is stored to LDS: a rolled
   // `load -> LDS store` loop waits for every load on its own, and phase A's loads used to be issued only behind it (two to four dependent
   // trips to the far cache levels at the start of the step's most latency-bound kernel)
@@ -242,6 +251,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
       lp2[(size_t)part * S + s] = t;
     }
     __syncthreads();
+    load_pa_joined();
     double sm = 0.0;
     if (S <= 64 * TAIL_SU) {
       // softmax over the samples WITHOUT block barriers: every wave does all of it for itself (lane takes samples lane, lane + 64, ...), with
@@ -362,6 +372,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
     }
   }
   __syncthreads();  // (phase A's scratch is dead: W takes its place)
+  if (!lik) load_pa_joined();
   ts[2] = wall_clock64();
   for (int e = tid; e < (big ? 0 : dp16 * ldw); e += TAIL_NT) Wm[e] = 0.f;  // padding rows / columns of the MFMA operand
   __syncthreads();
@@ -374,7 +385,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
 #pragma unroll
         for (int u = 0; u < TAIL_EPT; ++u) {
           const int e = e0 + u * TAIL_NT + tid;
-          pa[u] = e < dd ? wag[e] : 0.f;
+          pa[u] = e < dd ? tail_ld_joined(A, wag + e) : 0.f;
           pp[u] = e < dd ? pm[e] : 0.f;
           pw[u] = (e < dd && !lik) ? wlg[e] : 0.f;
         }
