@@ -491,6 +491,115 @@ __device__ __forceinline__ void bge_chol_quad(const float* __restrict__ R, int m
   last = lst;
 }
 
+// ---- one problem per PAIR of lanes (round 5), 17 <= n <= 24 ----------------------------------------------------------------------------
+// The quad layout repeats everything that is not a multiply-add of the update -- pivot broadcast, log2, rsqrt, the scaling of the pivot
+// column, index list, gather addresses, the double-precision score -- on four lanes per problem, and that is 55 % of its instructions
+// (N = 24: 686 update FMAs of ~1 520 instructions per lane, 6 080 lane-instructions per problem for n^3 / 6 <= 2 304 useful ones).  With
+// TWO lanes per problem -- lane p owns rows p, p + 2, ... -- the update costs 1 222 FMAs per lane (2 444 per problem: the row-cyclic
+// triangle wastes 6 % instead of 16 %) and the rest is paid twice instead of four times: ~3 950 lane-instructions per problem.  The pair
+// broadcast is the same DPP quad_perm inside v_fmac_f32_dpp ([0,0,2,2] / [1,1,3,3]).  156 registers of matrix at N = 24: the tiers beyond
+// (n = 25 .. 32) stay on the quad layout.
+__device__ __forceinline__ void fmac_pair(float& acc, const float& b, const float& own, int c) {
+  if (c & 1) asm volatile("v_fmac_f32_dpp %0, -%1, %2 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(own));
+  else asm volatile("v_fmac_f32_dpp %0, -%1, %2 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(b), "v"(own));
+}
+__device__ __forceinline__ float bcast_pair(const float& v, int c) {
+  float o;
+  if (c & 1) asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+  else asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v));
+  return o;
+}
+template <int NR, int K>
+struct BgePairCol {
+  static __device__ __forceinline__ void run(float (&L)[NR][2 * NR], int li, float& lsum, float& lst) {
+    constexpr int kb = K >> 1, N = 2 * NR;
+    const float piv = bcast_pair(L[kb][K], K);
+    lsum += __log2f(piv);
+    lst = (K == li) ? piv : lst;
+    float inv = __builtin_amdgcn_rsqf(piv);
+    asm volatile("s_nop 1" : "+v"(inv));  // (transcendental result -> VALU read inside an asm statement: see BgeQuadCol)
+#pragma unroll
+    for (int a = kb; a < NR; ++a) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(L[a][K]) : "v"(inv));
+    if (K + 1 < N) asm volatile("s_nop 1" ::: "memory");  // the scaled column is read through DPP next
+#pragma unroll
+    for (int c = K + 1; c < N; ++c)
+#pragma unroll
+      for (int a = c >> 1; a < NR; ++a) fmac_pair(L[a][c], L[c >> 1][K], L[a][K], c);
+    BgePairCol<NR, K + 1>::run(L, li, lsum, lst);
+  }
+};
+template <int NR>
+struct BgePairCol<NR, 2 * NR> {
+  static __device__ __forceinline__ void run(float (&)[NR][2 * NR], int, float&, float&) {}
+};
+#define BGE_PS 28  // ints of LDS per pair: index list of up to 24 entries, 16-byte aligned
+template <int NR, bool W2>
+__device__ __forceinline__ void bge_chol_pair(const float* __restrict__ R, int mat, int ldr, int d, int* __restrict__ pidx, uint64_t w0, uint64_t w1,
+                                              int j, int li, float& ld2, float& last) {
+  constexpr int N = 2 * NR;
+  const int p = threadIdx.x & 1;
+  // ---- index list: padding = d, each lane extracts the set bits of its half of the mask, j goes last
+#pragma unroll
+  for (int t = 0; t < NR; ++t) pidx[2 * t + p] = d;
+  wave_lds_fence();
+  {
+    uint64_t chunk;
+    int base_bit, t;
+    if (W2) {
+      chunk = p ? w1 : w0;
+      base_bit = 64 * p;
+      t = p ? __popcll(w0) : 0;
+    } else {
+      chunk = (w0 >> (32 * p)) & 0xFFFFFFFFull;
+      base_bit = 32 * p;
+      t = p ? __popc((uint32_t)w0) : 0;
+    }
+    while (__any(chunk != 0ull)) {
+      if (chunk) {
+        const int b = __ffsll((long long)chunk) - 1;
+        chunk &= chunk - 1ull;
+        if (t < N) pidx[t] = base_bit + b;
+        ++t;
+      }
+    }
+  }
+  wave_lds_fence();
+  if (p == 0 && li < N) pidx[li] = j;
+  wave_lds_fence();
+  int ro[NR];
+#pragma unroll
+  for (int a = 0; a < NR; ++a) ro[a] = mat + pidx[2 * a + p] * ldr;
+  // ---- gather, column by column (the column's index is read when it is needed: 24 registers less than holding the list):
+  // L[a][c] = row 2 a + p, column c <= 2 a + 1 (the entry right of the diagonal of lane 0's row is zero-filled scratch)
+  float L[NR][N];
+#pragma unroll
+  for (int c4 = 0; c4 < N; c4 += 4) {
+    const int4 ci4 = *reinterpret_cast<const int4*>(pidx + c4);
+    const int ci[4] = {ci4.x, ci4.y, ci4.z, ci4.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c4 + u;
+#pragma unroll
+      for (int a = c >> 1; a < NR; ++a) {
+        float v = R[ro[a] + ci[u]];
+        if (c > 2 * a) v = p ? v : 0.f;                                   // column 2 a + 1: only the odd lane's row reaches it
+        if (c >= 2 * a) v = (c - 2 * a == p && 2 * a + p > li) ? 1.f : v;  // padding row: unit diagonal
+        L[a][c] = v;
+      }
+    }
+  }
+  // (pinned into registers before the first DPP read: see bge_chol_quad)
+#pragma unroll
+  for (int a = 0; a < NR; ++a)
+#pragma unroll
+    for (int c = 0; c < 2 * a + 2; ++c) asm volatile("" : "+v"(L[a][c]));
+  asm volatile("s_nop 1" ::: "memory");
+  float lsum = 0.f, lst = 1.f;
+  BgePairCol<NR, 0>::run(L, li, lsum, lst);
+  ld2 = lsum - __log2f(lst);
+  last = lst;
+}
+
 // One problem per WAVE with 33 .. 64 rows, RIGHT-looking with the matrix in registers: lane r holds row r of the lower triangle (64
 // VGPRs); column step K scales the pivot column, publishes it in LDS (64 floats) and every lane updates its own row with broadcast reads
 // of that column -- a quarter of an LDS read per multiply-add where the left-looking bge_chol_wave needs two, and half a KiB of LDS per
@@ -550,7 +659,7 @@ __host__ __device__ inline size_t bge_generic_wave_bytes(int d) {
 // already be in the per-wave tier while its neighbour still builds quad index lists.  (Until the randomised test of tests/tools/gpu_fuzz.py
 // ran d = 96 / 112 with thousands of queued problems the regions were one array indexed by wave * max(sizes) but sized for nwg < 4 waves:
 // the quad lists of waves >= nwg lay beyond the allocation -- NaN node scores at d > 80.)
-__host__ __device__ inline size_t bge_quad_bytes() { return (size_t)16 * BGE_QS * 4; }
+__host__ __device__ inline size_t bge_quad_bytes() { return (size_t)32 * BGE_PS * 4; }  // (>= 16 * BGE_QS * 4: quad and pair lists share the region)
 // waves of a block that can work in the one-problem-per-wave tier (each needs a d x d factor in LDS)
 __host__ __device__ inline int bge_generic_waves(int d, bool r_in_lds) {
   const size_t r = r_in_lds ? (((size_t)2 * (d + 1) * (d + 1) * 4 + 15) & ~(size_t)15) : 0;
@@ -571,7 +680,7 @@ __host__ __device__ inline size_t bge_chol_lds_bytes(int d, bool r_in_lds) {
 // factorised, and a problem's table entries (log-gamma term, N_j, logdet R) as soon as its parent count is known -- at two waves per SIMD
 // (215 registers) nothing else hides those round trips (39 % of the wave cycles were s_waitcnt before: profiles/round2_pmc_lds_window.txt).
 template <bool R_LDS, bool W2>
-__global__ __launch_bounds__(256) void k_bge_chol(double* __restrict__ node_scores, BgeParams bp, BgeQueues qs, int d, int S,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(R_LDS ? 2 : 1))) void k_bge_chol(double* __restrict__ node_scores, BgeParams bp, BgeQueues qs, int d, int S,
                                                   unsigned long long* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ unsigned int cnt_s[BGE_NQ];
@@ -598,7 +707,7 @@ __global__ __launch_bounds__(256) void k_bge_chol(double* __restrict__ node_scor
 #pragma unroll
   for (int qi = 0; qi < BGE_NQ; ++qi) {
     cnt[qi] = cnt_s[qi];
-    const unsigned int per = qi == 0 ? 256u * BGE_NPL0 : (qi == 1 ? 256u * BGE_NPL1 : (qi == 2 ? 256u * BGE_NPL2 : (qi == 3 ? 256u : (qi < 8 ? 64u : (unsigned int)nwg))));
+    const unsigned int per = qi == 0 ? 256u * BGE_NPL0 : (qi == 1 ? 256u * BGE_NPL1 : (qi == 2 ? 256u * BGE_NPL2 : (qi == 3 ? 256u : (qi < 6 ? 128u : (qi < 8 ? 64u : (unsigned int)nwg)))));  // (tiers 4, 5: one problem per pair of lanes)
     units[qi] = (cnt[qi] + per - 1u) / per;
     total += units[qi];
   }
@@ -617,8 +726,8 @@ __global__ __launch_bounds__(256) void k_bge_chol(double* __restrict__ node_scor
   auto fetch = [&](int qi, unsigned int local, uint4 (&ea)[BGE_NPL0], uint4 (&eb)[BGE_NPL0]) {
     const unsigned int n_q = cnt_s[qi];
     const int npl = qi == 0 ? BGE_NPL0 : (qi == 1 ? BGE_NPL1 : (qi == 2 ? BGE_NPL2 : 1));
-    const unsigned int usz = qi < 4 ? 256u * (unsigned int)npl : (qi < 8 ? 64u : (unsigned int)nwg);
-    const unsigned int idx = qi < 4 ? (unsigned int)tid : (qi < 8 ? (unsigned int)(tid >> 2) : (unsigned int)wave);
+    const unsigned int usz = qi < 4 ? 256u * (unsigned int)npl : (qi < 6 ? 128u : (qi < 8 ? 64u : (unsigned int)nwg));
+    const unsigned int idx = qi < 4 ? (unsigned int)tid : (qi < 6 ? (unsigned int)(tid >> 1) : (qi < 8 ? (unsigned int)(tid >> 2) : (unsigned int)wave));
     const bool lane_ok = qi < 8 || wave < nwg;
     const uint4* lst = qs.list + (size_t)qi * qs.cap * W;  // (bge_entry_u4(W) == W for W <= 2)
 #pragma unroll
@@ -736,6 +845,18 @@ __global__ __launch_bounds__(256) void k_bge_chol(double* __restrict__ node_scor
     bge_chol_quad<NB_, W2>(Rm, mat, ldr, d, qbase + (lane >> 2) * BGE_QS, w0, w1, jj, li, ld2, last);          \
     store(has && (tid & 3) == 0, code, jj, tb, l, li, comp, ld2, last);                                            \
   }
+#define BGE_PAIR_TIER(NR_)                                                                                     \
+  {                                                                                                            \
+    bool has, comp;                                                                                            \
+    uint32_t code;                                                                                             \
+    int jj, l, li, mat;                                                                                        \
+    uint64_t w0, w1;                                                                                           \
+    float ld2, last;                                                                                           \
+    Tab tb;                                                                                                    \
+    load(ca[0], cb[0], has, code, jj, l, li, mat, comp, w0, w1, tb);                                           \
+    bge_chol_pair<NR_, W2>(Rm, mat, ldr, d, qbase + (lane >> 1) * BGE_PS, w0, w1, jj, li, ld2, last);          \
+    store(has && (tid & 1) == 0, code, jj, tb, l, li, comp, ld2, last);                                            \
+  }
   for (unsigned int u = blockIdx.x; u < total; u += gridDim.x) {
     const int qi = nqi;
     uint4 ca[BGE_NPL0], cb[BGE_NPL0];
@@ -757,8 +878,8 @@ __global__ __launch_bounds__(256) void k_bge_chol(double* __restrict__ node_scor
       case 1: BGE_LANE_TIER(8, BGE_NPL1) break;
       case 2: BGE_LANE_TIER(12, BGE_NPL2) break;
       case 3: BGE_LANE_TIER(16, 1) break;
-      case 4: BGE_QUAD_TIER(5) break;
-      case 5: BGE_QUAD_TIER(6) break;
+      case 4: BGE_PAIR_TIER(10) break;
+      case 5: BGE_PAIR_TIER(12) break;
       case 6: BGE_QUAD_TIER(7) break;
       case 7: BGE_QUAD_TIER(8) break;
       default:
@@ -790,6 +911,7 @@ __global__ __launch_bounds__(256) void k_bge_chol(double* __restrict__ node_scor
   }
 #undef BGE_LANE_TIER
 #undef BGE_QUAD_TIER
+#undef BGE_PAIR_TIER
   if (counters) {  // one atomic per block (same-address atomics from every wave cost tens of microseconds)
     __shared__ float fl_s[4];
     const float tot = wave_sum(flops);
