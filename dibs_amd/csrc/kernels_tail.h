@@ -77,7 +77,9 @@ __device__ __forceinline__ float tail_ld_joined(const TailArgs& A, const float* 
   return A.join_flag ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
 // one thread, last on the second stream
-__global__ void k_join_flag(unsigned int* flag, unsigned int seq) { __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+// (RELAXED: the end of the kernel in front of this one has already released its stores; a release here would write the L2 back once more --
+//  the one-thread kernel took 4.4 us with it)
+__global__ void k_join_flag(unsigned int* flag, unsigned int seq) { __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __host__ __device__ inline int tail_nsplit(int S, int d) {
   int n = TAIL_NT / (S > 0 ? S : 1);
