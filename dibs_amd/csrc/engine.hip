@@ -82,6 +82,7 @@ struct dibs_engine {
   float* acyc_big;  // n_vars > 112: buffers of the global-memory matrix powers (kernels_acyc_big.h)
   float* eas;       // [Mloc][d][d] exp(-alpha s) of this step (k_edge_scores -> k_acyc_hf / k_acyc_hfw); n_vars <= 112 only
   float *scores, *probs, *w_lik, *acyc_part, *w_acyc, *logprobs_z, *logprobs_th, *pack, *kz, *kt, *phi_z, *phi_th;
+  float* ksum = nullptr;  // joint models: kz + kt, formed by the k_kmat launch of kt (the weight matrix of the SVGD transform as ONE scalar-loadable array)
   uint32_t* thr;
   uint64_t* masks;
   BgeQueues bq;
@@ -303,6 +304,7 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   const size_t kpad = (((Ml + 127) / 128) * 128 - Ml) * e->M + 64;
   HIP_OK(dalloc(&e->kz, Ml * e->M + kpad));
   if (c.joint) HIP_OK(dalloc(&e->kt, Ml * e->M + kpad));
+  if (c.joint) HIP_OK(dalloc(&e->ksum, Ml * e->M + kpad));
   HIP_OK(dalloc(&e->phi_z, Ml * e->D));
   HIP_OK(dalloc(&e->phi_th, Ml * e->P));
   HIP_OK(dalloc(&e->counters, (size_t)DIBS_N_COUNTERS));
@@ -409,7 +411,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (e->stream2) hipStreamSynchronize(e->stream2);
   void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->eas, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
-                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot, e->join_flag, e->scores2, e->eas2};
+                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot, e->join_flag, e->scores2, e->eas2, e->ksum};
   for (void* p : ptrs)
     if (p) hipFree(p);
   joint_free(&e->jw);
@@ -865,10 +867,10 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
     allow_lds(k_kmat, kmat_lds(e->D > e->P ? e->D : e->P));
     const dim3 kg(e->Mloc, (e->M + KMAT_BT - 1) / KMAT_BT);
     hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->D), e->stream2, e->z, (size_t)e->D, (size_t)0, (int)e->D, e->kz, 0, e->M,
-                       (float)c.scale_latent, (float)c.h_latent, 1);
+                       (float)c.scale_latent, (float)c.h_latent, 1, (const float*)nullptr, (float*)nullptr);
     if (c.joint)
       hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->P), e->stream2, e->theta, (size_t)e->P, (size_t)0, (int)e->P, e->kt, 0, e->M,
-                         (float)c.scale_theta, (float)c.h_theta, 1);
+                         (float)c.scale_theta, (float)c.h_theta, 1, (const float*)e->kz, e->ksum);
     e->kmat_early = true;
   }
   if (fork) {
@@ -1013,10 +1015,10 @@ static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_s
     const dim3 kg(e->Mloc, (e->M + KMAT_BT - 1) / KMAT_BT);
     if (!e->kmat_fused)
       hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->D), e->stream, pack, rs.stride, rs.z_off,
-                         (int)e->D, e->kz, e->m0, e->M, (float)c.scale_latent, (float)c.h_latent, ksym);
+                         (int)e->D, e->kz, e->m0, e->M, (float)c.scale_latent, (float)c.h_latent, ksym, (const float*)nullptr, (float*)nullptr);
     if (c.joint)
       hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->P), e->stream, pack, rs.stride,
-                         rs.th_off, (int)e->P, e->kt, e->m0, e->M, (float)c.scale_theta, (float)c.h_theta, ksym);
+                         rs.th_off, (int)e->P, e->kt, e->m0, e->M, (float)c.scale_theta, (float)c.h_theta, ksym, (const float*)e->kz, e->ksum);
   }
   {
     KTimer tm(e, DIBS_K_PHI_UPDATE);
@@ -1047,6 +1049,9 @@ static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_s
       const size_t lds = phi_update_lds_bytes(ta, e->M);
       const int ngroups = (e->Mloc + ta - 1) / ta;
       const dim3 g((unsigned)(8 * ngroups * ((cols + 7) / 8)));
+      // joint models: the weights are kz + kt (e->ksum, formed by the k_kmat launch of kt), the repulsion uses the segment's own matrix
+      const float* const kw = e->kt ? e->ksum : e->kz;
+      const float* const kseg = e->kt ? (is_theta ? e->kt : e->kz) : nullptr;
       // FULL: whole 8-pair batches per wave and whole particle groups (no clamps inside the kernel)
       static const bool no_full = getenv("DIBS_PHI_NOFULL") != nullptr;  // (A/B switch)
       const bool full = !no_full && e->M % 64 == 0 && e->Mloc % ta == 0 && (size_t)e->M * rs.stride * 4 < ((size_t)1 << 32);  // (32-bit buffer offsets)
@@ -1055,17 +1060,17 @@ static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_s
         allow_lds(k_phi_update<TA_, F_, J_>, lds);                                                                               \
         if (stop_ev)                                                                                                             \
           hipExtLaunchKernelGGL((k_phi_update<TA_, F_, J_>), g, dim3(256), lds, e->stream, nullptr, stop_ev, 0, pack, rs.stride, val_off, grad_off, \
-                                (int)len, e->kz, e->kt, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize,      \
+                                (int)len, kw, kseg, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize,      \
                                 c.optimizer == DIBS_OPT_RMSPROP, (int)cols, ngroups, vals_send, (size_t)e->Ev,                    \
                                 is_theta ? (size_t)e->D : (size_t)0);                                                             \
         else                                                                                                                     \
-          hipLaunchKernelGGL((k_phi_update<TA_, F_, J_>), g, dim3(256), lds, e->stream, pack, rs.stride, val_off, grad_off, (int)len, e->kz, \
-                             e->kt, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize, c.optimizer == DIBS_OPT_RMSPROP, \
+          hipLaunchKernelGGL((k_phi_update<TA_, F_, J_>), g, dim3(256), lds, e->stream, pack, rs.stride, val_off, grad_off, (int)len, kw,   \
+                             kseg, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize, c.optimizer == DIBS_OPT_RMSPROP, \
                              (int)cols, ngroups, vals_send, (size_t)e->Ev, is_theta ? (size_t)e->D : (size_t)0);             \
         if (stop_ev) e->ev_z_valid = true;                                                                                       \
       }
 #define PHI_PICK(TA_)                                                                                                          \
-      if (e->kt) { PHI_LAUNCH(TA_, false, true) } /* (FULL + JOINT: hipcc hoists the scalar kernel entries into 230 VGPRs) */       \
+      if (e->kt) { if (full) PHI_LAUNCH(TA_, true, true) else PHI_LAUNCH(TA_, false, true) }                                     \
       else { if (full) PHI_LAUNCH(TA_, true, false) else PHI_LAUNCH(TA_, false, false) }
       if (ta == 16) { PHI_PICK(16) } else if (ta == 8) { PHI_PICK(8) } else { PHI_PICK(4) }
 #undef PHI_PICK
@@ -1150,10 +1155,10 @@ extern "C" int dibs_engine_kmat_values(dibs_engine* e, const void* vals_all_dev,
   const int ksym = e->Mloc == e->M;
   const float* vals = (const float*)vals_all_dev;
   hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->D), st, vals, (size_t)e->Ev, (size_t)0, (int)e->D, e->kz, e->m0, e->M, (float)c.scale_latent,
-                     (float)c.h_latent, ksym);
+                     (float)c.h_latent, ksym, (const float*)nullptr, (float*)nullptr);
   if (c.joint)
     hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->P), st, vals, (size_t)e->Ev, (size_t)e->D, (int)e->P, e->kt, e->m0, e->M, (float)c.scale_theta,
-                       (float)c.h_theta, ksym);
+                       (float)c.h_theta, ksym, (const float*)e->kz, e->ksum);
   HIP_OK(hipGetLastError());
   e->kmat_ext = true;
   return 0;

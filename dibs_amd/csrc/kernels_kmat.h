@@ -23,7 +23,10 @@ struct KmatFuse {
 #define KMAT_CH 32768  // floats of z_a staged in LDS at a time (128 KiB); longer vectors (DenseNN theta at d = 100) go in chunks
 __device__ __forceinline__ void kmat_block(float* __restrict__ smem, const float* __restrict__ pack, size_t pack_stride,
                                            size_t seg_off, int len, float* __restrict__ kout, int m0, int M, float scale, float h,
-                                           int symmetric, int a, int bt) {
+                                           int symmetric, int a, int bt, const float* __restrict__ kadd = nullptr,
+                                           float* __restrict__ ksum = nullptr) {
+  // (ksum != null: also writes kadd[a][b] + k[a][b] -- the joint models' weight matrix kz + kt, formed once here instead of per use in the
+  //  SVGD transform, where it can then be a scalar operand; kadd is the matrix of an EARLIER launch)
   // block (a, bt): particle a (local) against b = bt * KMAT_BT .. +KMAT_BT-1; wave w takes b = b0 + w, b0 + w + 4, ...
   // symmetric (one rank holds all particles): tiles below the diagonal are skipped and k[a][b] is mirrored into k[b][a]
   // -- the sum of squared differences is the same number either way, so the slab is bit-identical to the full computation.
@@ -113,6 +116,11 @@ __device__ __forceinline__ void kmat_block(float* __restrict__ smem, const float
       const float kv = (float)((double)scale * exp(-tot / (double)h));
       kout[(size_t)a * M + b] = kv;
       if (symmetric && b > a) kout[(size_t)b * M + a] = kv;
+      if (ksum) {
+        const float sv = kadd[(size_t)a * M + b] + kv;
+        ksum[(size_t)a * M + b] = sv;
+        if (symmetric && b > a) ksum[(size_t)b * M + a] = sv;
+      }
     }
   }
 }

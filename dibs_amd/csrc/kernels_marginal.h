@@ -193,9 +193,10 @@ __global__ __launch_bounds__(1024) void k_edge_scores_p(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, size_t pack_stride, size_t seg_off, int len,
-                                              float* __restrict__ kout, int m0, int M, float scale, float h, int symmetric) {
+                                              float* __restrict__ kout, int m0, int M, float scale, float h, int symmetric,
+                                              const float* __restrict__ kadd, float* __restrict__ ksum) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  kmat_block(smem, pack, pack_stride, seg_off, len, kout, m0, M, scale, h, symmetric, blockIdx.x, blockIdx.y);
+  kmat_block(smem, pack, pack_stride, seg_off, len, kout, m0, M, scale, h, symmetric, blockIdx.x, blockIdx.y, kadd, ksum);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -289,14 +290,20 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
     }
   };
   f32x2 ga[PFP], xa_[PFP], gb[PFP], xb_[PFP];
-  constexpr int KF = TA >= 8 ? 2 : 4;  // row pairs per group of scalar kernel-entry loads (TA * 2 KF SGPRs per group)
+  constexpr int KF = (TA >= 8 ? 2 : 4) / (JOINT ? 2 : 1);  // row pairs per group of scalar kernel-entry loads (TA * 2 KF SGPRs per group and matrix)
   fetch(0, ga, xa_);
-  f32x2 xa2[TA];  // the block's own values, each in both halves of a register pair (the packed subtraction below wants them so)
+  f32x2 xa2[TA];  // the block's own values, each in both halves of a register pair (the packed subtraction below wants them so); JOINT: times -(2 / h)
+  float xown[TA / 4];  // ... and those of the particles this thread finishes below (a0 + wave + 4 qq), as they are
+  const f32x2 mc2h = f32x2{-c2h, -c2h};
+#pragma unroll
+  for (int qq = 0; qq < TA / 4; ++qq) xown[qq] = 0.f;
 #pragma unroll
   for (int q = 0; q < TA; ++q) {
     const int a = (FULL || a0 + q < Mloc) ? a0 + q : Mloc - 1;
     const float t = FULL ? buf_ld(rs_x, il * 4u, (uint32_t)(m0 + a) * stride_b) : (pack + (size_t)(m0 + a) * pack_stride + val_off)[il];
-    xa2[q] = f32x2{t, t};
+    xa2[q] = JOINT ? f32x2{t, t} * mc2h : f32x2{t, t};
+#pragma unroll
+    for (int qq = 0; qq < TA / 4; ++qq) xown[qq] = (q == wave + 4 * qq) ? t : xown[qq];  // (wave-uniform select)
   }
   // optimizer state of the elements this thread finishes below (particle a0 + wave + 4 qq, element i)
   float ve[TA / 4];
@@ -308,10 +315,10 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
   f32x2 acc2[TA];
 #pragma unroll
   for (int q = 0; q < TA; ++q) acc2[q] = f32x2{0.f, 0.f};
-  const f32x2 mc2h = f32x2{-c2h, -c2h};
   // rows b = b_lo + 2 pr, b + 1 against the TA particles of the block; the two halves of acc2 = even / odd rows of the quarter
   auto pair_step = [&](int pr, f32x2 gp, f32x2 xp) {
     const int b = b_lo + 2 * pr;
+    const f32x2 xpc = JOINT ? xp * mc2h : xp;
     const bool two = FULL || 2 * pr + 1 < nrow;  // (an odd quarter's last pair has one row)
 #pragma unroll
     for (int q = 0; q < TA; ++q) {
@@ -322,10 +329,13 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
         // ks g - kr (x_b - x_a) with ks = kz, kr = (2 / h) kz:   kz (g - (2 / h) (x_b - x_a))
         acc2[q] = __builtin_elementwise_fma(k1, __builtin_elementwise_fma(mc2h, xp - xa2[q], gp), acc2[q]);
       } else {
+        // (kz + kt) g - (2 / h) k_seg (x_b - x_a) as three multiply-adds whose kernel entries stay scalar operands: forming kz + kt or
+        // (2 / h) k_seg first would be vector instructions on wave-uniform values (and, hoisted by hipcc, 230 VGPRs)
+        // JOINT: kz points at the weight matrix kz + kt (k_kmat forms it), kt at the matrix of THIS segment (repulsion); both stay scalar
+        // operands.  xpc / xac carry the factor -(2 / h).
         const float* tp = kt + (size_t)a * M + b;
         const f32x2 k2 = f32x2{tp[0], two ? tp[1] : 0.f};
-        const f32x2 ks = k1 + k2, kr = (seg_is_theta ? k2 : k1) * mc2h;  // (-(2 / h) k: the sign is folded in)
-        acc2[q] = __builtin_elementwise_fma(kr, xp - xa2[q], __builtin_elementwise_fma(ks, gp, acc2[q]));
+        acc2[q] = __builtin_elementwise_fma(k2, xpc - xa2[q], __builtin_elementwise_fma(k1, gp, acc2[q]));
       }
     }
   };
@@ -361,10 +371,7 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
       const float tot = ((part[(0 * TA + q) * 64 + lane] + part[(1 * TA + q) * 64 + lane]) + part[(2 * TA + q) * 64 + lane]) +
                         part[(3 * TA + q) * 64 + lane];
       const float phi = -tot / (float)M;
-      // (own value: one of the registers loaded in the prologue, picked with selects instead of a dynamically indexed register array)
-      float xv = xa2[0].x;
-#pragma unroll
-      for (int q_ = 1; q_ < TA; ++q_) xv = (q_ == q) ? xa2[q_].x : xv;
+      const float xv = xown[qq];  // (own value: loaded in the prologue)
       const size_t o = (size_t)a * len + i;
       if (phi_out) phi_out[o] = phi;
       float xn;

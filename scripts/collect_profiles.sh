@@ -42,7 +42,7 @@ f, w = parse(f"gpurun_out/{tag}_pmc_fetch.txt", "FETCH_SIZE"), parse(f"gpurun_ou
 # rocprof kernel name (prefix) -> the engine's timer name (bench.py's roofline looks its dominant kernel up by that name)
 prefixes = [("void k_acyc_hf", "acyc"), ("void k_acyc_bf", "acyc"), ("void k_acyc<", "acyc"), ("k_acyc_reduce", "acyc_reduce"), ("void k_bge_sample", "bge_nodes"),
             ("void k_bge_chol", "bge_big"), ("k_particle_grad", "particle_grad"), ("k_kmat", "kmat"), ("void k_phi_update", "phi_update"),
-            ("void k_edge_scores", "edge"), ("void k_lin_logprobs", "lin_logprobs"), ("void k_lin_grad", "lin_grad"), ("void k_nn_logprobs", "nn_logprobs"), ("k_nn_tables_hf", "nn_tables"),
+            ("void k_edge_scores", "edge"), ("k_edge_scores_p", "edge"), ("void k_lin_logprobs", "lin_logprobs"), ("void k_lin_grad", "lin_grad"), ("void k_nn_logprobs", "nn_logprobs"), ("k_nn_tables_hf", "nn_tables"),
             ("void k_nn_grad", "nn_grad"), ("k_nng_logprobs", "nng_logprobs"), ("k_nng_grad", "nng_grad"), ("void k_bge_soft", "bge_soft")]
 res = {}
 for k in f:
