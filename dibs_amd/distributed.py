@@ -75,10 +75,21 @@ class OverlapBuffers:
         self.gen = None      # ... i.e. of this generation of it (Engine.state_gen: bumped by init_particles / set_state)
 
 
+def torch_mul(src, dst):
+    import torch
+    torch.mul(src, 1, out=dst[:src.numel()] if dst.numel() != src.numel() else dst)
+
+
 def _gather(dst, src, group, single):
     import torch.distributed as dist
     if single:
-        dst.copy_(src)
+        if dst.is_cuda:
+            # a copy KERNEL, not Tensor.copy_ (= hipMemcpyAsync device-to-device): on a side stream the runtime's copy path resolves the
+            # cross-stream dependency on the host -- measured 360 us per step instead of 90 in the single-GPU emulation of an 8-way rank
+            # (profiles/round5_shard_scaling.txt); the collectives of a real group are kernels
+            torch_mul(src, dst)
+        else:
+            dst.copy_(src)
     else:
         dist.all_gather_into_tensor(dst, src, group=group)
 

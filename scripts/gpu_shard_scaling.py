@@ -33,7 +33,7 @@ for R in (1, 2, 4, 8):
         def go(t0, k):
             for t in range(t0, t0 + k):
                 e.step_local(t, sends[0].data_ptr())
-                recv[:n].copy_(sends[0])
+                torch.mul(sends[0], 1, out=recv[:n])
                 e.step_update(t, recv.data_ptr())
         go(T0, 20); torch.cuda.synchronize()
         t0 = time.perf_counter(); go(T0 + 20, 200); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 200
@@ -45,7 +45,7 @@ for R in (1, 2, 4, 8):
         planes = torch.zeros(2 * nv * R, device="cuda"); gs = torch.zeros(nv, device="cuda"); vs = torch.zeros(nv, device="cuda")
         ready = torch.cuda.Event()
         for r in range(R):
-            engs[r].export_values(vs.data_ptr()); planes[r * nv:(r + 1) * nv].copy_(vs)
+            engs[r].export_values(vs.data_ptr()); torch.mul(vs, 1, out=planes[r * nv:(r + 1) * nv])
         for o in engs[1:]:   # (their frozen rows stay in `planes`; eight engines' streams oversubscribe the hardware queues of one process)
             o.close()
         side, exported = torch.cuda.Stream(), torch.cuda.Event()
@@ -53,12 +53,12 @@ for R in (1, 2, 4, 8):
         def go2(t0, k):
             for t in range(t0, t0 + k):
                 e.step_local_grads(t, gs.data_ptr())
-                planes[nv * R:nv * R + nv].copy_(gs)            # (stands in for the gradient all-gather)
+                torch.mul(gs, 1, out=planes[nv * R:nv * R + nv])   # (stands in for the gradient all-gather; a copy KERNEL: Tensor.copy_ is hipMemcpyAsync)
                 ts.wait_event(ready)
                 e.step_update_planes(t, planes.data_ptr(), vs.data_ptr())
                 exported.record(ts)
                 with torch.cuda.stream(side):                  # (stands in for the all-gather of the values on the side stream)
-                    side.wait_event(exported); planes[:nv].copy_(vs); e.kmat_values(planes.data_ptr(), side.cuda_stream); ready.record(side)
+                    side.wait_event(exported); torch.mul(vs, 1, out=planes[:nv]); e.kmat_values(planes.data_ptr(), side.cuda_stream); ready.record(side)
         go2(T0 + 270, 20); torch.cuda.synchronize()
         t0 = time.perf_counter(); go2(T0 + 290, 200); torch.cuda.synchronize(); dt2 = (time.perf_counter() - t0) / 200
     # the same rank in the IN-ENGINE loop (dibs_engine_run_sharded, no Python between the steps) with a loopback communicator: the
