@@ -406,7 +406,7 @@ def main():
         roof.update(launches=dom_n, share_of_step=dom_ms / total_ms,
                     duration="kernel alone on the GPU (the step is serialised while timing); in the timed region the acyclicity kernel runs on "
                              "its second stream beside the likelihood kernels, see kernel_us_per_step_concurrent / frac_concurrent")
-        for tag in ("round4", "round3", "round2"):   # separate rocprofv3 --pmc passes of this command (scripts/collect_profiles.sh)
+        for tag in ("round5", "round4", "round3", "round2"):   # separate rocprofv3 --pmc passes of this command (scripts/collect_profiles.sh)
             suffix = "" if args.config == "headline" else f"_cfg{args.config}"
             pmc = os.path.join(ROOT, "profiles", f"{tag}{suffix}_pmc_hbm.json")
             if os.path.exists(pmc):

@@ -108,6 +108,7 @@ struct dibs_engine {
   unsigned int* join_flag = nullptr;   // device word: sequence number stored by the second stream's last kernel of a step (k_join_flag)
   unsigned int* join_err = nullptr;    // pinned host word: raised by tail_join_wait when the flag did not arrive (checked after every chunk)
   unsigned int join_seq = 0;
+  bool streams_concurrent = false;     // kernels of the two streams run side by side (probed at creation): the in-kernel join is safe
   bool kmat_early;  // this step's kernel matrices were launched on the second stream (behind the acyclicity kernel)
   bool kmat_ext;    // ... or by dibs_engine_kmat_values on a stream of the caller (overlapped exchange)
   double t_ms[DIBS_K_COUNT];
@@ -264,6 +265,24 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
     HIP_OK(dalloc(&e->join_flag, (size_t)4));
     HIP_OK(hipHostMalloc((void**)&e->join_err, 4, hipHostMallocDefault));
     *e->join_err = 0u;
+    // the in-kernel join needs the two streams to make progress side by side (see k_probe_wait): asked once per process and device
+    static std::mutex mu;
+    static std::map<int, bool> concurrent;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = concurrent.find(c.device_id);
+    if (it == concurrent.end()) {
+      unsigned int* pr = nullptr;
+      HIP_OK(dalloc(&pr, (size_t)2));
+      hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, e->stream, pr, pr + 1);
+      hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, e->stream2, pr);
+      HIP_OK(hipStreamSynchronize(e->stream));
+      HIP_OK(hipStreamSynchronize(e->stream2));
+      unsigned int seen = 0;
+      HIP_OK(hipMemcpy(&seen, pr + 1, 4, hipMemcpyDeviceToHost));
+      hipFree(pr);
+      it = concurrent.emplace(c.device_id, seen != 0u).first;
+    }
+    e->streams_concurrent = it->second;
   }
   const size_t Ml = e->Mloc, dd = (size_t)e->d * e->d;
   HIP_OK(dalloc(&e->z, Ml * e->D));
@@ -784,11 +803,12 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
   // on the main stream and 96 us on its own.
   // (a small acyclicity launch -- <= 512 blocks: config 2, or a rank of a sharded headline run -- stays on the main stream: the fork / join
   //  events cost 6 + 6 us of the critical path, more than such a launch can hide; measured at config 2: 16 100 -> see DESIGN.md)
-  const bool fork = do_prior && do_lik && e->stream2 != nullptr && (long)e->acyc_nblk * e->Mloc > 512, join_now = e->profiling && !e->profiling_concurrent;
+  static const long fork_min = getenv("DIBS_FORK_MIN_BLOCKS") ? atol(getenv("DIBS_FORK_MIN_BLOCKS")) : 512;  // (tuning override)
+  const bool fork = do_prior && do_lik && e->stream2 != nullptr && (long)e->acyc_nblk * e->Mloc > fork_min, join_now = e->profiling && !e->profiling_concurrent;
   static const bool want_flag_join = getenv("DIBS_NO_FLAG_JOIN") == nullptr, no_ext_fork = getenv("DIBS_NO_EXT_FORK") != nullptr;
   // the join inside k_particle_grad (tail_join_wait) instead of an event wait in front of it: measured neutral to slightly slower (the
   // acquire fence of every polling block drops its XCD's L2), kept behind DIBS_FLAG_JOIN=1; per-kernel timing always uses the event
-  const bool flag_join = fork && !join_now && want_flag_join && e->join_flag != nullptr;
+  const bool flag_join = fork && !join_now && want_flag_join && e->join_flag != nullptr && e->streams_concurrent;
   auto launch_edge = [&](hipStream_t st, hipEvent_t stop_ev, bool copy2 = false) {
     KTimer tm(e, DIBS_K_EDGE, st);
     const size_t lds = (size_t)2 * e->dpad * e->ldk * 4;

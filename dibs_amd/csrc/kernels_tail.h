@@ -76,6 +76,16 @@ __device__ __forceinline__ void tail_join_wait(const TailArgs& A) {
 __device__ __forceinline__ float tail_ld_joined(const TailArgs& A, const float* p) {
   return A.join_flag ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
+// Do kernels of two streams really run side by side here?  Counter collection (rocprofv3 --pmc), AMD_SERIALIZE_KERNEL and debuggers run ONE
+// dispatch at a time in submission order: a consumer that polls for a flag of a kernel queued behind it would then spin until its time-out.
+// The engine asks once per process: k_probe_wait on the main stream (spins up to 2 ms), k_probe_set on the second stream behind it.
+__global__ void k_probe_wait(const unsigned int* flag, unsigned int* seen) {
+  const unsigned long long t0 = wall_clock64();
+  unsigned int v = 0;
+  while ((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && wall_clock64() - t0 < 200000ull) __builtin_amdgcn_s_sleep(8);
+  *seen = v;
+}
+__global__ void k_probe_set(unsigned int* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // one thread, last on the second stream
 // (RELAXED: the end of the kernel in front of this one has already released its stores; a release here would write the L2 back once more --
 //  the one-thread kernel took 4.4 us with it)
