@@ -801,9 +801,11 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
   // While per-kernel timing is on (set_profiling(1)) the main stream joins right away, so that every duration is a kernel alone on the
   // GPU -- but the launch still goes to the second stream: with that (high-priority) queue in existence the same kernel takes 104 us
   // on the main stream and 96 us on its own.
-  // (a small acyclicity launch -- <= 512 blocks: config 2, or a rank of a sharded headline run -- stays on the main stream: the fork / join
-  //  events cost 6 + 6 us of the critical path, more than such a launch can hide; measured at config 2: 16 100 -> see DESIGN.md)
-  static const long fork_min = getenv("DIBS_FORK_MIN_BLOCKS") ? atol(getenv("DIBS_FORK_MIN_BLOCKS")) : 512;  // (tuning override)
+  // (Until round 4 a small acyclicity launch -- <= 512 blocks: config 2, or a rank of a sharded headline run -- stayed on the main stream: the
+  //  fork / join events cost 6 + 6 us of the critical path, more than such a launch could hide.  With the fork as the edge kernel's completion
+  //  signal and the join polled inside k_particle_grad the second stream pays at every size: config 2 18 460 -> 20 440 steps/s, a rank of
+  //  a 4- / 8-way headline run 101.0 -> 91.4 / 85.8 -> 78.0 us per step.  DIBS_FORK_MIN_BLOCKS=512 restores the old rule.)
+  static const long fork_min = getenv("DIBS_FORK_MIN_BLOCKS") ? atol(getenv("DIBS_FORK_MIN_BLOCKS")) : 0;  // (tuning override)
   const bool fork = do_prior && do_lik && e->stream2 != nullptr && (long)e->acyc_nblk * e->Mloc > fork_min, join_now = e->profiling && !e->profiling_concurrent;
   static const bool want_flag_join = getenv("DIBS_NO_FLAG_JOIN") == nullptr, no_ext_fork = getenv("DIBS_NO_EXT_FORK") != nullptr;
   // the join inside k_particle_grad (tail_join_wait) instead of an event wait in front of it: measured neutral to slightly slower (the
