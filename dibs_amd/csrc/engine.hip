@@ -82,6 +82,7 @@ struct dibs_engine {
   float* acyc_big;  // n_vars > 112: buffers of the global-memory matrix powers (kernels_acyc_big.h)
   float* eas;       // [Mloc][d][d] exp(-alpha s) of this step (k_edge_scores -> k_acyc_hf / k_acyc_hfw); n_vars <= 112 only
   float *scores, *probs, *w_lik, *acyc_part, *w_acyc, *logprobs_z, *logprobs_th, *pack, *kz, *kt, *phi_z, *phi_th;
+  float* kpart = nullptr;  // tiled kernel matrix (kernels_kmat.h): partial squared distances [nchunk][Mloc][M]; single-rank engines only
   float* ksum = nullptr;  // joint models: kz + kt, formed by the k_kmat launch of kt (the weight matrix of the SVGD transform as ONE scalar-loadable array)
   uint32_t* thr;
   uint64_t* masks;
@@ -173,6 +174,11 @@ static int64_t theta_size(const dibs_config& c) {
   return 0;
 }
 
+// the tiled kernel matrix (k_kmat_tile + k_kmat_finish) from this many particles
+static int kmat_tiled_min() {
+  const char* v = getenv("DIBS_KMAT_TILED_MIN");  // (tuning / test override, read per engine and per step)
+  return v ? atoi(v) : 128;
+}
 template <typename T>
 static hipError_t dalloc(T** p, size_t n) {
   *p = nullptr;
@@ -324,6 +330,13 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   HIP_OK(dalloc(&e->kz, Ml * e->M + kpad));
   if (c.joint) HIP_OK(dalloc(&e->kt, Ml * e->M + kpad));
   if (c.joint) HIP_OK(dalloc(&e->ksum, Ml * e->M + kpad));
+  if (e->Mloc == e->M && e->M >= kmat_tiled_min() && !getenv("DIBS_KMAT_OLD")) {  // (optional: without it the direct kernel k_kmat runs)
+    const size_t n = (size_t)kmat_nchunk((int)(e->D > e->P ? e->D : e->P)) * Ml * e->M;
+    if (n * 4 <= ((size_t)512 << 20) && hipMalloc((void**)&e->kpart, n * 4) != hipSuccess) {
+      e->kpart = nullptr;
+      (void)hipGetLastError();
+    }
+  }
   HIP_OK(dalloc(&e->phi_z, Ml * e->D));
   HIP_OK(dalloc(&e->phi_th, Ml * e->P));
   HIP_OK(dalloc(&e->counters, (size_t)DIBS_N_COUNTERS));
@@ -430,7 +443,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (e->stream2) hipStreamSynchronize(e->stream2);
   void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->eas, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
-                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot, e->join_flag, e->scores2, e->eas2, e->ksum};
+                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot, e->join_flag, e->scores2, e->eas2, e->ksum, e->kpart};
   for (void* p : ptrs)
     if (p) hipFree(p);
   joint_free(&e->jw);
@@ -808,9 +821,16 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
   static const long fork_min = getenv("DIBS_FORK_MIN_BLOCKS") ? atol(getenv("DIBS_FORK_MIN_BLOCKS")) : 0;  // (tuning override)
   const bool fork = do_prior && do_lik && e->stream2 != nullptr && (long)e->acyc_nblk * e->Mloc > fork_min, join_now = e->profiling && !e->profiling_concurrent;
   static const bool want_flag_join = getenv("DIBS_NO_FLAG_JOIN") == nullptr, no_ext_fork = getenv("DIBS_NO_EXT_FORK") != nullptr;
-  // the join inside k_particle_grad (tail_join_wait) instead of an event wait in front of it: measured neutral to slightly slower (the
-  // acquire fence of every polling block drops its XCD's L2), kept behind DIBS_FLAG_JOIN=1; per-kernel timing always uses the event
-  const bool flag_join = fork && !join_now && want_flag_join && e->join_flag != nullptr && e->streams_concurrent;
+  // the join inside k_particle_grad (tail_join_wait, agent-scope loads of a flag word the second stream's last kernel stores) instead of an
+  // event wait in front of it: -7 us per step.  The polling blocks hold their CUs while the second stream still has kernels to place, so
+  // the flag is used only while they cannot fill the machine (<= 128 particles: one block each on half of the CUs) and the two streams
+  // were seen to run concurrently (streams_concurrent; not under a serialising profiler); otherwise the event.  The wait is bounded
+  // (join_err).  Per-kernel timing always uses the event.
+  const bool flag_join = fork && !join_now && want_flag_join && e->join_flag != nullptr && e->streams_concurrent && e->Mloc <= 128;
+  // where this step's kernel matrices come from (single rank): the joint models and many particles put them on the second stream behind the
+  // acyclicity chain (kmat_on_s2, see below); otherwise the latent matrix rides inside k_bge_sample
+  const bool kmat_on_s2 = c.joint || (long)e->M * e->D > 4L * e->S * e->d * e->d;
+  const bool kmat_early_now = fork && !xk && kmat_on_s2 && e->Mloc == e->M && !e->kmat_ext && !getenv("DIBS_NO_KMAT_EARLY");
   auto launch_edge = [&](hipStream_t st, hipEvent_t stop_ev, bool copy2 = false) {
     KTimer tm(e, DIBS_K_EDGE, st);
     const size_t lds = (size_t)2 * e->dpad * e->ldk * 4;
@@ -820,11 +840,11 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
         hipLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, e->z, e->scores2, (uint32_t*)nullptr, (float*)nullptr, e->eas2, alpha,
                            e->d, e->k, e->dpad, e->ldk);
       else if (stop_ev)
-        hipExtLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, nullptr, stop_ev, 0, e->z, e->scores, e->thr, e->probs, e->eas,
-                              alpha, e->d, e->k, e->dpad, e->ldk);
+        hipExtLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, nullptr, stop_ev, 0, e->z, e->scores, e->thr, e->probs,
+                              e->eas, alpha, e->d, e->k, e->dpad, e->ldk);
       else
-        hipLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, e->z, e->scores, e->thr, e->probs, e->eas, alpha, e->d, e->k,
-                           e->dpad, e->ldk);
+        hipLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, e->z, e->scores, e->thr, e->probs, e->eas, alpha, e->d,
+                           e->k, e->dpad, e->ldk);
       return;
     }
 
@@ -876,8 +896,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
   // Measured: config 3 (joint, 128 particles) 1 400 -> 1 453 steps/s, config 4 (1 024 particles) 329 -> 395.  At the headline size the
   // latent matrix stays inside the k_bge_sample launch (KmatFuse: 8 us of that kernel's 70; on the second stream 3 999 -> 3 902 steps/s,
   // and ahead of the acyclicity kernel it delays that kernel).
-  const bool kmat_on_s2 = c.joint || (long)e->M * e->D > 4L * e->S * e->d * e->d;
-  if (fork && !xk && kmat_on_s2 && e->Mloc == e->M && !e->kmat_ext && !getenv("DIBS_NO_KMAT_EARLY")) {
+  if (kmat_early_now) {
     if (join_now) {  // per-kernel timing: one kernel at a time
       hipEventRecord(e->ev_k1, e->stream2);
       hipStreamWaitEvent(e->stream, e->ev_k1, 0);
@@ -885,14 +904,30 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
       hipStreamWaitEvent(e->stream2, e->ev_k0, 0);
     }
     KTimer tm(e, DIBS_K_KMAT, e->stream2);
-    auto kmat_lds = [](size_t len) { return (size_t)(((len < KMAT_CH ? len : (size_t)KMAT_CH) + 3) & ~(size_t)3) * 4; };
-    allow_lds(k_kmat, kmat_lds(e->D > e->P ? e->D : e->P));
-    const dim3 kg(e->Mloc, (e->M + KMAT_BT - 1) / KMAT_BT);
-    hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->D), e->stream2, e->z, (size_t)e->D, (size_t)0, (int)e->D, e->kz, 0, e->M,
-                       (float)c.scale_latent, (float)c.h_latent, 1, (const float*)nullptr, (float*)nullptr);
-    if (c.joint)
-      hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->P), e->stream2, e->theta, (size_t)e->P, (size_t)0, (int)e->P, e->kt, 0, e->M,
-                         (float)c.scale_theta, (float)c.h_theta, 1, (const float*)e->kz, e->ksum);
+    // tiled (kernels_kmat.h: partial sums per 32 x 32 tile and chunk, then one finishing block per row) from 128 particles: config 4 597 ->
+    // 645 steps/s, config 5 108.5 -> 115, config 3 2290 -> 2328 on the same box (each row is read once per tile instead of once per pair)
+    if (e->kpart && e->M >= kmat_tiled_min()) {
+      const int nta = (e->M + KT_T - 1) / KT_T;
+      allow_lds(k_kmat_tile, kmat_tile_lds_bytes());
+      auto tiled = [&](const float* x, size_t len, float* kout, float scale, float h, const float* kadd, float* ksum) {
+        const KmatTile kt{x, len, 0, (int)len, e->kpart, 0, e->Mloc, e->M, kmat_nchunk((int)len), nta, nta, 1};
+        // (persistent blocks, one per CU by their registers, looping over the units with the next unit's rows prefetched)
+        const int units = kmat_tile_count(nta, nta, 1) * kt.nchunk;
+        hipLaunchKernelGGL(k_kmat_tile, dim3((unsigned)(units < 256 ? units : 256)), dim3(KT_NT), kmat_tile_lds_bytes(), e->stream2, kt);
+        hipLaunchKernelGGL(k_kmat_finish, dim3(e->Mloc), dim3(256), 0, e->stream2, e->kpart, kt.nchunk, e->Mloc, e->M, 1, scale, h, kout, kadd, ksum);
+      };
+      tiled(e->z, (size_t)e->D, e->kz, (float)c.scale_latent, (float)c.h_latent, nullptr, nullptr);
+      if (c.joint) tiled(e->theta, (size_t)e->P, e->kt, (float)c.scale_theta, (float)c.h_theta, e->kz, e->ksum);
+    } else {
+      auto kmat_lds = [](size_t len) { return (size_t)(((len < KMAT_CH ? len : (size_t)KMAT_CH) + 3) & ~(size_t)3) * 4; };
+      allow_lds(k_kmat, kmat_lds(e->D > e->P ? e->D : e->P));
+      const dim3 kg(e->Mloc, (e->M + KMAT_BT - 1) / KMAT_BT);
+      hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->D), e->stream2, e->z, (size_t)e->D, (size_t)0, (int)e->D, e->kz, 0, e->M,
+                         (float)c.scale_latent, (float)c.h_latent, 1, (const float*)nullptr, (float*)nullptr);
+      if (c.joint)
+        hipLaunchKernelGGL(k_kmat, kg, dim3(256), kmat_lds(e->P), e->stream2, e->theta, (size_t)e->P, (size_t)0, (int)e->P, e->kt, 0, e->M,
+                           (float)c.scale_theta, (float)c.h_theta, 1, (const float*)e->kz, e->ksum);
+    }
     e->kmat_early = true;
   }
   if (fork) {

@@ -15,6 +15,189 @@ struct KmatFuse {
 };
 
 // ------------------------------------------------------------------------------------------------
+// K8a' (round 5)  the same matrix, TILED: a block takes a 32 x 32 tile of (a, b) pairs and one chunk of KT_CH elements, stages the 32 + 32
+//     row pieces in LDS (each row read once per tile instead of once per pair: 1/8 of the L2 traffic of kmat_block, which is what bounded it --
+//     164 MB per launch at 128 particles) and every thread of the first four waves accumulates a 2 x 2 block of squared distances on packed
+//     FMAs (direct differences as before).  The per-chunk partial sums part[chunk][a][b] (floats, all terms >= 0) are added in double, in chunk
+//     order, by kmat_finish_row, which also applies exp(-./h), mirrors the upper triangle (symmetric = one rank holds all particles: only
+//     tiles tb >= ta are computed, k[a][b] and k[b][a] come from the same sums) and forms kz + kt for the joint models.
+//     Splitting the element range over blocks is what makes the kernel short enough (~5 us at 128 particles, 200 blocks) to ride in the
+//     k_edge_scores_p launch, i.e. on an otherwise idle machine, instead of inside the VALU-bound k_bge_sample.
+//     reference: kernel.py:20-30 / 52-71, svgd.py:165-176 / 537-551
+// ------------------------------------------------------------------------------------------------
+#define KT_CH 256
+#define KT_T 32
+#define KT_LD (KT_CH + 4)  // row stride (floats): 16-byte aligned, rows 4 banks apart (conflict-free 16-byte reads of 8 different rows)
+struct KmatTile {
+  const float* x;        // rows [M][stride], the segment starts at `off`
+  size_t stride, off;
+  int len;
+  float* part;           // [nchunk][Mloc][M]
+  int m0, Mloc, M, nchunk, nta, ntb, symmetric;
+};
+__host__ __device__ inline size_t kmat_tile_lds_bytes() { return (size_t)2 * KT_T * KT_LD * 4; }  // (>= 16 x 1024 floats of partial sums)
+__host__ __device__ inline int kmat_tile_count(int nta, int ntb, int symmetric) { return symmetric ? nta * (nta + 1) / 2 : nta * ntb; }
+__host__ __device__ inline int kmat_nchunk(int len) { return (len + KT_CH - 1) / KT_CH; }
+
+// (tile, chunk) units by a block of KT_NT = 1024 threads.  Staging: 64 row pieces as float4 (16-byte aligned rows) or scalars, 16 floats per
+// thread, fetched for the NEXT unit of the block while the current one is computed.  Wave w takes the elements 16 w .. 16 w + 15 of the chunk;
+// lane (ag, bg) = (lane / 8, lane % 8) the 4 x 4 pairs (ag + 8 i, bg + 8 j): 8 LDS reads of 16 bytes feed 64 packed instructions (rows 1
+// apart are 4 banks apart: conflict-free), so a unit is VALU-bound, not LDS-bound.  The 16 waves' partial sums meet in LDS and are added in
+// double.
+#define KT_NT 1024
+#define KT_RV (2 * KT_T * KT_CH / KT_NT)  // staged floats per thread
+struct KtUnit {
+  int a0, b0, c0, clen, chunk;
+};
+__device__ __forceinline__ KtUnit kt_unit(const KmatTile& K, int unit) {
+  const int tile = unit / K.nchunk, chunk = unit - tile * K.nchunk;
+  int ta, tb;
+  if (K.symmetric) {
+    ta = 0;
+    int t = tile;
+    while (t >= K.nta - ta) { t -= K.nta - ta; ++ta; }
+    tb = ta + t;
+  } else {
+    ta = tile / K.ntb;
+    tb = tile - ta * K.ntb;
+  }
+  const int c0 = chunk * KT_CH;
+  return KtUnit{ta * KT_T, tb * KT_T, c0, K.len - c0 < KT_CH ? K.len - c0 : KT_CH, chunk};
+}
+template <bool VEC>
+__device__ __forceinline__ void kt_fetch(const KmatTile& K, const KtUnit& U, int tid, float (&v)[KT_RV]) {
+  auto grow = [&](int row) {
+    return row < KT_T ? K.m0 + (U.a0 + row < K.Mloc ? U.a0 + row : K.Mloc - 1) : (U.b0 + row - KT_T < K.M ? U.b0 + row - KT_T : K.M - 1);
+  };
+  if (VEC) {
+    // (vec: 16-byte aligned rows, segment length a multiple of 4 -- a float4 is all inside or all outside -- and the rows within 4 GiB:
+    //  uniform base + 32-bit byte offsets (the SGPR-base form of global_load; this hipcc lowers the b64 / b128 buffer-load builtins to a
+    //  single dword).  Clamped offset here + select at staging time keep the batch free of branches and waits, i.e. in flight together)
+    const char* base = reinterpret_cast<const char*>(K.x + K.off + (size_t)U.c0);
+#pragma unroll
+    for (int u = 0; u < KT_RV / 4; ++u) {
+      const int i = u * KT_NT + tid, row = i / (KT_CH / 4), e = (i - row * (KT_CH / 4)) * 4;
+      const uint32_t bo = ((uint32_t)grow(row) * (uint32_t)K.stride + (uint32_t)(e < U.clen ? e : 0)) * 4u;
+      const float4 t = *reinterpret_cast<const float4*>(base + bo);
+      v[4 * u] = t.x, v[4 * u + 1] = t.y, v[4 * u + 2] = t.z, v[4 * u + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < KT_RV; ++u) {
+      const int i = u * KT_NT + tid, row = i / KT_CH, e = i - row * KT_CH;
+      const float* src = K.x + (size_t)grow(row) * K.stride + K.off + U.c0;
+      v[u] = src[e < U.clen ? e : 0];
+    }
+  }
+}
+template <bool VEC>
+__device__ __forceinline__ void kt_stage(float* __restrict__ smem, int clen, int tid, const float (&v)[KT_RV]) {
+  if (VEC) {
+#pragma unroll
+    for (int u = 0; u < KT_RV / 4; ++u) {
+      const int i = u * KT_NT + tid, row = i / (KT_CH / 4), e = (i - row * (KT_CH / 4)) * 4;
+      const bool in = e < clen;
+      *reinterpret_cast<float4*>(smem + row * KT_LD + e) =
+          make_float4(in ? v[4 * u] : 0.f, in ? v[4 * u + 1] : 0.f, in ? v[4 * u + 2] : 0.f, in ? v[4 * u + 3] : 0.f);
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < KT_RV; ++u) {
+      const int i = u * KT_NT + tid, row = i / KT_CH, e = i - row * KT_CH;
+      smem[row * KT_LD + e] = e < clen ? v[u] : 0.f;
+    }
+  }
+}
+// units first, first + step, ... of nta (x ntb) tiles x nchunk chunks
+template <bool VEC>
+__device__ __forceinline__ void kmat_tile_loop(float* __restrict__ smem, const KmatTile& K, int first, int step, int units, int tid) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int lane = tid & 63, wave = tid >> 6, ag = lane >> 3, bg = lane & 7;
+  const float4* pa = reinterpret_cast<const float4*>(smem + ag * KT_LD) + wave * (KT_CH / 4 / 16);
+  const float4* pb = reinterpret_cast<const float4*>(smem + (KT_T + bg) * KT_LD) + wave * (KT_CH / 4 / 16);
+  float v[KT_RV];
+  KtUnit U = kt_unit(K, first);
+  kt_fetch<VEC>(K, U, tid, v);
+  for (int u = first; u < units; u += step) {
+    kt_stage<VEC>(smem, U.clen, tid, v);
+    __syncthreads();
+    const KtUnit Ucur = U;
+    if (u + step < units) {  // (block-uniform) the next unit's rows are in flight during this one's arithmetic
+      U = kt_unit(K, u + step);
+      kt_fetch<VEC>(K, U, tid, v);
+    }
+    f32x2 acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < KT_CH / 4 / 16; ++it) {
+      float4 x[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[i] = pa[i * 8 * (KT_LD / 4) + it];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 y = pb[j * 8 * (KT_LD / 4) + it];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x2 t = f32x2{x[i].x, x[i].y} - f32x2{y.x, y.y};
+          acc[i * 4 + j] = __builtin_elementwise_fma(t, t, acc[i * 4 + j]);
+          t = f32x2{x[i].z, x[i].w} - f32x2{y.z, y.w};
+          acc[i * 4 + j] = __builtin_elementwise_fma(t, t, acc[i * 4 + j]);
+        }
+      }
+    }
+    __syncthreads();  // (the staged rows are dead: their space takes the 16 x 1024 partial sums)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) smem[wave * 1024 + q * 64 + lane] = acc[q].x + acc[q].y;
+    __syncthreads();
+    {
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) tot += (double)smem[w * 1024 + tid];
+      const int q = tid >> 6, a = Ucur.a0 + ag + 8 * (q >> 2), b = Ucur.b0 + bg + 8 * (q & 3);
+      if (a < K.Mloc && b < K.M) K.part[((size_t)Ucur.chunk * K.Mloc + a) * K.M + b] = (float)tot;
+    }
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ void kmat_tile_block(float* __restrict__ smem, const KmatTile& K, int first, int step, int tid) {
+  const int units = kmat_tile_count(K.nta, K.ntb, K.symmetric) * K.nchunk;
+  if (first >= units) return;
+  // (two copies of the loop: merged, the compiler shares the tails of the two fetch batches and waits on every load)
+  const bool vec = (((K.stride | K.off | (size_t)K.len) & 3) == 0) && ((reinterpret_cast<uintptr_t>(K.x) & 15) == 0) &&
+                   ((size_t)(K.m0 + K.Mloc > K.M ? K.m0 + K.Mloc : K.M) * K.stride + K.off + (size_t)K.len) * 4 < ((size_t)1 << 32);
+  if (vec)
+    kmat_tile_loop<true>(smem, K, first, step, units, tid);
+  else
+    kmat_tile_loop<false>(smem, K, first, step, units, tid);
+}
+
+// row a of the matrix from the partial sums: threads tid, tid + nthr, ... take the columns b
+__device__ __forceinline__ void kmat_finish_row(const float* __restrict__ part, int nchunk, int Mloc, int M, int symmetric, float scale, float h,
+                                                float* __restrict__ kout, const float* __restrict__ kadd, float* __restrict__ ksum, int a, int tid,
+                                                int nthr) {
+  for (int b = tid; b < M; b += nthr) {
+    // (symmetric: only tiles tb >= ta exist; below them the transposed entry is the same sum)
+    const bool up = !symmetric || (b / KT_T) >= (a / KT_T);
+    const float* p = part + (up ? (size_t)a * M + b : (size_t)b * M + a);
+    const size_t cs = (size_t)Mloc * M;
+    double tot = 0.0;
+    int c = 0;
+    for (; c + 8 <= nchunk; c += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(c + u) * cs];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) tot += (double)v[u];
+    }
+    for (; c < nchunk; ++c) tot += (double)p[(size_t)c * cs];
+    const float kv = (float)((double)scale * exp(-tot / (double)h));
+    kout[(size_t)a * M + b] = kv;
+    if (ksum) ksum[(size_t)a * M + b] = kadd[(size_t)a * M + b] + kv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K8a kernel matrix slab: kz[a, b] = scale * exp(-||z_a - z_b||^2 / h) for local a, all b (direct differences:
 //     the entries are ~e^-40 at d = 50 and must not be flushed or computed by cancellation).
 //     reference: kernel.py:20-30 / 52-71, svgd.py:165-176 / 537-551

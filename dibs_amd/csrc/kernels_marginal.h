@@ -192,6 +192,17 @@ __global__ __launch_bounds__(1024) void k_edge_scores_p(const float* __restrict_
   }
 }
 
+// the tiled kernel matrix as launches of its own (second stream of the joint / many-particle configurations): grid <= tiles * chunks, block = 1024;
+// dynamic LDS = kmat_tile_lds_bytes().  k_kmat_finish: grid = Mloc, block = 256
+__global__ __launch_bounds__(KT_NT) void k_kmat_tile(KmatTile kt) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  kmat_tile_block(smem, kt, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x);
+}
+__global__ __launch_bounds__(256) void k_kmat_finish(const float* __restrict__ part, int nchunk, int Mloc, int M, int symmetric, float scale, float h,
+                                                     float* __restrict__ kout, const float* __restrict__ kadd, float* __restrict__ ksum) {
+  kmat_finish_row(part, nchunk, Mloc, M, symmetric, scale, h, kout, kadd, ksum, (int)blockIdx.x, (int)threadIdx.x, 256);
+}
+
 __global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, size_t pack_stride, size_t seg_off, int len,
                                               float* __restrict__ kout, int m0, int M, float scale, float h, int symmetric,
                                               const float* __restrict__ kadd, float* __restrict__ ksum) {

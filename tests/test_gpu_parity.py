@@ -375,6 +375,23 @@ def test_sample_api_contract():
     (112, 2, 16, 4, "score", "sf", False, (1,)),      # engine maximum
 ])
 def test_joint_lingauss_step_stages(c_oracle64, d, M, S, Sa, est, prior, interv, steps):
+    _lingauss_step_stages(c_oracle64, d, M, S, Sa, est, prior, interv, steps)
+
+
+@pytest.mark.parametrize("d,M,S,Sa,est,prior,interv,steps", [
+    (5, 3, 16, 4, "reparam", "er", False, (1, 2)),    # D = 50, P = 25: scalar staging, one ragged chunk, one ragged tile
+    (6, 260, 8, 4, "reparam", "er", False, (1, 2)),   # 9 x 9 tiles (the last ragged), D = 72: float4 staging
+    (20, 70, 16, 4, "score", "sf", True, (1,)),       # D = 800: four chunks, the last short; 3 x 3 tiles
+    (33, 3, 32, 8, "score", "sf", True, (1,)),        # D = 2178, P = 1089: scalar staging over several chunks
+    (50, 4, 128, 32, "reparam", "er", False, (2,)),   # D = 5000 (headline vector length), P = 2500
+])
+def test_joint_lingauss_tiled_kernel_matrix(c_oracle64, monkeypatch, d, M, S, Sa, est, prior, interv, steps):
+    """The tiled kernel matrix (k_kmat_tile + k_kmat_finish, default from 256 particles) forced at every size: same stages, same bounds."""
+    monkeypatch.setenv("DIBS_KMAT_TILED_MIN", "1")
+    _lingauss_step_stages(c_oracle64, d, M, S, Sa, est, prior, interv, steps)
+
+
+def _lingauss_step_stages(c_oracle64, d, M, S, Sa, est, prior, interv, steps):
     data, _, _ = make_data(d, seed=2, joint=True)
     mask = None
     if interv:
