@@ -29,12 +29,13 @@ static void launch_nt(const AcycLaunch& a) {
 // (d <= 32 stays on k_acyc<NT>: measured at config 2 (d = 20, 32 particles) the 64-padded k_acyc_hf takes 17.4 us against 14.3 us for
 //  k_acyc<2> -- its element-order draws do not make up for products that are 3 x 3 instead of 2 x 2 tiles; DIBS_ACYC_SMALL_HF=1 selects it)
 static bool acyc_use_bf16(const AcycLaunch& a) {
-  static const bool off = getenv("DIBS_ACYC_F32") != nullptr, small_hf = getenv("DIBS_ACYC_SMALL_HF") != nullptr;
+  static const bool small_hf = getenv("DIBS_ACYC_SMALL_HF") != nullptr;
+  const bool off = getenv("DIBS_ACYC_F32") != nullptr;  // (read per launch: the tests compare the two pipes in one process)
   return !off && a.units != a.Sa && a.d >= (small_hf ? 4 : 33) && a.d <= 64;
 }
 // 65 <= d <= 112 with paired chains: the same scheme with NT = 5 .. 7 tiles and waves (k_acyc_bfw)
 static bool acyc_use_bfw(const AcycLaunch& a) {
-  static const bool off = getenv("DIBS_ACYC_F32") != nullptr;
+  const bool off = getenv("DIBS_ACYC_F32") != nullptr;
   return !off && a.units != a.Sa && a.d > 64 && a.d <= 112;
 }
 // two-piece f16 operands for 65 <= d <= 112 (k_acyc_hfw, kernels_acyc_f16.h); DIBS_ACYC_BF16=1 keeps k_acyc_bfw (A/B runs)
@@ -135,9 +136,10 @@ void acyc_launch_power(const AcycLaunch& a) {
     return;
   }
   if (acyc_use_bfw(a)) {
-    // The two-piece f16 scheme carries a truncation bias of ~1e-7 per product level inside the MFMA's 32-term dot product (three-piece bf16:
-    // ~0.5e-7; measured, scripts/probe/acyc_hf_probe.hip), i.e. ~(d - 1) 1e-7 on M^(d-1): within the 1e-5 of the W_ACYC tests up to d = 80,
-    // beyond it at d = 96 (1.0e-5) -- the wider sizes stay on the three-piece kernel.
+    // The two-piece f16 scheme carries a truncation bias inside the MFMA's dot products (measured against the f32-MFMA kernel,
+    // test_acyclicity_f16_pipe_worst_cases): k_acyc_hf (K = 64) -9e-7 on M^(d-1) at d = 64; k_acyc_hfw (K = 96 / 128) ~-1.15e-7 per
+    // product level, i.e. -(d - 1) 1.15e-7 = -1.0e-5 at d = 80, which the kernel compensates to first order (residual 4e-6).  The
+    // wider sizes stay on the three-piece bf16 kernel.
     static const bool bf16w = getenv("DIBS_ACYC_BF16") != nullptr;
     if (!bf16w && a.d <= 80) {
       switch ((a.d + 15) / 16) {

@@ -218,6 +218,46 @@ def test_acyclicity_kernel_sizes_65_to_112(c_oracle64, d, Sa):
     eng.close()
 
 
+@pytest.mark.parametrize("d,Sa,t", [(64, 4, 20000), (64, 2, 200000), (50, 4, 20000), (80, 2, 20000), (80, 4, 400), (72, 2, 100000)])
+def test_acyclicity_f16_pipe_worst_cases(c_oracle64, monkeypatch, d, Sa, t):
+    """The two-piece f16 operands of k_acyc_hf / k_acyc_hfw (22 mantissa bits, truncation bias ~1e-7 per product level)
+    where the bias is largest: the longest product chains of each kernel (d = 64: 63 = 111111b, a multiply after every squaring; d = 80,
+    the last size on the f16 pipe) and hard soft graphs (alpha = 0.05 t = 1000 .. 10000: entries of the matrix either ~1/d or ~0, the
+    few edges near 1/2 carry the whole gradient).
+    Two comparisons.  (1) f16 pipe against the f32-MFMA kernel (DIBS_ACYC_F32=1) on the same inputs: the pipe's own contribution, bounded
+    by 1e-7 (d - 1) (measured 1.2e-6 at d = 64; 4.1e-6 at d = 80 with k_acyc_hfw's first-order bias compensation, 1.3e-5 without).  (2) both against the float64 oracle: at alpha >= 1000 ANY float32 evaluation of sigmoid(alpha (s + l)) --
+    the reference's included -- carries alpha 2^-24 relative error per edge (measured: the f32 kernel 2.0e-4 at d = 50, alpha = 1000,
+    the f16 pipe the same 2.0e-4), so the bound scales with alpha there.  reference: graph_utils.py:8-28, dibs.py:557-601"""
+    M, S = 2, 2
+    data, _, _ = make_data(d, seed=2, n_obs=2 * d)
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=2 * d, n_grad_mc_samples=S, n_acyclicity_mc_samples=Sa)
+    st = c_oracle64.new_state(cfg, prng.PRNGKey(7))
+    dbg = None
+    out = {}
+    for pipe in ("f16", "f32"):
+        if pipe == "f32":
+            monkeypatch.setenv("DIBS_ACYC_F32", "1")
+        eng = _engine(cfg, data.x)
+        _sync_states(eng, st)
+        if dbg is None:
+            snap = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in st.items()}
+            dbg = c_oracle64.step(cfg, data.x, None, st, t, debug=True)
+            st = snap
+        eng.run(t, 1)
+        out[pipe] = eng.read("W_ACYC").copy()
+        eng.close()
+    ref = np.asarray(dbg["w_acyc"])
+    assert np.abs(ref).max() > 0, "vacuous: every edge saturated"
+    alpha = 0.05 * t
+    e16, e32, pipe_err = rel_err(out["f16"], ref), rel_err(out["f32"], ref), rel_err(out["f16"], out["f32"])
+    print(f"d={d} Sa={Sa} alpha={alpha:g}: vs oracle f16 {e16:.2e} f32 {e32:.2e}; f16 vs f32 {pipe_err:.2e}; nonzero share {np.mean(ref != 0):.3f}")
+    big = np.abs(out["f32"]) > 1e-3 * np.abs(out["f32"]).max()
+    r = out["f16"][big].astype(np.float64) / out["f32"][big].astype(np.float64) - 1.0
+    print(f"   ratio-1 over {big.sum()} entries: mean {r.mean():.3e} std {r.std():.3e} min {r.min():.3e} max {r.max():.3e}")
+    assert pipe_err < 1e-7 * (d - 1)
+    assert e16 < max(1e-5, 4 * alpha * 2.0 ** -24) and e32 < max(1e-5, 4 * alpha * 2.0 ** -24)
+
+
 @pytest.mark.parametrize("d,Sa", [(20, 4), (40, 4), (50, 4), (50, 3), (70, 2)])
 def test_acyclicity_gradient_of_saturated_soft_graphs_is_zero(c_oracle64, d, Sa):
     """Once alpha * score leaves the range where float32 resolves sigmoid from 0 / 1 (every edge after the first few hundred steps of a
