@@ -82,7 +82,8 @@ struct dibs_engine {
   float* acyc_big;  // n_vars > 112: buffers of the global-memory matrix powers (kernels_acyc_big.h)
   float* eas;       // [Mloc][d][d] exp(-alpha s) of this step (k_edge_scores -> k_acyc_hf / k_acyc_hfw); n_vars <= 112 only
   float *scores, *probs, *w_lik, *acyc_part, *w_acyc, *logprobs_z, *logprobs_th, *pack, *kz, *kt, *phi_z, *phi_th;
-  float* kpart = nullptr;  // tiled kernel matrix (kernels_kmat.h): partial squared distances [nchunk][Mloc][M]; single-rank engines only
+  float* kpart = nullptr;  // tiled kernel matrix (kernels_kmat.h): partial squared distances [nsplit][Mloc][M]; single-rank engines only
+  int kmat_ns_max = 0;     // 0: the direct kernel k_kmat; otherwise the largest nsplit kpart has room for
   float* ksum = nullptr;  // joint models: kz + kt, formed by the k_kmat launch of kt (the weight matrix of the SVGD transform as ONE scalar-loadable array)
   uint32_t* thr;
   uint64_t* masks;
@@ -331,11 +332,16 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   if (c.joint) HIP_OK(dalloc(&e->kt, Ml * e->M + kpad));
   if (c.joint) HIP_OK(dalloc(&e->ksum, Ml * e->M + kpad));
   if (e->Mloc == e->M && e->M >= kmat_tiled_min() && !getenv("DIBS_KMAT_OLD")) {  // (optional: without it the direct kernel k_kmat runs)
-    const size_t n = (size_t)kmat_nchunk((int)(e->D > e->P ? e->D : e->P)) * Ml * e->M;
-    if (n * 4 <= ((size_t)512 << 20) && hipMalloc((void**)&e->kpart, n * 4) != hipSuccess) {
+    // room for up to 32 pieces per pair, less for many particles (<= 512 MiB); 1 = no buffer, every unit holds whole distances
+    size_t ns = ((size_t)512 << 20) / (Ml * e->M * 4);
+    ns = ns > 32 ? 32 : (ns < 1 ? 1 : ns);
+    if (!kmat_tile_addressable((size_t)e->M, e->D > e->P ? e->D : e->P, 0, 0)) ns = 0;  // (32-bit row offsets in the tile kernel)
+    if (ns > 1 && hipMalloc((void**)&e->kpart, ns * Ml * e->M * 4) != hipSuccess) {
       e->kpart = nullptr;
       (void)hipGetLastError();
+      ns = 1;
     }
+    e->kmat_ns_max = (int)ns;
   }
   HIP_OK(dalloc(&e->phi_z, Ml * e->D));
   HIP_OK(dalloc(&e->phi_th, Ml * e->P));
@@ -906,15 +912,17 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
     KTimer tm(e, DIBS_K_KMAT, e->stream2);
     // tiled (kernels_kmat.h: partial sums per 32 x 32 tile and chunk, then one finishing block per row) from 128 particles: config 4 597 ->
     // 645 steps/s, config 5 108.5 -> 115, config 3 2290 -> 2328 on the same box (each row is read once per tile instead of once per pair)
-    if (e->kpart && e->M >= kmat_tiled_min()) {
-      const int nta = (e->M + KT_T - 1) / KT_T;
+    if (e->kmat_ns_max > 0 && e->M >= kmat_tiled_min()) {
+      const int nta = (e->M + KT_T - 1) / KT_T, tiles = kmat_tile_count(nta, nta, 1);
       allow_lds(k_kmat_tile, kmat_tile_lds_bytes());
       auto tiled = [&](const float* x, size_t len, float* kout, float scale, float h, const float* kadd, float* ksum) {
-        const KmatTile kt{x, len, 0, (int)len, e->kpart, 0, e->Mloc, e->M, kmat_nchunk((int)len), nta, nta, 1};
-        // (persistent blocks, one per CU by their registers, looping over the units with the next unit's rows prefetched)
-        const int units = kmat_tile_count(nta, nta, 1) * kt.nchunk;
+        const int nchunk = kmat_nchunk((int)len), ns = kmat_pick_nsplit(tiles, nchunk, e->kmat_ns_max), cps = (nchunk + ns - 1) / ns;
+        const KmatTile kt{x, len, 0, (int)len, e->kpart, 0, e->Mloc, e->M, nchunk, nta, nta, 1, ns, cps, scale, h, kout, kadd, ksum};
+        // (persistent blocks, one per CU by their registers, looping over the units with the next step's rows prefetched)
+        const int units = tiles * ns;
         hipLaunchKernelGGL(k_kmat_tile, dim3((unsigned)(units < 256 ? units : 256)), dim3(KT_NT), kmat_tile_lds_bytes(), e->stream2, kt);
-        hipLaunchKernelGGL(k_kmat_finish, dim3(e->Mloc), dim3(256), 0, e->stream2, e->kpart, kt.nchunk, e->Mloc, e->M, 1, scale, h, kout, kadd, ksum);
+        if (ns > 1)
+          hipLaunchKernelGGL(k_kmat_finish, dim3(e->Mloc), dim3(256), 0, e->stream2, e->kpart, ns, e->Mloc, e->M, 1, scale, h, kout, kadd, ksum);
       };
       tiled(e->z, (size_t)e->D, e->kz, (float)c.scale_latent, (float)c.h_latent, nullptr, nullptr);
       if (c.joint) tiled(e->theta, (size_t)e->P, e->kt, (float)c.scale_theta, (float)c.h_theta, e->kz, e->ksum);

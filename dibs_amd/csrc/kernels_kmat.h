@@ -15,26 +15,51 @@ struct KmatFuse {
 };
 
 // ------------------------------------------------------------------------------------------------
-// K8a' (round 5)  the same matrix, TILED: a block takes a 32 x 32 tile of (a, b) pairs and one chunk of KT_CH elements, stages the 32 + 32
-//     row pieces in LDS (each row read once per tile instead of once per pair: 1/8 of the L2 traffic of kmat_block, which is what bounded it --
-//     164 MB per launch at 128 particles) and every thread of the first four waves accumulates a 2 x 2 block of squared distances on packed
-//     FMAs (direct differences as before).  The per-chunk partial sums part[chunk][a][b] (floats, all terms >= 0) are added in double, in chunk
-//     order, by kmat_finish_row, which also applies exp(-./h), mirrors the upper triangle (symmetric = one rank holds all particles: only
-//     tiles tb >= ta are computed, k[a][b] and k[b][a] come from the same sums) and forms kz + kt for the joint models.
-//     Splitting the element range over blocks is what makes the kernel short enough (~5 us at 128 particles, 200 blocks) to ride in the
-//     k_edge_scores_p launch, i.e. on an otherwise idle machine, instead of inside the VALU-bound k_bge_sample.
+// K8a' (round 5)  the same matrix, TILED: a block takes a 32 x 32 tile of (a, b) pairs and a range of KT_CH-element chunks, stages the
+//     32 + 32 row pieces of a chunk in LDS (each row read once per tile instead of once per pair: 1/8 of the L2 traffic of kmat_block, which
+//     is what bounded it -- 164 MB per launch at 128 particles) and every thread accumulates a 4 x 4 block of squared distances on packed
+//     FMAs (direct differences as before).  Per chunk the 16 waves' partial sums (floats, all terms >= 0) meet in LDS and are added in
+//     double into the thread that owns the pair; with the whole chunk range in one unit (many tiles) that thread applies exp(-./h), mirrors
+//     the upper triangle (symmetric = one rank holds all particles: only tiles tb >= ta are computed) and forms kz + kt for the joint
+//     models; with few tiles the range is cut into nsplit pieces (kmat_pick_nsplit) whose sums k_kmat_finish adds.
+//     Bound: the per-CU fetch rate (64 KB per chunk at ~11 B/clk/CU when every CU fetches) -- 3.5 us per chunk against 1.7 us of VALU work.
+//     Measured: config 4 (1 024 particles) k_kmat 330 -> 227 us, 597 -> 664 steps/s; config 5 108.5 -> 115; config 3 2 290 -> 2 330.
 //     reference: kernel.py:20-30 / 52-71, svgd.py:165-176 / 537-551
 // ------------------------------------------------------------------------------------------------
 #define KT_CH 256
 #define KT_T 32
 #define KT_LD (KT_CH + 4)  // row stride (floats): 16-byte aligned, rows 4 banks apart (conflict-free 16-byte reads of 8 different rows)
 struct KmatTile {
-  const float* x;        // rows [M][stride], the segment starts at `off`
+  const float* x;        // rows [M][stride], the segment starts at `off`; all rows within 4 GiB of x (32-bit byte offsets)
   size_t stride, off;
   int len;
-  float* part;           // [nchunk][Mloc][M]
+  float* part;           // [nsplit][Mloc][M] partial squared distances (nsplit > 1)
   int m0, Mloc, M, nchunk, nta, ntb, symmetric;
+  // the chunk range of a tile is cut into nsplit pieces of cps chunks, one unit each.  nsplit == 1: the unit holds the whole distance and
+  // writes the matrix entries itself (exp, mirror, kadd + k); otherwise k_kmat_finish adds the pieces.
+  int nsplit, cps;
+  float scale, h;
+  float* kout;
+  const float* kadd;
+  float* ksum;
 };
+// host: how many pieces.  Cost model in chunk times: the blocks (one per CU, 256 of them) take ceil(units / 256) rounds of cps chunks plus
+// the exposed first fetch; the pieces cost a second pass over nsplit matrices.
+__host__ inline int kmat_pick_nsplit(int tiles, int nchunk, int max_ns) {
+  int best = 1;
+  double bc = 1e30;
+  for (int ns = 1; ns <= nchunk && ns <= max_ns; ++ns) {
+    const int cps = (nchunk + ns - 1) / ns, ns_eff = (nchunk + cps - 1) / cps;
+    if (ns_eff != ns) continue;
+    const double c = (double)((tiles * ns + 255) / 256) * (cps + 0.6) + (ns > 1 ? 0.3 + 0.05 * ns : 0.0);
+    if (c < bc - 1e-9) bc = c, best = ns;
+  }
+  return best;
+}
+// (host) the tile kernel addresses the rows with 32-bit byte offsets
+__host__ inline bool kmat_tile_addressable(size_t rows, size_t stride, size_t off, size_t len) {
+  return (rows * stride + off + len) * 4 < ((size_t)1 << 32);
+}
 __host__ __device__ inline size_t kmat_tile_lds_bytes() { return (size_t)2 * KT_T * KT_LD * 4; }  // (>= 16 x 1024 floats of partial sums)
 __host__ __device__ inline int kmat_tile_count(int nta, int ntb, int symmetric) { return symmetric ? nta * (nta + 1) / 2 : nta * ntb; }
 __host__ __device__ inline int kmat_nchunk(int len) { return (len + KT_CH - 1) / KT_CH; }
@@ -49,8 +74,7 @@ __host__ __device__ inline int kmat_nchunk(int len) { return (len + KT_CH - 1) /
 struct KtUnit {
   int a0, b0, c0, clen, chunk;
 };
-__device__ __forceinline__ KtUnit kt_unit(const KmatTile& K, int unit) {
-  const int tile = unit / K.nchunk, chunk = unit - tile * K.nchunk;
+__device__ __forceinline__ KtUnit kt_unit(const KmatTile& K, int tile, int chunk) {
   int ta, tb;
   if (K.symmetric) {
     ta = 0;
@@ -69,11 +93,11 @@ __device__ __forceinline__ void kt_fetch(const KmatTile& K, const KtUnit& U, int
   auto grow = [&](int row) {
     return row < KT_T ? K.m0 + (U.a0 + row < K.Mloc ? U.a0 + row : K.Mloc - 1) : (U.b0 + row - KT_T < K.M ? U.b0 + row - KT_T : K.M - 1);
   };
-  if (VEC) {
-    // (vec: 16-byte aligned rows, segment length a multiple of 4 -- a float4 is all inside or all outside -- and the rows within 4 GiB:
-    //  uniform base + 32-bit byte offsets (the SGPR-base form of global_load; this hipcc lowers the b64 / b128 buffer-load builtins to a
-    //  single dword).  Clamped offset here + select at staging time keep the batch free of branches and waits, i.e. in flight together)
-    const char* base = reinterpret_cast<const char*>(K.x + K.off + (size_t)U.c0);
+  // uniform base + 32-bit byte offsets (the SGPR-base form of global_load: no 64-bit address per load; this hipcc lowers the b64 / b128
+  // buffer-load builtins to a single dword).  Clamped offsets here + zeroing at staging time keep the batch free of branches and waits,
+  // i.e. in flight together.
+  const char* base = reinterpret_cast<const char*>(K.x + K.off + (size_t)U.c0);
+  if (VEC) {  // 16-byte aligned rows, segment length a multiple of 4: a float4 is all inside or all outside
 #pragma unroll
     for (int u = 0; u < KT_RV / 4; ++u) {
       const int i = u * KT_NT + tid, row = i / (KT_CH / 4), e = (i - row * (KT_CH / 4)) * 4;
@@ -85,8 +109,8 @@ __device__ __forceinline__ void kt_fetch(const KmatTile& K, const KtUnit& U, int
 #pragma unroll
     for (int u = 0; u < KT_RV; ++u) {
       const int i = u * KT_NT + tid, row = i / KT_CH, e = i - row * KT_CH;
-      const float* src = K.x + (size_t)grow(row) * K.stride + K.off + U.c0;
-      v[u] = src[e < U.clen ? e : 0];
+      const uint32_t bo = ((uint32_t)grow(row) * (uint32_t)K.stride + (uint32_t)(e < U.clen ? e : 0)) * 4u;
+      v[u] = *reinterpret_cast<const float*>(base + bo);
     }
   }
 }
@@ -108,7 +132,8 @@ __device__ __forceinline__ void kt_stage(float* __restrict__ smem, int clen, int
     }
   }
 }
-// units first, first + step, ... of nta (x ntb) tiles x nchunk chunks
+// units first, first + step, ... of nta (x ntb) tiles x nsplit pieces; one flat sequence of (unit, chunk) steps with the next step's rows
+// in flight
 template <bool VEC>
 __device__ __forceinline__ void kmat_tile_loop(float* __restrict__ smem, const KmatTile& K, int first, int step, int units, int tid) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -116,14 +141,23 @@ __device__ __forceinline__ void kmat_tile_loop(float* __restrict__ smem, const K
   const float4* pa = reinterpret_cast<const float4*>(smem + ag * KT_LD) + wave * (KT_CH / 4 / 16);
   const float4* pb = reinterpret_cast<const float4*>(smem + (KT_T + bg) * KT_LD) + wave * (KT_CH / 4 / 16);
   float v[KT_RV];
-  KtUnit U = kt_unit(K, first);
+  int u = first, c = (u % K.nsplit) * K.cps;
+  KtUnit U = kt_unit(K, u / K.nsplit, c);
   kt_fetch<VEC>(K, U, tid, v);
-  for (int u = first; u < units; u += step) {
+  double tot = 0.0;
+  for (;;) {
     kt_stage<VEC>(smem, U.clen, tid, v);
     __syncthreads();
     const KtUnit Ucur = U;
-    if (u + step < units) {  // (block-uniform) the next unit's rows are in flight during this one's arithmetic
-      U = kt_unit(K, u + step);
+    const int sp = u % K.nsplit, c_hi = (sp + 1) * K.cps < K.nchunk ? (sp + 1) * K.cps : K.nchunk;
+    int un = u, cn = c + 1;
+    if (cn >= c_hi) {
+      un = u + step;
+      cn = (un % K.nsplit) * K.cps;
+    }
+    const bool more = un < units;  // (block-uniform)
+    if (more) {
+      U = kt_unit(K, un / K.nsplit, cn);
       kt_fetch<VEC>(K, U, tid, v);
     }
     f32x2 acc[16];
@@ -150,22 +184,37 @@ __device__ __forceinline__ void kmat_tile_loop(float* __restrict__ smem, const K
 #pragma unroll
     for (int q = 0; q < 16; ++q) smem[wave * 1024 + q * 64 + lane] = acc[q].x + acc[q].y;
     __syncthreads();
-    {
-      double tot = 0.0;
 #pragma unroll
-      for (int w = 0; w < 16; ++w) tot += (double)smem[w * 1024 + tid];
+    for (int w = 0; w < 16; ++w) tot += (double)smem[w * 1024 + tid];
+    if (un != u) {  // (block-uniform) last chunk of the unit: thread tid holds the pair (a, b)
       const int q = tid >> 6, a = Ucur.a0 + ag + 8 * (q >> 2), b = Ucur.b0 + bg + 8 * (q & 3);
-      if (a < K.Mloc && b < K.M) K.part[((size_t)Ucur.chunk * K.Mloc + a) * K.M + b] = (float)tot;
+      if (a < K.Mloc && b < K.M) {
+        if (K.nsplit > 1) {
+          K.part[((size_t)sp * K.Mloc + a) * K.M + b] = (float)tot;
+        } else {
+          const float kv = (float)((double)K.scale * exp(-tot / (double)K.h));
+          const bool mirror = K.symmetric && Ucur.b0 > Ucur.a0;  // (diagonal tiles hold both orders of their pairs: the same sums)
+          K.kout[(size_t)a * K.M + b] = kv;
+          if (mirror) K.kout[(size_t)b * K.M + a] = kv;
+          if (K.ksum) {
+            K.ksum[(size_t)a * K.M + b] = K.kadd[(size_t)a * K.M + b] + kv;
+            if (mirror) K.ksum[(size_t)b * K.M + a] = K.kadd[(size_t)b * K.M + a] + kv;
+          }
+        }
+      }
+      tot = 0.0;
     }
+    if (!more) break;
+    u = un;
+    c = cn;
     __syncthreads();
   }
 }
 __device__ __forceinline__ void kmat_tile_block(float* __restrict__ smem, const KmatTile& K, int first, int step, int tid) {
-  const int units = kmat_tile_count(K.nta, K.ntb, K.symmetric) * K.nchunk;
+  const int units = kmat_tile_count(K.nta, K.ntb, K.symmetric) * K.nsplit;
   if (first >= units) return;
   // (two copies of the loop: merged, the compiler shares the tails of the two fetch batches and waits on every load)
-  const bool vec = (((K.stride | K.off | (size_t)K.len) & 3) == 0) && ((reinterpret_cast<uintptr_t>(K.x) & 15) == 0) &&
-                   ((size_t)(K.m0 + K.Mloc > K.M ? K.m0 + K.Mloc : K.M) * K.stride + K.off + (size_t)K.len) * 4 < ((size_t)1 << 32);
+  const bool vec = (((K.stride | K.off | (size_t)K.len) & 3) == 0) && ((reinterpret_cast<uintptr_t>(K.x) & 15) == 0);
   if (vec)
     kmat_tile_loop<true>(smem, K, first, step, units, tid);
   else
