@@ -23,7 +23,8 @@ struct KmatFuse {
 //     the upper triangle (symmetric = one rank holds all particles: only tiles tb >= ta are computed) and forms kz + kt for the joint
 //     models; with few tiles the range is cut into nsplit pieces (kmat_pick_nsplit) whose sums k_kmat_finish adds.
 //     Bound: the per-CU fetch rate (64 KB per chunk at ~11 B/clk/CU when every CU fetches) -- 3.5 us per chunk against 1.7 us of VALU work.
-//     Measured: config 4 (1 024 particles) k_kmat 330 -> 227 us, 597 -> 664 steps/s; config 5 108.5 -> 115; config 3 2 290 -> 2 330.
+//     Measured (profiles/round5_cfg{3,4,5}_kernel_stats.csv): config 4 (1 024 particles) tile + finish 227 us (direct kernel, round 3: 434), 597 -> 664 steps/s;
+//     config 5 108.5 -> 115; config 3 2 290 -> 2 330.
 //     reference: kernel.py:20-30 / 52-71, svgd.py:165-176 / 537-551
 // ------------------------------------------------------------------------------------------------
 #define KT_CH 256
