@@ -82,8 +82,9 @@ struct dibs_engine {
   float* acyc_big;  // n_vars > 112: buffers of the global-memory matrix powers (kernels_acyc_big.h)
   float* eas;       // [Mloc][d][d] exp(-alpha s) of this step (k_edge_scores -> k_acyc_hf / k_acyc_hfw); n_vars <= 112 only
   float *scores, *probs, *w_lik, *acyc_part, *w_acyc, *logprobs_z, *logprobs_th, *pack, *kz, *kt, *phi_z, *phi_th;
-  float* kpart = nullptr;  // tiled kernel matrix (kernels_kmat.h): partial squared distances [nsplit][Mloc][M]; single-rank engines only
+  double* kpart = nullptr;  // tiled kernel matrix (kernels_kmat.h): partial squared distances [nsplit][Mloc][M]
   int kmat_ns_max = 0;     // 0: the direct kernel k_kmat; otherwise the largest nsplit kpart has room for
+  unsigned int* kmat_ctr = nullptr;  // one counter per tile (units riding in k_particle_grad: the last unit of a tile writes the entries)
   float* ksum = nullptr;  // joint models: kz + kt, formed by the k_kmat launch of kt (the weight matrix of the SVGD transform as ONE scalar-loadable array)
   uint32_t* thr;
   uint64_t* masks;
@@ -331,17 +332,21 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   HIP_OK(dalloc(&e->kz, Ml * e->M + kpad));
   if (c.joint) HIP_OK(dalloc(&e->kt, Ml * e->M + kpad));
   if (c.joint) HIP_OK(dalloc(&e->ksum, Ml * e->M + kpad));
-  if (e->Mloc == e->M && e->M >= kmat_tiled_min() && !getenv("DIBS_KMAT_OLD")) {  // (optional: without it the direct kernel k_kmat runs)
+  if (e->M >= kmat_tiled_min() && !getenv("DIBS_KMAT_OLD")) {  // (the same rule on every rank: it depends on the global particle count only)
     // room for up to 32 pieces per pair, less for many particles (<= 512 MiB); 1 = no buffer, every unit holds whole distances
-    size_t ns = ((size_t)512 << 20) / (Ml * e->M * 4);
+    size_t ns = ((size_t)512 << 20) / (Ml * e->M * 8);
     ns = ns > 32 ? 32 : (ns < 1 ? 1 : ns);
-    if (!kmat_tile_addressable((size_t)e->M, e->D > e->P ? e->D : e->P, 0, 0)) ns = 0;  // (32-bit row offsets in the tile kernel)
-    if (ns > 1 && hipMalloc((void**)&e->kpart, ns * Ml * e->M * 4) != hipSuccess) {
+    if (!kmat_tile_addressable((size_t)2 * e->M, e->E > e->Ev ? e->E : e->Ev, 0, 0)) ns = 0;  // (32-bit row offsets in the tile kernel)
+    if (ns > 1 && hipMalloc((void**)&e->kpart, ns * Ml * e->M * 8) != hipSuccess) {
       e->kpart = nullptr;
       (void)hipGetLastError();
       ns = 1;
     }
     e->kmat_ns_max = (int)ns;
+    if (ns > 1 && e->Mloc == e->M) {
+      const size_t nta = (e->M + KT_T - 1) / KT_T;
+      HIP_OK(dalloc(&e->kmat_ctr, nta * (nta + 1) / 2));
+    }
   }
   HIP_OK(dalloc(&e->phi_z, Ml * e->D));
   HIP_OK(dalloc(&e->phi_th, Ml * e->P));
@@ -449,7 +454,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (e->stream2) hipStreamSynchronize(e->stream2);
   void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->eas, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
-                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot, e->join_flag, e->scores2, e->eas2, e->ksum, e->kpart};
+                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot, e->join_flag, e->scores2, e->eas2, e->ksum, e->kpart, e->kmat_ctr};
   for (void* p : ptrs)
     if (p) hipFree(p);
   joint_free(&e->jw);
@@ -754,6 +759,22 @@ struct DevBuf {
   hipError_t alloc(size_t n) { return dalloc(&p, n); }
 };
 
+// One kernel-matrix algorithm per global particle count, on every rank and at every launch site: from kmat_tiled_min() particles the tiled
+// kernel (whose entries do not depend on how the work was cut, kernels_kmat.h), below it the direct one.
+static bool kmat_tiled_on(const dibs_engine* e) { return e->kmat_ns_max > 0 && e->M >= kmat_tiled_min(); }
+// rows of all M particles at x + m * stride + off (len floats); this engine's slab [Mloc][M] (symmetric when it holds every particle)
+static void kmat_launch_tiled(dibs_engine* e, hipStream_t st, const float* x, size_t stride, size_t off, size_t len, float* kout, float scale, float h,
+                              const float* kadd, float* ksum) {
+  const int sym = e->Mloc == e->M;
+  const int nta = (e->Mloc + KT_T - 1) / KT_T, ntb = (e->M + KT_T - 1) / KT_T, tiles = kmat_tile_count(nta, ntb, sym);
+  const int nchunk = kmat_nchunk((int)len), ns = kmat_pick_nsplit(tiles, nchunk, e->kmat_ns_max), cps = (nchunk + ns - 1) / ns;
+  const KmatTile kt{x, stride, off, (int)len, e->kpart, e->m0, e->Mloc, e->M, nchunk, nta, ntb, sym, ns, cps, scale, h, kout, kadd, ksum, nullptr};
+  dibs_allow_lds((const void*)k_kmat_tile, kmat_tile_lds_bytes());
+  // (persistent blocks, one per CU by their registers, looping over the units with the next step's rows prefetched)
+  const int units = tiles * ns;
+  hipLaunchKernelGGL(k_kmat_tile, dim3((unsigned)(units < 256 ? units : 256)), dim3(KT_NT), kmat_tile_lds_bytes(), st, kt);
+  if (ns > 1) hipLaunchKernelGGL(k_kmat_finish, dim3(e->Mloc), dim3(256), 0, st, (const double*)e->kpart, ns, e->Mloc, e->M, sym, scale, h, kout, kadd, ksum);
+}
 static bool edge_old_env() {
   static const bool v = getenv("DIBS_EDGE_OLD") != nullptr;  // (A/B switch: k_edge_scores with four blocks per particle also where k_edge_scores_p applies)
   return v;
@@ -817,6 +838,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
   const bool do_lik = (terms & TERMS_LIK) != 0, do_prior = (terms & TERMS_PRIOR) != 0;
 
   e->kmat_early = false;
+  e->kmat_fused = false;
   // While per-kernel timing is on (set_profiling(1)) the main stream joins right away, so that every duration is a kernel alone on the
   // GPU -- but the launch still goes to the second stream: with that (high-priority) queue in existence the same kernel takes 104 us
   // on the main stream and 96 us on its own.
@@ -837,6 +859,10 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
   // acyclicity chain (kmat_on_s2, see below); otherwise the latent matrix rides inside k_bge_sample
   const bool kmat_on_s2 = c.joint || (long)e->M * e->D > 4L * e->S * e->d * e->d;
   const bool kmat_early_now = fork && !xk && kmat_on_s2 && e->Mloc == e->M && !e->kmat_ext && !getenv("DIBS_NO_KMAT_EARLY");
+  // marginal models, single rank, 128+ particles: the latent matrix as tile units riding in the k_particle_grad launch (TailArgs::kt)
+  const bool tile_in_grad = !c.joint && !xk && !kmat_early_now && !e->kmat_ext && e->Mloc == e->M && e->kmat_ns_max > 1 && e->kmat_ctr != nullptr &&
+                            e->M >= kmat_tiled_min() && e->Mloc < 256 && e->w_tot == nullptr && !getenv("DIBS_NO_KMAT_FUSE") &&
+                            !getenv("DIBS_NO_KMAT_GRAD");
   auto launch_edge = [&](hipStream_t st, hipEvent_t stop_ev, bool copy2 = false) {
     KTimer tm(e, DIBS_K_EDGE, st);
     const size_t lds = (size_t)2 * e->dpad * e->ldk * 4;
@@ -912,20 +938,9 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
     KTimer tm(e, DIBS_K_KMAT, e->stream2);
     // tiled (kernels_kmat.h: partial sums per 32 x 32 tile and chunk, then one finishing block per row) from 128 particles: config 4 597 ->
     // 645 steps/s, config 5 108.5 -> 115, config 3 2290 -> 2328 on the same box (each row is read once per tile instead of once per pair)
-    if (e->kmat_ns_max > 0 && e->M >= kmat_tiled_min()) {
-      const int nta = (e->M + KT_T - 1) / KT_T, tiles = kmat_tile_count(nta, nta, 1);
-      allow_lds(k_kmat_tile, kmat_tile_lds_bytes());
-      auto tiled = [&](const float* x, size_t len, float* kout, float scale, float h, const float* kadd, float* ksum) {
-        const int nchunk = kmat_nchunk((int)len), ns = kmat_pick_nsplit(tiles, nchunk, e->kmat_ns_max), cps = (nchunk + ns - 1) / ns;
-        const KmatTile kt{x, len, 0, (int)len, e->kpart, 0, e->Mloc, e->M, nchunk, nta, nta, 1, ns, cps, scale, h, kout, kadd, ksum};
-        // (persistent blocks, one per CU by their registers, looping over the units with the next step's rows prefetched)
-        const int units = tiles * ns;
-        hipLaunchKernelGGL(k_kmat_tile, dim3((unsigned)(units < 256 ? units : 256)), dim3(KT_NT), kmat_tile_lds_bytes(), e->stream2, kt);
-        if (ns > 1)
-          hipLaunchKernelGGL(k_kmat_finish, dim3(e->Mloc), dim3(256), 0, e->stream2, e->kpart, ns, e->Mloc, e->M, 1, scale, h, kout, kadd, ksum);
-      };
-      tiled(e->z, (size_t)e->D, e->kz, (float)c.scale_latent, (float)c.h_latent, nullptr, nullptr);
-      if (c.joint) tiled(e->theta, (size_t)e->P, e->kt, (float)c.scale_theta, (float)c.h_theta, e->kz, e->ksum);
+    if (kmat_tiled_on(e)) {
+      kmat_launch_tiled(e, e->stream2, e->z, (size_t)e->D, 0, (size_t)e->D, e->kz, (float)c.scale_latent, (float)c.h_latent, nullptr, nullptr);
+      if (c.joint) kmat_launch_tiled(e, e->stream2, e->theta, (size_t)e->P, 0, (size_t)e->P, e->kt, (float)c.scale_theta, (float)c.h_theta, e->kz, e->ksum);
     } else {
       auto kmat_lds = [](size_t len) { return (size_t)(((len < KMAT_CH ? len : (size_t)KMAT_CH) + 3) & ~(size_t)3) * 4; };
       allow_lds(k_kmat, kmat_lds(e->D > e->P ? e->D : e->P));
@@ -957,7 +972,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
       KmatFuse kf{nullptr, nullptr, 0, 0, 0, 0.f, 0.f};
       e->kmat_fused = false;
       // single rank, vector fits one LDS chunk: the latent kernel matrix rides along (see KmatFuse)
-      if (!xk && !e->kmat_early && !e->kmat_ext && e->Mloc == e->M && e->D <= KMAT_CH && (size_t)e->D * 4 + 64 <= 80 * 1024 && !getenv("DIBS_NO_KMAT_FUSE")) {
+      if (!tile_in_grad && !kmat_tiled_on(e) && !xk && !e->kmat_early && !e->kmat_ext && e->Mloc == e->M && e->D <= KMAT_CH && (size_t)e->D * 4 + 64 <= 80 * 1024 && !getenv("DIBS_NO_KMAT_FUSE")) {
         kf = KmatFuse{e->z, e->kz, (int)e->D, e->M, (e->d + 3) / 4, (float)c.scale_latent, (float)c.h_latent};
         e->kmat_fused = true;
       }
@@ -1028,13 +1043,33 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
     const int ldz = e->w_tot ? 0 : tail_ldz(e->d, e->k, e->S, score_lik, LDS_LIMIT - 2048);
     const int cap = score_lik ? tail_stage_cap(e->d, ldz, e->S, e->W, LDS_LIMIT - 2048) : 0;
     const size_t lds = tail_lds_bytes(e->d, ldz, e->S, e->W, score_lik, cap);
-    const TailArgs ta{score_lik ? e->node_scores : nullptr, e->masks, e->logprobs_z, e->baseline, e->baseline2, c.score_function_baseline,
+    TailArgs ta{score_lik ? e->node_scores : nullptr, e->masks, e->logprobs_z, e->baseline, e->baseline2, c.score_function_baseline,
                       score_lik ? e->bq.counts : nullptr, e->S, e->W, cap, e->probs, do_lik ? e->w_lik : const_cast<float*>(zero_w), e->w_acyc, alpha,
                       do_prior ? beta : 0.f, do_prior ? c.graph_prior : (int)DIBS_PRIOR_UNIFORM, er_c,
                       e->z, pack, rt.stride, rt.copy_vals, e->m0, e->d, e->k, ldz, inv_sig2, e->profiling ? e->counters : nullptr,
-                      e->w_tot, flag_join ? e->join_flag : nullptr, e->join_seq, e->join_err};
-    allow_lds(k_particle_grad, lds);
-    hipLaunchKernelGGL(k_particle_grad, dim3(e->Mloc), dim3(TAIL_NT), lds, e->stream, ta);
+                      e->w_tot, flag_join ? e->join_flag : nullptr, e->join_seq, e->join_err, e->Mloc,
+                      KmatTile{nullptr, 0, 0, 0, nullptr, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr}};
+    size_t lds_g = lds;
+    int nrider = 0;
+    if (tile_in_grad) {
+      const int nta = (e->M + KT_T - 1) / KT_T, tiles = kmat_tile_count(nta, nta, 1), nchunk = kmat_nchunk((int)e->D);
+      // (pieces: enough units for the CUs the particles leave free, one round of them -- measured at the headline size, launch time on the
+      //  event timer: no units 20.7 us; 100 units of 2 chunks 21.2; 70 of 3 chunks 25.2; 200 of 1 chunk on 128 blocks 25.8)
+      int ns = getenv("DIBS_KMAT_GRAD_NS") ? atoi(getenv("DIBS_KMAT_GRAD_NS")) : (256 - e->Mloc + tiles - 1) / tiles;  // (tuning override)
+      ns = ns > nchunk ? nchunk : ns;
+      ns = ns > e->kmat_ns_max ? e->kmat_ns_max : ns;
+      const int cps = (nchunk + ns - 1) / ns;
+      ns = (nchunk + cps - 1) / cps;
+      if (ns > 1) {
+        ta.kt = KmatTile{e->z, (size_t)e->D, 0, (int)e->D, e->kpart, 0, e->Mloc, e->M, nchunk, nta, nta, 1, ns, cps, (float)c.scale_latent,
+                         (float)c.h_latent, e->kz, nullptr, nullptr, e->kmat_ctr};
+        nrider = tiles * ns < 256 - e->Mloc ? tiles * ns : 256 - e->Mloc;
+        lds_g = lds > kmat_tile_lds_bytes() ? lds : kmat_tile_lds_bytes();
+        e->kmat_fused = true;
+      }
+    }
+    allow_lds(k_particle_grad, lds_g);
+    hipLaunchKernelGGL(k_particle_grad, dim3(e->Mloc + nrider), dim3(TAIL_NT), lds_g, e->stream, ta);
     if (e->w_tot) {
       const size_t lb = backproject_big_lds(e->d);
       allow_lds(k_backproject_big, lb);
@@ -1072,7 +1107,13 @@ static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_s
   // values right behind this call and sets the flag again; every other caller -- packed protocol, dibs_engine_run, step_update -- leaves
   // it cleared, so that the next overlapped chunk / gather_particles re-gathers instead of using the stale plane)
   e->vals_fresh = false;
-  if (!kmat_ext && !e->kmat_early && (!e->kmat_fused || c.joint)) {
+  if (!kmat_ext && !e->kmat_early && (!e->kmat_fused || c.joint) && kmat_tiled_on(e)) {
+    KTimer tm(e, DIBS_K_KMAT);
+    if (!e->kmat_fused)
+      kmat_launch_tiled(e, e->stream, pack, rs.stride, rs.z_off, (size_t)e->D, e->kz, (float)c.scale_latent, (float)c.h_latent, nullptr, nullptr);
+    if (c.joint)
+      kmat_launch_tiled(e, e->stream, pack, rs.stride, rs.th_off, (size_t)e->P, e->kt, (float)c.scale_theta, (float)c.h_theta, e->kz, e->ksum);
+  } else if (!kmat_ext && !e->kmat_early && (!e->kmat_fused || c.joint)) {
     KTimer tm(e, DIBS_K_KMAT);
     const int ksym = e->Mloc == e->M;  // single rank: the slab is the whole (symmetric) matrix
     auto kmat_lds = [](size_t len) { return (size_t)(((len < KMAT_CH ? len : (size_t)KMAT_CH) + 3) & ~(size_t)3) * 4; };
@@ -1214,6 +1255,14 @@ extern "C" int dibs_engine_kmat_values(dibs_engine* e, const void* vals_all_dev,
   HIP_OK(hipSetDevice(e->cfg.device_id));
   const dibs_config& c = e->cfg;
   hipStream_t st = (hipStream_t)stream;
+  if (kmat_tiled_on(e)) {
+    const float* v = (const float*)vals_all_dev;
+    kmat_launch_tiled(e, st, v, (size_t)e->Ev, 0, (size_t)e->D, e->kz, (float)c.scale_latent, (float)c.h_latent, nullptr, nullptr);
+    if (c.joint) kmat_launch_tiled(e, st, v, (size_t)e->Ev, (size_t)e->D, (size_t)e->P, e->kt, (float)c.scale_theta, (float)c.h_theta, e->kz, e->ksum);
+    HIP_OK(hipGetLastError());
+    e->kmat_ext = true;
+    return 0;
+  }
   auto kmat_lds = [](size_t len) { return (size_t)(((len < KMAT_CH ? len : (size_t)KMAT_CH) + 3) & ~(size_t)3) * 4; };
   dibs_allow_lds((const void*)k_kmat, kmat_lds(e->D > e->P ? e->D : e->P));
   const dim3 kg(e->Mloc, (e->M + KMAT_BT - 1) / KMAT_BT);

@@ -22,6 +22,10 @@ struct KmatFuse {
 //     double into the thread that owns the pair; with the whole chunk range in one unit (many tiles) that thread applies exp(-./h), mirrors
 //     the upper triangle (symmetric = one rank holds all particles: only tiles tb >= ta are computed) and forms kz + kt for the joint
 //     models; with few tiles the range is cut into nsplit pieces (kmat_pick_nsplit) whose sums k_kmat_finish adds.
+//     Grouping: a wave's 16-element sum is a float; everything above it is added in double, where sums of a few thousand floats of similar
+//     size are exact -- so the entry does not depend on how the chunk range was cut into pieces, on which unit finished last, or on
+//     whether the slab is the symmetric whole (one rank) or a rank's rows (sharded): rank engines and the single-rank engine agree bit
+//     for bit, as they did with the direct kernel.
 //     Bound: the per-CU fetch rate (64 KB per chunk at ~11 B/clk/CU when every CU fetches) -- 3.5 us per chunk against 1.7 us of VALU work.
 //     Measured (profiles/round5_cfg{3,4,5}_kernel_stats.csv): config 4 (1 024 particles) tile + finish 227 us (direct kernel, round 3: 434), 597 -> 664 steps/s;
 //     config 5 108.5 -> 115; config 3 2 290 -> 2 330.
@@ -34,7 +38,7 @@ struct KmatTile {
   const float* x;        // rows [M][stride], the segment starts at `off`; all rows within 4 GiB of x (32-bit byte offsets)
   size_t stride, off;
   int len;
-  float* part;           // [nsplit][Mloc][M] partial squared distances (nsplit > 1)
+  double* part;          // [nsplit][Mloc][M] partial squared distances (nsplit > 1), in double: see the note on grouping below
   int m0, Mloc, M, nchunk, nta, ntb, symmetric;
   // the chunk range of a tile is cut into nsplit pieces of cps chunks, one unit each.  nsplit == 1: the unit holds the whole distance and
   // writes the matrix entries itself (exp, mirror, kadd + k); otherwise k_kmat_finish adds the pieces.
@@ -43,6 +47,10 @@ struct KmatTile {
   float* kout;
   const float* kadd;
   float* ksum;
+  // nsplit > 1 and tile_ctr != null: no second pass -- every unit stores its piece at agent scope and counts itself on its tile's counter, the LAST one of
+  // a tile adds the pieces (fixed order: the result does not depend on which unit came last) and writes the entries.  Lets the units ride
+  // in another kernel's launch (k_particle_grad).  Counters are zero between launches.
+  unsigned int* tile_ctr;
 };
 // host: how many pieces.  Cost model in chunk times: the blocks (one per CU, 256 of them) take ceil(units / 256) rounds of cps chunks plus
 // the exposed first fetch; the pieces cost a second pass over nsplit matrices.
@@ -191,7 +199,12 @@ __device__ __forceinline__ void kmat_tile_loop(float* __restrict__ smem, const K
       const int q = tid >> 6, a = Ucur.a0 + ag + 8 * (q >> 2), b = Ucur.b0 + bg + 8 * (q & 3);
       if (a < K.Mloc && b < K.M) {
         if (K.nsplit > 1) {
-          K.part[((size_t)sp * K.Mloc + a) * K.M + b] = (float)tot;
+          // (tile_ctr: agent-scope store -- written through, complete at agent scope once the block's barrier below has drained vmcnt --
+          //  instead of a plain store + release fence: the fence writes the XCD's whole L2 back, +2 us on the launch the units ride in)
+          if (K.tile_ctr)
+            __hip_atomic_store(K.part + ((size_t)sp * K.Mloc + a) * K.M + b, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else
+            K.part[((size_t)sp * K.Mloc + a) * K.M + b] = tot;
         } else {
           const float kv = (float)((double)K.scale * exp(-tot / (double)K.h));
           const bool mirror = K.symmetric && Ucur.b0 > Ucur.a0;  // (diagonal tiles hold both orders of their pairs: the same sums)
@@ -204,6 +217,40 @@ __device__ __forceinline__ void kmat_tile_loop(float* __restrict__ smem, const K
         }
       }
       tot = 0.0;
+      if (K.nsplit > 1 && K.tile_ctr) {  // (block-uniform)
+        unsigned int* const ctr = K.tile_ctr + u / K.nsplit;
+        unsigned int* const last = reinterpret_cast<unsigned int*>(smem + 16 * 1024);  // (first word behind the partial sums)
+        __syncthreads();  // (every piece store of the block has completed: the barrier's release drains vmcnt)
+        if (tid == 0) {
+          const unsigned int done = atomicAdd(ctr, 1u) + 1u;
+          if (done == (unsigned int)K.nsplit) atomicExch(ctr, 0u);
+          *last = done == (unsigned int)K.nsplit;
+        }
+        __syncthreads();
+        if (*last && a < K.Mloc && b < K.M) {
+          // (agent-scope loads: this XCD's L2 may hold last step's lines of `part`; the other units released theirs to memory)
+          double t2 = 0.0;
+          const double* pp = K.part + (size_t)a * K.M + b;
+          const size_t cs = (size_t)K.Mloc * K.M;
+          int s8 = 0;
+          for (; s8 + 8 <= K.nsplit; s8 += 8) {
+            double pv[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) pv[w] = __hip_atomic_load(pp + (size_t)(s8 + w) * cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t2 += pv[w];
+          }
+          for (; s8 < K.nsplit; ++s8) t2 += __hip_atomic_load(pp + (size_t)s8 * cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float kv = (float)((double)K.scale * exp(-t2 / (double)K.h));
+          const bool mirror = K.symmetric && Ucur.b0 > Ucur.a0;
+          K.kout[(size_t)a * K.M + b] = kv;
+          if (mirror) K.kout[(size_t)b * K.M + a] = kv;
+          if (K.ksum) {
+            K.ksum[(size_t)a * K.M + b] = K.kadd[(size_t)a * K.M + b] + kv;
+            if (mirror) K.ksum[(size_t)b * K.M + a] = K.kadd[(size_t)b * K.M + a] + kv;
+          }
+        }
+      }
     }
     if (!more) break;
     u = un;
@@ -222,25 +269,25 @@ __device__ __forceinline__ void kmat_tile_block(float* __restrict__ smem, const 
     kmat_tile_loop<false>(smem, K, first, step, units, tid);
 }
 
-// row a of the matrix from the partial sums: threads tid, tid + nthr, ... take the columns b
-__device__ __forceinline__ void kmat_finish_row(const float* __restrict__ part, int nchunk, int Mloc, int M, int symmetric, float scale, float h,
+// row a of the matrix from the pieces: threads tid, tid + nthr, ... take the columns b
+__device__ __forceinline__ void kmat_finish_row(const double* __restrict__ part, int nsplit, int Mloc, int M, int symmetric, float scale, float h,
                                                 float* __restrict__ kout, const float* __restrict__ kadd, float* __restrict__ ksum, int a, int tid,
                                                 int nthr) {
   for (int b = tid; b < M; b += nthr) {
     // (symmetric: only tiles tb >= ta exist; below them the transposed entry is the same sum)
     const bool up = !symmetric || (b / KT_T) >= (a / KT_T);
-    const float* p = part + (up ? (size_t)a * M + b : (size_t)b * M + a);
+    const double* p = part + (up ? (size_t)a * M + b : (size_t)b * M + a);
     const size_t cs = (size_t)Mloc * M;
     double tot = 0.0;
     int c = 0;
-    for (; c + 8 <= nchunk; c += 8) {
-      float v[8];
+    for (; c + 8 <= nsplit; c += 8) {
+      double v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(c + u) * cs];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) tot += (double)v[u];
+      for (int u = 0; u < 8; ++u) tot += v[u];
     }
-    for (; c < nchunk; ++c) tot += (double)p[(size_t)c * cs];
+    for (; c < nsplit; ++c) tot += p[(size_t)c * cs];
     const float kv = (float)((double)scale * exp(-tot / (double)h));
     kout[(size_t)a * M + b] = kv;
     if (ksum) ksum[(size_t)a * M + b] = kadd[(size_t)a * M + b] + kv;

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(KT_NT) void k_kmat_tile(KmatTile kt) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   kmat_tile_block(smem, kt, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x);
 }
-__global__ __launch_bounds__(256) void k_kmat_finish(const float* __restrict__ part, int nchunk, int Mloc, int M, int symmetric, float scale, float h,
+__global__ __launch_bounds__(256) void k_kmat_finish(const double* __restrict__ part, int nchunk, int Mloc, int M, int symmetric, float scale, float h,
                                                      float* __restrict__ kout, const float* __restrict__ kadd, float* __restrict__ ksum) {
   kmat_finish_row(part, nchunk, Mloc, M, symmetric, scale, h, kout, kadd, ksum, (int)blockIdx.x, (int)threadIdx.x, 256);
 }

@@ -3,6 +3,7 @@
 // was latency-bound (three dependent launches of 9-15 us for ~1 GFLOP between them).
 #pragma once
 #include "common.h"
+#include "kernels_kmat.h"
 
 // ------------------------------------------------------------------------------------------------
 // K4+K7  one block of 1024 threads per particle, everything staged in LDS:
@@ -52,6 +53,11 @@ struct TailArgs {
   const unsigned int* join_flag;
   unsigned int join_seq;
   unsigned int* join_err;   // set to 1 when the flag did not arrive within the time-out (the host checks it after the chunk)
+  // kt.x != null: blocks blockIdx.x >= n_part are units of the tiled latent kernel matrix (kmat_tile_block, last unit of a tile writes the
+  // entries) riding along: the matrix needs only Z, the next kernel (the SVGD transform) is its first reader, and this launch leaves half
+  // of the machine idle for 17 us at 128 particles
+  int n_part;
+  KmatTile kt;
 };
 
 // The main stream does not wait for the second stream with an event (a barrier packet in front of this kernel: +2.5 .. 7 us on the
@@ -125,6 +131,10 @@ __host__ inline size_t tail_lds_bytes(int d, int ldz, int S, int W, bool lik, in
 
 __global__ __launch_bounds__(TAIL_NT) void k_particle_grad(TailArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (A.kt.x != nullptr && (int)blockIdx.x >= A.n_part) {  // (block-uniform)
+    kmat_tile_block(reinterpret_cast<float*>(smem_raw), A.kt, (int)blockIdx.x - A.n_part, (int)gridDim.x - A.n_part, (int)threadIdx.x);
+    return;
+  }
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = A.d, k = A.k, S = A.S, W = A.W, ldz = A.ldz;
   const int dd = d * d, dp16 = (d + 15) & ~15, kp4 = (d + 3) & ~3, ldw = tail_ldw(d);

@@ -1131,3 +1131,29 @@ def test_randomised_differential(monkeypatch, mode, n, seed):
         monkeypatch.setenv(mode, "1")
     monkeypatch.setattr(sys, "argv", ["gpu_fuzz.py", str(n), str(seed)])
     assert gpu_fuzz.main() == 0
+
+
+def test_kernel_matrix_units_in_particle_grad_launch(monkeypatch):
+    """128+ particles, single rank, marginal model: the latent kernel matrix is computed by tile units riding in the k_particle_grad launch
+    (pieces stored at agent scope, the last unit of a tile adds them -- no fence, no second pass).  200 steps in lock step with an engine
+    that computes the matrix inside k_bge_sample (DIBS_NO_KMAT_GRAD=1, read per step): a piece read too early would be the previous
+    step's (the buffer is reused), i.e. an entry off by ~1e-3.  Same sums in another order: 2e-6.  kernel.py:20-30, svgd.py:165-176"""
+    d, M = 20, 128
+    data, _, _ = make_data(d, seed=0)
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=100, n_grad_mc_samples=16, n_acyclicity_mc_samples=4)
+    a, b = _engine(cfg, data.x), _engine(cfg, data.x)
+    a.init_particles(prng.PRNGKey(5))
+    worst = 0.0
+    for t in range(200):
+        st = {k: v for k, v in a.get_state().items() if v is not None}
+        b.set_state(**st)
+        monkeypatch.delenv("DIBS_NO_KMAT_GRAD", raising=False)
+        a.run(t, 1)
+        monkeypatch.setenv("DIBS_NO_KMAT_GRAD", "1")
+        b.run(t, 1)
+        ka, kb = a.read("KXX"), b.read("KXX")
+        worst = max(worst, float(np.abs(ka - kb).max() / np.abs(kb).max()))
+        assert worst < 2e-6, (t, worst)
+        assert rel_err(a.get_state()["z"], b.get_state()["z"]) < 1e-5
+    monkeypatch.delenv("DIBS_NO_KMAT_GRAD", raising=False)
+    a.close(); b.close()
