@@ -232,15 +232,17 @@ __device__ __forceinline__ void kmat_tile_loop(float* __restrict__ smem, const K
           double t2 = 0.0;
           const double* pp = K.part + (size_t)a * K.M + b;
           const size_t cs = (size_t)K.Mloc * K.M;
-          int s8 = 0;
-          for (; s8 + 8 <= K.nsplit; s8 += 8) {
-            double pv[8];
+          // (all pieces of a pair requested together, 16 at a time: each is a trip past the L2)
+          for (int s16 = 0; s16 < K.nsplit; s16 += 16) {
+            double pv[16];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) pv[w] = __hip_atomic_load(pp + (size_t)(s8 + w) * cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int w = 0; w < 16; ++w) {
+              const int sq = s16 + w < K.nsplit ? s16 + w : K.nsplit - 1;
+              pv[w] = __hip_atomic_load(pp + (size_t)sq * cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
 #pragma unroll
-            for (int w = 0; w < 8; ++w) t2 += pv[w];
+            for (int w = 0; w < 16; ++w) t2 += s16 + w < K.nsplit ? pv[w] : 0.0;
           }
-          for (; s8 < K.nsplit; ++s8) t2 += __hip_atomic_load(pp + (size_t)s8 * cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const float kv = (float)((double)K.scale * exp(-t2 / (double)K.h));
           const bool mirror = K.symmetric && Ucur.b0 > Ucur.a0;
           K.kout[(size_t)a * K.M + b] = kv;
