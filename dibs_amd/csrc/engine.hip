@@ -82,6 +82,8 @@ struct dibs_engine {
   float* acyc_big;  // n_vars > 112: buffers of the global-memory matrix powers (kernels_acyc_big.h)
   float* eas;       // [Mloc][d][d] exp(-alpha s) of this step (k_edge_scores -> k_acyc_hf / k_acyc_hfw); n_vars <= 112 only
   float *scores, *probs, *w_lik, *acyc_part, *w_acyc, *logprobs_z, *logprobs_th, *pack, *kz, *kt, *phi_z, *phi_th;
+  unsigned int* fork_flag = nullptr;  // [0] sequence number published by k_edge_scores_p's last block, [1] its block counter (flag fork)
+  unsigned int fork_seq = 0;
   double* kpart = nullptr;  // tiled kernel matrix (kernels_kmat.h): partial squared distances [nsplit][Mloc][M]
   int kmat_ns_max = 0;     // 0: the direct kernel k_kmat; otherwise the largest nsplit kpart has room for
   unsigned int* kmat_ctr = nullptr;  // one counter per tile (units riding in k_particle_grad: the last unit of a tile writes the entries)
@@ -254,9 +256,11 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   if (!getenv("DIBS_NO_ACYC_STREAM2")) {
     int lo = 0, hi = 0;
     hipDeviceGetStreamPriorityRange(&lo, &hi);  // (lo = least, hi = greatest priority)
-    // measured at the headline size: serial 3 906 steps/s; second stream at least / normal / greatest priority 3 906 / 3 964 / 4 001
+    // round 3, headline size: serial 3 906 steps/s; second stream at least / normal / greatest priority 3 906 / 3 964 / 4 001.
+    // round 5 (fork by flag, both chains start together -- see flag_fork in step_local): least priority; with the event fork the three
+    // priorities measure the same now (5 193-5 217), configs 3 / 5 gain 1-2 % at the least priority, config 4 is unchanged.
     const char* pr = getenv("DIBS_ACYC_PRIO");
-    const int prio = pr ? (atoi(pr) > 0 ? hi : (atoi(pr) < 0 ? lo : (lo + hi) / 2)) : hi;
+    const int prio = pr ? (atoi(pr) > 0 ? hi : (atoi(pr) < 0 ? lo : (lo + hi) / 2)) : lo;
     // (an optimisation only: without it every kernel goes to the engine stream)
     if (hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, prio) != hipSuccess &&
         hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess) {
@@ -271,6 +275,7 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
     HIP_OK(hipEventCreateWithFlags(&e->ev_k1, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&e->ev_z, hipEventDisableTiming));
     HIP_OK(dalloc(&e->join_flag, (size_t)4));
+    HIP_OK(dalloc(&e->fork_flag, (size_t)4));
     HIP_OK(hipHostMalloc((void**)&e->join_err, 4, hipHostMallocDefault));
     *e->join_err = 0u;
     // the in-kernel join needs the two streams to make progress side by side (see k_probe_wait): asked once per process and device
@@ -454,7 +459,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (e->stream2) hipStreamSynchronize(e->stream2);
   void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->eas, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
-                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot, e->join_flag, e->scores2, e->eas2, e->ksum, e->kpart, e->kmat_ctr};
+                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot, e->join_flag, e->fork_flag, e->scores2, e->eas2, e->ksum, e->kpart, e->kmat_ctr};
   for (void* p : ptrs)
     if (p) hipFree(p);
   joint_free(&e->jw);
@@ -863,20 +868,34 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
   const bool tile_in_grad = !c.joint && !xk && !kmat_early_now && !e->kmat_ext && e->Mloc == e->M && e->kmat_ns_max > 1 && e->kmat_ctr != nullptr &&
                             e->M >= kmat_tiled_min() && e->Mloc < 256 && e->w_tot == nullptr && !getenv("DIBS_NO_KMAT_FUSE") &&
                             !getenv("DIBS_NO_KMAT_GRAD");
+  // fork without an event (marginal models; DIBS_NO_FLAG_FORK=1: the edge kernel's completion signal as before): k_edge_scores_p stores what
+  // the second stream reads (scores, exp(-alpha s)) at agent scope, every block counts itself and the last one publishes a sequence number;
+  // one polling wave (k_wait_flag) heads the second stream's chain.  The completion signal cost the NEXT kernel of the main stream 4.7 us
+  // (edge -> sample gap; 1.0 us between plain launches).  With the two chains starting together the acyclicity stream must not have
+  // priority over the sampling kernel (it took the machine: sampling 130 us, the factorisation then alone for 33): the stream is created
+  // with the LOWEST priority now.  bench.py, same box: event fork 5 193-5 217 steps/s; flag fork with greatest / normal / lowest priority
+  // 5 218-5 226 / 5 296 / 5 341; config 2 20 560 -> 22 200.  Joint models keep the event (config 3: 2 345 vs 2 311 with the flag).
+  static const bool want_flag_fork = getenv("DIBS_NO_FLAG_FORK") == nullptr;
+  const bool flag_fork = flag_join && want_flag_fork && !c.joint && !e->profiling && !no_ext_fork && e->fork_flag != nullptr && !edge_old_env() &&
+                         e->d <= 64 && e->k <= 64 && e->edge_kc >= e->k && e->ldk <= 128 && getenv("DIBS_DUP_EDGE") == nullptr;
   auto launch_edge = [&](hipStream_t st, hipEvent_t stop_ev, bool copy2 = false) {
     KTimer tm(e, DIBS_K_EDGE, st);
     const size_t lds = (size_t)2 * e->dpad * e->ldk * 4;
     if (!edge_old_env() && e->d <= 64 && e->k <= 64 && e->edge_kc >= e->k && e->ldk <= 128) {  // one 16-wave block per particle (k_edge_scores_p)
       allow_lds(k_edge_scores_p, lds);
+      unsigned int* const none = nullptr;
       if (copy2)  // (the second stream's own copy: scores / eas for the acyclicity kernel)
         hipLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, e->z, e->scores2, (uint32_t*)nullptr, (float*)nullptr, e->eas2, alpha,
-                           e->d, e->k, e->dpad, e->ldk);
+                           e->d, e->k, e->dpad, e->ldk, none, none, 0u);
+      else if (flag_fork)  // (the last block publishes fork_seq: k_wait_flag on the second stream)
+        hipLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, e->z, e->scores, e->thr, e->probs, e->eas, alpha, e->d,
+                           e->k, e->dpad, e->ldk, e->fork_flag + 1, e->fork_flag, ++e->fork_seq);
       else if (stop_ev)
         hipExtLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, nullptr, stop_ev, 0, e->z, e->scores, e->thr, e->probs,
-                              e->eas, alpha, e->d, e->k, e->dpad, e->ldk);
+                              e->eas, alpha, e->d, e->k, e->dpad, e->ldk, none, none, 0u);
       else
         hipLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, e->z, e->scores, e->thr, e->probs, e->eas, alpha, e->d,
-                           e->k, e->dpad, e->ldk);
+                           e->k, e->dpad, e->ldk, none, none, 0u);
       return;
     }
 
@@ -910,8 +929,13 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
       hipStreamWaitEvent(e->stream2, e->ev_z, 0);
       launch_edge(e->stream2, nullptr, true);
     } else {
-      if (!ext_fork) hipEventRecord(e->ev_fork, e->stream);
-      hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
+      if (flag_fork) {
+        const unsigned int delay = getenv("DIBS_FORK_DELAY") ? (unsigned int)atoi(getenv("DIBS_FORK_DELAY")) : 0u;
+        hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, e->stream2, (const unsigned int*)e->fork_flag, e->fork_seq, delay, e->join_err);
+      } else {
+        if (!ext_fork) hipEventRecord(e->ev_fork, e->stream);
+        hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
+      }
     }
     const AcycLaunch al{e->stream2, dup_edge ? e->scores2 : e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, Mg, e->Mloc, e->d, e->Sa,
                         e->acyc_cpb, e->acyc_units, e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr,

@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void k_edge_scores(const float* __restrict__ z
 // grid = Mloc, block = 1024; dynamic LDS = 2 * dpad * ldk * 4
 __global__ __launch_bounds__(1024) void k_edge_scores_p(const float* __restrict__ z, float* __restrict__ scores, uint32_t* __restrict__ thr,
                                                         float* __restrict__ probs, float* __restrict__ eas, float alpha, int d, int k,
-                                                        int dpad, int ldk) {
+                                                        int dpad, int ldk, unsigned int* __restrict__ done_ctr,
+                                                        unsigned int* __restrict__ done_flag, unsigned int done_seq) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Us = smem;
   float* Vs = smem + (size_t)dpad * ldk;
@@ -170,24 +171,39 @@ __global__ __launch_bounds__(1024) void k_edge_scores_p(const float* __restrict_
   }
   __syncthreads();
   const int t = wave;
-  if (t >= nt * nt) return;  // (wave-uniform; no barrier below)
-  const int ti = t / nt, tj = t - ti * nt, kp = (k + 3) & ~3;
-  const float* ua = Us + (size_t)(ti * 16 + (lane & 15)) * ldk + (lane >> 4);
-  const float* vb = Vs + (size_t)(tj * 16 + (lane & 15)) * ldk + (lane >> 4);
-  f32x4 a = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < kp; k0 += 4) a = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[k0], vb[k0], a, 0, 0, 0);
+  if (t < nt * nt) {  // (wave-uniform)
+    const int ti = t / nt, tj = t - ti * nt, kp = (k + 3) & ~3;
+    const float* ua = Us + (size_t)(ti * 16 + (lane & 15)) * ldk + (lane >> 4);
+    const float* vb = Vs + (size_t)(tj * 16 + (lane & 15)) * ldk + (lane >> 4);
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < kp; k0 += 4) a = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[k0], vb[k0], a, 0, 0, 0);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = ti * 16 + (lane >> 4) * 4 + r, col = tj * 16 + (lane & 15);
-    if (row < d && col < d) {
-      const float s = a[r];
-      const size_t o = ((size_t)m * d + row) * d + col;
-      scores[o] = s;
-      const double ex = exp(-(double)__fmul_rn(alpha, s));  // (the epilogue of k_edge_scores, operation for operation)
-      const float pf = (float)(1.0 / (1.0 + ex));
-      if (eas) eas[o] = (float)ex;
-      if (thr) thr[o] = row == col ? 0u : (uint32_t)ceilf(pf * 8388608.0f);  // (null: the copy of the second stream, scores / eas only)
-      if (probs) probs[o] = row == col ? 0.f : pf;
+    for (int r = 0; r < 4; ++r) {
+      const int row = ti * 16 + (lane >> 4) * 4 + r, col = tj * 16 + (lane & 15);
+      if (row < d && col < d) {
+        const float s = a[r];
+        const size_t o = ((size_t)m * d + row) * d + col;
+        const double ex = exp(-(double)__fmul_rn(alpha, s));  // (the epilogue of k_edge_scores, operation for operation)
+        const float pf = (float)(1.0 / (1.0 + ex));
+        if (done_ctr) {  // (what the second stream reads goes out at agent scope: see below)
+          __hip_atomic_store(scores + o, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (eas) __hip_atomic_store(eas + o, (float)ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          scores[o] = s;
+          if (eas) eas[o] = (float)ex;
+        }
+        if (thr) thr[o] = row == col ? 0u : (uint32_t)ceilf(pf * 8388608.0f);  // (null: the copy of the second stream, scores / eas only)
+        if (probs) probs[o] = row == col ? 0.f : pf;
+      }
+    }
+  }
+  // done_ctr != null: the fork to the engine's second stream without an event (k_wait_flag there polls done_flag): scores / eas were stored at
+  // agent scope (complete once the barrier has drained vmcnt), every block counts itself, the last one publishes the step's sequence number
+  if (done_ctr) {
+    __syncthreads();
+    if (tid == 0 && atomicAdd(done_ctr, 1u) == gridDim.x - 1u) {
+      atomicExch(done_ctr, 0u);  // (the next launch of this kernel is behind this one in its stream)
+      __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

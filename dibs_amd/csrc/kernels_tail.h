@@ -92,6 +92,22 @@ __global__ void k_probe_wait(const unsigned int* flag, unsigned int* seen) {
   *seen = v;
 }
 __global__ void k_probe_set(unsigned int* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one wave, FIRST on the second stream of a step (fork without an event): waits until k_edge_scores_p's last block has published `seq`,
+// then `delay` more ticks (100 MHz; DIBS_FORK_DELAY, default 0: measured, no gain once the stream has the lowest priority).  One polling
+// wave leaves the machine to the kernels it waits for; the kernels behind it start with the usual acquire.  Bounded like tail_join_wait.
+__global__ void k_wait_flag(const unsigned int* flag, unsigned int seq, unsigned int delay, unsigned int* err) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long t0 = wall_clock64();
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+    __builtin_amdgcn_s_sleep(2);
+    if (wall_clock64() - t0 > 20000000ull) {
+      if (err) *err = 2u;
+      break;
+    }
+  }
+  const unsigned long long t1 = wall_clock64();
+  while (wall_clock64() - t1 < delay) __builtin_amdgcn_s_sleep(1);
+}
 // one thread, last on the second stream
 // (RELAXED: the end of the kernel in front of this one has already released its stores; a release here would write the L2 back once more --
 //  the one-thread kernel took 4.4 us with it)
