@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <string>
 #include <vector>
 #include <utility>
@@ -192,6 +193,12 @@ static hipError_t dalloc(T** p, size_t n) {
   return e;
 }
 
+// Engines alive in this process.  The in-kernel flags (fork: k_wait_flag, join: tail_join_wait) are used by an engine that is ALONE in its
+// process -- the production layout, one process per GPU: its two or three streams have a hardware queue each.  Several engines in one process
+// (the single-GPU emulation of a sharded run, tests with rank engines) share hardware queues, and a polling kernel at the head of a shared
+// queue holds up the kernels behind it, possibly the one it waits for, until its bound: those engines use events.  DIBS_FLAGS_MULTI=1 lifts
+// the rule (scripts/gpu_shard_scaling.py: what a rank of a real run would do).
+static std::atomic<int> g_live_engines{0};
 extern "C" int dibs_engine_destroy(dibs_engine* e);
 extern "C" int dibs_engine_comm_destroy(dibs_engine* e);
 // sizes, stream, events and every device buffer of a new engine; on failure the caller destroys the half-built engine
@@ -450,6 +457,7 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
     return fail(std::string("libdibs_hip is built for gfx950 only; device is ") + prop.gcnArchName);
 
   dibs_engine* e = new dibs_engine();  // value-initialised: every POD member starts at zero
+  g_live_engines.fetch_add(1);
   if (engine_alloc(e, c, stream)) {
     const std::string msg = g_err;
     dibs_engine_destroy(e);  // frees whatever had been allocated (stream, events, buffers)
@@ -462,6 +470,7 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
 
 extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (!e) return 0;
+  g_live_engines.fetch_sub(1);
   hipSetDevice(e->cfg.device_id);
   if (e->stream) hipStreamSynchronize(e->stream);
   if (e->stream2) hipStreamSynchronize(e->stream2);
@@ -867,7 +876,9 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
   // the flag is used only while they cannot fill the machine (<= 128 particles: one block each on half of the CUs) and the two streams
   // were seen to run concurrently (streams_concurrent; not under a serialising profiler); otherwise the event.  The wait is bounded
   // (join_err).  Per-kernel timing always uses the event.
-  const bool flag_join = fork && !join_now && want_flag_join && e->join_flag != nullptr && e->streams_concurrent && e->Mloc <= 128;
+  static const bool flags_multi = getenv("DIBS_FLAGS_MULTI") != nullptr;
+  const bool flag_join = fork && !join_now && want_flag_join && e->join_flag != nullptr && e->streams_concurrent && e->Mloc <= 128 &&
+                         (flags_multi || g_live_engines.load() == 1);
   // where this step's kernel matrices come from (single rank): the joint models and many particles put them on the second stream behind the
   // acyclicity chain (kmat_on_s2, see below); otherwise the latent matrix rides inside k_bge_sample
   const bool kmat_on_s2 = c.joint || (long)e->M * e->D > 4L * e->S * e->d * e->d;

@@ -2,6 +2,7 @@
 follow the real trajectory to t=T0, then rank 0 alone is timed (wall clock and per kernel) against frozen rows of the others.
 Gives the compute+launch side of strong scaling; the all-gather (E*M*4 bytes per step) comes on top."""
 import os, sys, time
+os.environ.setdefault("DIBS_FLAGS_MULTI", "1")  # R rank engines in ONE process: use the in-kernel flags as a rank alone in its process would
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
