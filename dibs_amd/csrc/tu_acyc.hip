@@ -141,7 +141,8 @@ void acyc_launch_power(const AcycLaunch& a) {
     // product level, i.e. -(d - 1) 1.15e-7 = -1.0e-5 at d = 80, which the kernel compensates to first order (residual 4e-6).  The
     // wider sizes stay on the three-piece bf16 kernel.
     static const bool bf16w = getenv("DIBS_ACYC_BF16") != nullptr;
-    if (!bf16w && a.d <= 80) {
+    const char* hm = getenv("DIBS_ACYC_HFW_MAX");  // (tuning / test override, read per launch)
+    if (!bf16w && a.d <= (hm ? atoi(hm) : 80)) {
       switch ((a.d + 15) / 16) {
         case 5: launch_hfw<5>(a); break;
         case 6: launch_hfw<6>(a); break;
