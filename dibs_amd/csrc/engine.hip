@@ -1236,7 +1236,10 @@ static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_s
 // after a chunk has been synchronised: did a k_particle_grad give up waiting for the second stream (tail_join_wait)?
 static int check_join(dibs_engine* e) {
   if (e->join_err && *e->join_err) {
+    const unsigned int code = *e->join_err;
     *e->join_err = 0u;
+    if (code == 2u)
+      return fail("internal: the edge kernel's completion flag did not arrive (k_wait_flag on the second stream timed out; results of this chunk are invalid)");
     return fail("internal: the acyclicity stream's completion flag did not arrive (k_particle_grad timed out waiting; results of this chunk are invalid)");
   }
   return 0;
