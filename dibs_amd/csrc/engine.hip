@@ -396,13 +396,9 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
   // 113 .. 256 variables: the LDS-resident kernels give way to the global-memory paths (kernels_acyc_big.h, k_backproject_big, chunked
   // k_edge_scores, k_bge_chol_wide)
   if (c.n_vars > 112) {
-    const size_t dd4 = (size_t)c.n_vars * c.n_vars * 4;
-    // the joint models run on their general paths there: LinearGaussian on the Gram-matrix kernels (two d x d float operands in LDS:
-    // n_vars <= 141), DenseNonlinearGaussian on kernels_nn_generic.h (one: n_vars <= 198); soft-graph BGe has its own limit below
-    if (c.likelihood == DIBS_LIK_LINGAUSS && 2 * dd4 + 256 > LDS_LIMIT - 1024)
-      return fail("JointDiBS + LinearGaussian: n_vars <= 141 (two n_vars x n_vars operands of the Gram-matrix kernels in LDS)");
-    if (c.likelihood == DIBS_LIK_DENSENN && dd4 + 256 > LDS_LIMIT - 1024)
-      return fail("JointDiBS + DenseNonlinearGaussian: n_vars <= 198 (the sampled graph of the general path in LDS)");
+    // the joint models run on their general paths there: LinearGaussian on the Gram-matrix kernels, DenseNonlinearGaussian on
+    // kernels_nn_generic.h; beyond the LDS capacity (two n_vars x n_vars float operands: 141, one: 198) the blocks keep them in global
+    // scratch (round 5: the limits of 141 / 198 variables are gone); soft-graph BGe has its own limit below
   }
   if (c.n_dim < 1) return fail("n_dim must be >= 1");
   if (c.n_particles < 1 || c.n_grad_mc_samples < 1 || c.n_acyclicity_mc_samples < 1) return fail("sizes must be >= 1");

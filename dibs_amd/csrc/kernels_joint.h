@@ -38,7 +38,21 @@ struct JointWork {
   bool nhf_valid, nhx_valid;
   float* nng_scratch;         // general DenseNN path (kernels_nn_generic.h): activation records, grown on first use
   size_t nng_scratch_floats;
+  // general paths beyond the LDS capacity (LinearGaussian Gram kernels: n_vars > 141 / 198, DenseNN general kernels: n_vars > 198): the
+  // sampled graph (and the masked weights) of a block live here instead of in LDS; grown on first use
+  float* gs_scratch;
+  size_t gs_scratch_floats;
 };
+static inline float* joint_gs_scratch(JointWork* w, size_t floats) {
+  if (w->gs_scratch_floats < floats) {
+    if (w->gs_scratch) hipFree(w->gs_scratch);
+    w->gs_scratch = nullptr;
+    w->gs_scratch_floats = 0;
+    if (hipMalloc((void**)&w->gs_scratch, floats * 4) != hipSuccess) return nullptr;
+    w->gs_scratch_floats = floats;
+  }
+  return w->gs_scratch;
+}
 
 struct JointLaunch {
   hipStream_t stream;
@@ -970,6 +984,9 @@ static size_t ling_lds(int d, int n_gram, bool grad) {
   const size_t dd = (size_t)d * d;
   return (n_gram == 1 ? dd * 8 : 0) + (((grad ? 2 : 1) * dd * 4 + 15) & ~(size_t)15) + 128;
 }
+// the operands of a block (masked weights; for the gradient kernel the graph as well) beyond the LDS capacity: global scratch
+// (n_vars > 198 for the log-probabilities, > 141 for the gradients)
+static bool ling_ops_global(int d, bool grad) { return ling_lds(d, -1, grad) > (size_t)160 * 1024 - 1024; }
 // the n_gram argument of the Gram kernels: a single matrix stays in LDS only while it fits beside the operands (d <= 101 for the gradient
 // kernel); beyond that it is read through the caches (-1).  (Found by tests/tools/gpu_fuzz.py: d = 112 with 500 observations failed to launch.)
 static int ling_ngram_arg(int d, int n_gram, bool grad) {
@@ -985,6 +1002,8 @@ int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) {
   w->any_mask = 0;
   w->nng_scratch = nullptr;
   w->nng_scratch_floats = 0;
+  w->gs_scratch = nullptr;
+  w->gs_scratch_floats = 0;
   w->nhf_w1s = w->nhf_w1p = nullptr;
   w->nhf_ew = nullptr;
   w->nhf_pairs = 0;
@@ -1007,6 +1026,9 @@ void joint_free(JointWork* w) {
   w->w1t = nullptr;
   w->w1t_floats = 0;
   if (w->nng_scratch) hipFree(w->nng_scratch);
+  if (w->gs_scratch) hipFree(w->gs_scratch);
+  w->gs_scratch = nullptr;
+  w->gs_scratch_floats = 0;
   if (w->nhf_w1s) hipFree(w->nhf_w1s);
   if (w->nhf_w1p) hipFree(w->nhf_w1p);
   if (w->nhf_ew) hipFree(w->nhf_ew);
@@ -1140,15 +1162,20 @@ static void joint_lin_grads(JointWork* w, const JointLaunch& jl, Key2 carry_thet
 void joint_lin_all_logprobs(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z) {
   const int mz = jl.est_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM;
   if (w->n_gram) {  // Gram-matrix path (x does not fit LDS)
-    const int ng = ling_ngram_arg(jl.d, w->n_gram, false);
-    const size_t lds = ling_lds(jl.d, ng, false);
+    const bool glob = ling_ops_global(jl.d, false);
+    const int ng = glob ? (w->n_gram == 1 ? -1 : w->n_gram) : ling_ngram_arg(jl.d, w->n_gram, false);
+    const size_t lds = glob ? 256 : ling_lds(jl.d, ng, false);
+    // (global operands: a bounded number of blocks per particle loop over the samples, each with its own d x d scratch)
+    const int gx = glob ? (jl.S < 1024 / jl.Mloc ? jl.S : (1024 / jl.Mloc > 1 ? 1024 / jl.Mloc : 1)) : jl.S;
+    float* gs = glob ? joint_gs_scratch(w, (size_t)gx * jl.Mloc * jl.d * jl.d) : nullptr;
+    if (glob && !gs) return;  // (allocation failure: the launch error check of the step reports hipErrorOutOfMemory)
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_ling_logprobs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_ling_logprobs, dim3(jl.S, jl.Mloc), dim3(256), lds, jl.stream, w->gram, w->ncnt, ng, jl.theta, jl.scores, jl.thr,
+    hipLaunchKernelGGL(k_ling_logprobs, dim3(gx, jl.Mloc), dim3(256), lds, jl.stream, w->gram, w->ncnt, ng, jl.theta, jl.scores, jl.thr,
                        jl.logprobs_th, carry_theta, (int)LIN_MODE_THETA, jl.m0, jl.M, jl.d, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise,
-                       jl.mean_edge, jl.sig_edge);
-    hipLaunchKernelGGL(k_ling_logprobs, dim3(jl.S, jl.Mloc), dim3(256), lds, jl.stream, w->gram, w->ncnt, ng, jl.theta, jl.scores, jl.thr,
+                       jl.mean_edge, jl.sig_edge, gs);
+    hipLaunchKernelGGL(k_ling_logprobs, dim3(gx, jl.Mloc), dim3(256), lds, jl.stream, w->gram, w->ncnt, ng, jl.theta, jl.scores, jl.thr,
                        jl.logprobs_z, carry_z, mz, jl.m0, jl.M, jl.d, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise, jl.mean_edge,
-                       jl.sig_edge);
+                       jl.sig_edge, gs);
     return;
   }
 #define LIN_CALL(NT_) { joint_lin_logprobs<NT_>(w, jl, carry_theta, LIN_MODE_THETA); joint_lin_logprobs<NT_>(w, jl, carry_z, mz); }
@@ -1158,15 +1185,18 @@ void joint_lin_all_logprobs(JointWork* w, const JointLaunch& jl, Key2 carry_thet
 // both softmax-weighted gradients in one launch
 void joint_lin_all_grads(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z) {
   if (w->n_gram) {
-    const int ng = ling_ngram_arg(jl.d, w->n_gram, true);
-    const size_t lds = ling_lds(jl.d, ng, true);
+    const bool glob = ling_ops_global(jl.d, true);
+    const int ng = glob ? (w->n_gram == 1 ? -1 : w->n_gram) : ling_ngram_arg(jl.d, w->n_gram, true);
+    const size_t lds = glob ? 256 : ling_lds(jl.d, ng, true);
+    float* gs = glob ? joint_gs_scratch(w, (size_t)2 * jl.Mloc * 2 * jl.d * jl.d) : nullptr;
+    if (glob && !gs) return;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_ling_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const LinGradJob jt{jl.logprobs_th, jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off, jl.pack_stride,
                         jl.copy_theta ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr, nullptr, carry_theta, LIN_MODE_THETA};
     const LinGradJob jz{jl.logprobs_z, jl.w_lik, (size_t)jl.d * jl.d, nullptr, jl.baseline_out, carry_z,
                         jl.est_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM};
     hipLaunchKernelGGL(k_ling_grad, dim3(jl.Mloc, 2), dim3(256), lds, jl.stream, w->gram, ng, jl.theta, jl.scores, jl.thr, jt, jz, jl.baseline,
-                       jl.m0, jl.M, jl.d, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise, jl.mean_edge, jl.sig_edge, jl.sf_baseline);
+                       jl.m0, jl.M, jl.d, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise, jl.mean_edge, jl.sig_edge, jl.sf_baseline, gs);
     return;
   }
 #define LIN_CALL(NT_) joint_lin_grads<NT_>(w, jl, carry_theta, carry_z)
@@ -1187,12 +1217,15 @@ static void launch_lin_given(const JointWork& jw, const float* theta, const int3
 void joint_lin_score_given(const JointWork& jw, const float* theta, const int32_t* g, float* out, int n, int d, int N, float obs_noise,
                            float mean_edge, float sig_edge, hipStream_t stream) {
   if (jw.n_gram) {
-    const int ng = ling_ngram_arg(d, jw.n_gram, false);
-    const size_t lds = ling_lds(d, ng, false);
+    const bool glob = ling_ops_global(d, false);
+    const int ng = glob ? (jw.n_gram == 1 ? -1 : jw.n_gram) : ling_ngram_arg(d, jw.n_gram, false);
+    const size_t lds = glob ? 256 : ling_lds(d, ng, false);
+    float* gs = glob ? joint_gs_scratch(const_cast<JointWork*>(&jw), (size_t)n * d * d) : nullptr;
+    if (glob && !gs) return;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_ling_logprobs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_ling_logprobs, dim3(1, n), dim3(256), lds, stream, jw.gram, jw.ncnt, ng, theta, (const float*)nullptr,
                        reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, 1, 0.f, 1.f, 0, 0, obs_noise, mean_edge,
-                       sig_edge);
+                       sig_edge, gs);
     return;
   }
   switch ((d + 15) / 16) {

@@ -28,20 +28,23 @@ __device__ __forceinline__ void ling_cw(const double* __restrict__ Cs, const dou
 
 // ------------------------------------------------------------------------------------------------
 // log p(theta, D | G_s), one sample per block.  grid = (S, Mloc) [mode GIVEN: (1, n graphs)], block = 256
-// dynamic LDS = d*d*4 (W) + (n_gram == 1 ? d*d*8 : 0) (C) + 64;  n_gram: 1 = one Gram matrix, LDS-resident; d = one per node (interventions);
+// dynamic LDS = d*d*4 (W) + (n_gram == 1 ? d*d*8 : 0) (C) + 64 (ops_glob: 256, grid.x <= S);  n_gram: 1 = one Gram matrix, LDS-resident; d = one per node (interventions);
 // -1 = one matrix that does not fit LDS beside the operands (d > 100), read through the caches
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ling_logprobs(const double* __restrict__ gram, const double* __restrict__ ncnt, int n_gram,
                                                        const float* __restrict__ theta, const float* __restrict__ scores,
                                                        const uint32_t* __restrict__ thr, float* __restrict__ logprobs, Key2 carry, int mode,
                                                        int m0, int M_global, int d, int S, float alpha, float tau, int layout, int tiny,
-                                                       float obs_noise, float mu, float sig) {
+                                                       float obs_noise, float mu, float sig, float* __restrict__ ops_glob) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* Cs = reinterpret_cast<double*>(smem_raw);
   const size_t dd = (size_t)d * d;
-  float* WG = reinterpret_cast<float*>(smem_raw + (n_gram == 1 ? dd * 8 : 0));
-  double* red = reinterpret_cast<double*>(smem_raw + (n_gram == 1 ? dd * 8 : 0) + ((dd * 4 + 15) & ~(size_t)15));
-  const int m = blockIdx.y, s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ops_glob != null (n_vars > 198): the masked weights of this block in global scratch [gridDim.y][gridDim.x][d*d] instead of LDS (the block's
+  // own barriers order its writes and reads), LDS holds the reduction slots only; the block then loops over the samples s, s + gridDim.x, ...
+  float* WG = ops_glob ? ops_glob + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * dd : reinterpret_cast<float*>(smem_raw + (n_gram == 1 ? dd * 8 : 0));
+  double* red = ops_glob ? reinterpret_cast<double*>(smem_raw)
+                         : reinterpret_cast<double*>(smem_raw + (n_gram == 1 ? dd * 8 : 0) + ((dd * 4 + 15) & ~(size_t)15));
+  const int m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* TH = theta + (size_t)m * dd;
   const Key2 key = (mode == LIN_MODE_GIVEN) ? Key2{0, 0} : lin_mode_key(mode, carry, M_global, m0 + m, layout);
   const uint64_t nbits = (uint64_t)S * dd;
@@ -49,6 +52,7 @@ __global__ __launch_bounds__(256) void k_ling_logprobs(const double* __restrict_
   const float* sc_m = scores ? scores + (size_t)m * dd : nullptr;
   if (n_gram == 1)
     for (int e = tid; e < (int)dd; e += 256) Cs[e] = gram[e];
+  for (int s = blockIdx.x; s < S; s += gridDim.x) {
   double part = 0.0;
   for (int e = tid; e < (int)dd; e += 256) {
     const int a = e / d, j = e - a * d;
@@ -72,6 +76,8 @@ __global__ __launch_bounds__(256) void k_ling_logprobs(const double* __restrict_
   if (lane == 0) red[wave] = tot;
   __syncthreads();
   if (tid == 0) logprobs[(size_t)m * S + s] = (float)(red[0] + red[1] + red[2] + red[3]);
+  __syncthreads();  // (the operands and the reduction slots are rewritten by the next sample of this block)
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -82,15 +88,17 @@ __global__ __launch_bounds__(256) void k_ling_grad(const double* __restrict__ gr
                                                    const float* __restrict__ scores, const uint32_t* __restrict__ thr, LinGradJob job0,
                                                    LinGradJob job1, const float* __restrict__ baseline, int m0, int M_global, int d, int S,
                                                    float alpha, float tau, int layout, int tiny, float obs_noise, float mu, float sig,
-                                                   double sf_baseline) {
+                                                   double sf_baseline, float* __restrict__ ops_glob) {
   const LinGradJob job = blockIdx.y ? job1 : job0;
   const int mode = job.mode;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* Cs = reinterpret_cast<double*>(smem_raw);
   const size_t dd = (size_t)d * d;
-  float* WG = reinterpret_cast<float*>(smem_raw + (n_gram == 1 ? dd * 8 : 0));
+  // (ops_glob != null, n_vars > 141: masked weights and graph of this block in global scratch [gridDim.y][gridDim.x][2][d*d], see k_ling_logprobs)
+  float* WG = ops_glob ? ops_glob + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * dd : reinterpret_cast<float*>(smem_raw + (n_gram == 1 ? dd * 8 : 0));
   float* GS = WG + dd;
-  double* red = reinterpret_cast<double*>(smem_raw + (n_gram == 1 ? dd * 8 : 0) + ((2 * dd * 4 + 15) & ~(size_t)15));
+  double* red = ops_glob ? reinterpret_cast<double*>(smem_raw)
+                         : reinterpret_cast<double*>(smem_raw + (n_gram == 1 ? dd * 8 : 0) + ((2 * dd * 4 + 15) & ~(size_t)15));
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* TH = theta + (size_t)m * dd;
   float* om = job.out + (size_t)m * job.out_stride;

@@ -809,24 +809,30 @@ static int nng_blocks(long work) { return (int)(work < 2048 ? work : 2048); }
 
 static int joint_nng_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_) {
   const NNNet net = nn_net(jl.d, np_);
-  const size_t lds = (((size_t)jl.d * jl.d + 3) & ~(size_t)3) * 4 + 128;
+  size_t lds = (((size_t)jl.d * jl.d + 3) & ~(size_t)3) * 4 + 128;
   const int nb = nng_blocks((long)jl.S * jl.Mloc);
   const size_t need1 = (size_t)nb * 256 * net.hsum, need2 = (size_t)jl.Mloc * 2 * net.hsum * jl.d * jl.N;
   float* scr = nng_scratch(w, need1 > need2 ? need1 : need2);
   if (!scr) return 1;
+  float* gs = nullptr;  // (n_vars > 198: the sampled graph of a block does not fit LDS -- global scratch)
+  if (lds > (size_t)160 * 1024 - 1024) {
+    gs = joint_gs_scratch(w, (size_t)(nb > jl.Mloc ? nb : jl.Mloc) * jl.d * jl.d);
+    if (!gs) return 1;
+    lds = 256;
+  }
   float* lp = mode == LIN_MODE_THETA ? jl.logprobs_th : jl.logprobs_z;
   if (lds > 48 * 1024) {
     hipFuncSetAttribute((const void*)k_nng_logprobs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void*)k_nng_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   hipLaunchKernelGGL(k_nng_logprobs, dim3(nb), dim3(256), lds, jl.stream, w->x, w->mask, jl.theta, jl.scores, jl.thr, lp, carry, mode,
-                     jl.m0, jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, w->any_mask, scr, jl.Mloc);
+                     jl.m0, jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, w->any_mask, scr, jl.Mloc, gs);
   float* out = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off : jl.w_lik;
   const size_t ostride = mode == LIN_MODE_THETA ? jl.pack_stride : (size_t)jl.d * jl.d;
   float* tcopy = (mode == LIN_MODE_THETA && jl.copy_theta) ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr;
   hipLaunchKernelGGL(k_nng_grad, dim3(jl.Mloc), dim3(256), lds, jl.stream, w->x, w->mask, jl.theta, jl.scores, jl.thr, lp, out, ostride, tcopy,
                      jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S,
-                     jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask, scr);
+                     jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask, scr, gs);
   return 0;
 }
 
@@ -859,13 +865,19 @@ int joint_nn_score_given(const JointWork& jw, const float* theta, const int32_t*
                          size_t P, hipStream_t stream) {
   if (!joint_nn_fast_path(d, N, np_)) {
     const NNNet net = nn_net(d, np_);
-    const size_t lds = (((size_t)d * d + 3) & ~(size_t)3) * 4 + 128;
+    size_t lds = (((size_t)d * d + 3) & ~(size_t)3) * 4 + 128;
     const int nb = nng_blocks(n);
     float* scr = nng_scratch(const_cast<JointWork*>(&jw), (size_t)nb * 256 * net.hsum);
     if (!scr) return 1;
+    float* gs = nullptr;
+    if (lds > (size_t)160 * 1024 - 1024) {
+      gs = joint_gs_scratch(const_cast<JointWork*>(&jw), (size_t)nb * d * d);
+      if (!gs) return 1;
+      lds = 256;
+    }
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_nng_logprobs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_nng_logprobs, dim3(nb), dim3(256), lds, stream, jw.x, jw.mask, theta, (const float*)nullptr,
-                       reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, N, 1, 0.f, 1.f, 0, 0, np_, jw.any_mask, scr, n);
+                       reinterpret_cast<const uint32_t*>(g), out, Key2{0, 0}, (int)LIN_MODE_GIVEN, 0, n, d, N, 1, 0.f, 1.f, 0, 0, np_, jw.any_mask, scr, n, gs);
     return 0;
   }
   switch ((d + 15) / 16) {

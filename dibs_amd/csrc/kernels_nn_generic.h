@@ -86,10 +86,13 @@ __global__ __launch_bounds__(256) void k_nng_logprobs(const float* __restrict__ 
                                                       const float* __restrict__ theta, const float* __restrict__ scores,
                                                       const uint32_t* __restrict__ thr, float* __restrict__ logprobs, Key2 carry, int mode,
                                                       int m0, int M_global, int d, int N, int S, float alpha, float tau, int layout,
-                                                      int tiny, NNParams np_, int any_mask, float* __restrict__ scratch, int n_m) {
+                                                      int tiny, NNParams np_, int any_mask, float* __restrict__ scratch, int n_m,
+                                                      float* __restrict__ gs_glob) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* GS = smem;
-  double* red = reinterpret_cast<double*>(smem + (((size_t)d * d + 3) & ~(size_t)3));
+  // (gs_glob != null, n_vars > 198: the sampled graph of this block in global scratch [gridDim.x][d*d] instead of LDS; the block's own
+  //  barriers order its writes and reads)
+  float* GS = gs_glob ? gs_glob + (size_t)blockIdx.x * d * d : smem;
+  double* red = reinterpret_cast<double*>(gs_glob ? smem : smem + (((size_t)d * d + 3) & ~(size_t)3));
   const NNNet net = nn_net(d, np_);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t dd = (size_t)d * d;
@@ -152,10 +155,11 @@ __global__ __launch_bounds__(256) void k_nng_grad(const float* __restrict__ x, c
                                                   float* __restrict__ out, size_t out_stride, float* __restrict__ theta_copy,
                                                   const float* __restrict__ baseline, float* __restrict__ baseline_out, Key2 carry, int mode,
                                                   int m0, int M_global, int d, int N, int S, float alpha, float tau, int layout, int tiny,
-                                                  NNParams np_, double sf_baseline, int any_mask, float* __restrict__ scratch) {
+                                                  NNParams np_, double sf_baseline, int any_mask, float* __restrict__ scratch,
+                                                  float* __restrict__ gs_glob) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* GS = smem;
-  double* red = reinterpret_cast<double*>(smem + (((size_t)d * d + 3) & ~(size_t)3));
+  float* GS = gs_glob ? gs_glob + (size_t)blockIdx.x * d * d : smem;  // (see k_nng_logprobs)
+  double* red = reinterpret_cast<double*>(gs_glob ? smem : smem + (((size_t)d * d + 3) & ~(size_t)3));
   const NNNet net = nn_net(d, np_);
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t dd = (size_t)d * d, NI = (size_t)d * N;

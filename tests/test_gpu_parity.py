@@ -474,7 +474,10 @@ def _lingauss_step_stages(c_oracle64, d, M, S, Sa, est, prior, interv, steps):
     (112, 2, 8, 4, "score", False, 500, False),     # one Gram matrix that no longer fits LDS beside the operands (d > 100): read through the caches
     (104, 2, 8, 4, "reparam", False, 300, False),   # (launch failure found by tests/tools/gpu_fuzz.py)
     (128, 2, 8, 2, "reparam", True, 300, False),    # > 112 variables: Gram path + the global-memory acyclicity / back-projection kernels
-    (140, 2, 4, 2, "score", False, 200, False),     # close to the limit of the two LDS operands (141)
+    (140, 2, 4, 2, "score", False, 200, False),     # the last size with both operands of the gradient kernel in LDS (141)
+    (150, 2, 4, 2, "reparam", False, 200, False),   # round 5: graph + masked weights of the gradient kernel in global scratch (142 .. 198)
+    (200, 2, 4, 2, "score", True, 250, False),      # ... and the masked weights of the log-prob kernel too (> 198); one Gram matrix per node
+    (256, 2, 2, 2, "reparam", False, 300, False),   # engine maximum
 ])
 def test_joint_lingauss_gram_path(c_oracle64, monkeypatch, d, M, S, Sa, est, interv, N, force):
     """LinearGaussian for any number of observations (linearGaussian.py:292-316): the Gram-matrix path of kernels_lin_gram.h,
@@ -683,6 +686,8 @@ def test_joint_densenn_step_stages(c_oracle64, d, M, S, Sa, H, act, bias, est, i
     (20, 3, 16, 4, (32,), "relu", True, "reparam", False, (2,), 60),        # (32,): MFMA path, listed next to (8, 8) for comparison
     (7, 2, 8, 2, (4, 4, 3, 3, 2, 2), "tanh", True, "reparam", True, (1,), 30),   # six hidden layers (the config struct carries up to eight)
     (128, 2, 4, 2, (4,), "relu", True, "reparam", True, (1,), 60),               # > 112 variables: general path + global-memory kernels
+    (200, 2, 2, 2, (3,), "relu", True, "reparam", False, (1,), 40),              # round 5, > 198 variables: the sampled graph of a block in global scratch
+    (256, 2, 2, 2, (2,), "tanh", False, "score", True, (1,), 30),                # engine maximum
 ])
 def test_joint_densenn_general_stacks(c_oracle64, d, M, S, Sa, hidden, act, bias, est, interv, steps, N):
     """DenseNonlinearGaussian with an arbitrary tuple of hidden layers / width / observation count (nonlinearGaussian.py:35-81,
