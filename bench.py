@@ -97,7 +97,7 @@ def roofline_of(dom, avg_s, cfgname, M, K, eng_counters):
             roof.update(rocprof_kernel=f"k_acyc_bf<{'true' if d > 48 else 'false'}>", pipe="mfma_bf16 (3-way split operands: 6 bf16 products per f32 product)",
                         pipe_mantissa_bits=24, executed_bf16_tflops=bf16_flops / avg_s / 1e12, peak_bf16_tflops=PEAK_BF16_TFLOPS,
                         frac_of_bf16_peak=bf16_flops / avg_s / 1e12 / PEAK_BF16_TFLOPS)
-        elif 32 < d <= 80 and not os.environ.get("DIBS_ACYC_F32"):
+        elif 32 < d <= int(os.environ.get("DIBS_ACYC_HFW_MAX", "112")) and not os.environ.get("DIBS_ACYC_F32") and not (d > 64 and os.environ.get("DIBS_ACYC_BF16")):
             # float products evaluated on the f16 matrix pipe with two block-scaled pieces per operand (3 f16 MFMAs of 16 cycles per
             # 16 x 16 x 32 block, kernels_acyc_f16.h).  `achieved` / `frac` price the ALGORITHMIC float flops against the FP32 peak; the f16
             # flops the kernel actually issues (16-padded tiles, 32-padded contraction, 3 products) against the dense 16-bit peak next to it.
@@ -110,7 +110,7 @@ def roofline_of(dom, avg_s, cfgname, M, K, eng_counters):
                         executed_f16_tflops=f16_flops / avg_s / 1e12, peak_f16_tflops=PEAK_BF16_TFLOPS,
                         frac_of_f16_peak=f16_flops / avg_s / 1e12 / PEAK_BF16_TFLOPS)
         elif 80 < d <= 112 and not os.environ.get("DIBS_ACYC_F32"):
-            nt = (d + 15) // 16   # three-piece bf16 kernel (the two-piece f16 scheme's truncation bias ~ (d - 1) 1e-7 exceeds 1e-5 there)
+            nt = (d + 15) // 16   # three-piece bf16 kernel (DIBS_ACYC_HFW_MAX=80 / DIBS_ACYC_BF16=1; the default there is the f16 kernel above since round 5)
             bf16_flops = M * SA_MC * n_mm * 6 * 2 * (16 * nt) ** 3
             roof.update(rocprof_kernel=f"k_acyc_bfw<{nt}>", pipe="mfma_bf16 (3-way split operands: 6 bf16 products per f32 product)", pipe_mantissa_bits=24,
                         executed_bf16_tflops=bf16_flops / avg_s / 1e12, peak_bf16_tflops=PEAK_BF16_TFLOPS,

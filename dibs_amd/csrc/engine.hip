@@ -893,6 +893,10 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
   static const bool want_flag_fork = getenv("DIBS_NO_FLAG_FORK") == nullptr;
   const bool flag_fork = flag_join && want_flag_fork && !c.joint && !e->profiling && !no_ext_fork && e->fork_flag != nullptr && !edge_old_env() &&
                          e->d <= 64 && e->k <= 64 && e->edge_kc >= e->k && e->ldk <= 128 && getenv("DIBS_DUP_EDGE") == nullptr;
+  // BGe with the score estimator: the flag is published by the FIRST BLOCK OF k_bge_sample instead (it starts when the edge kernel has ended and
+  // released its plain stores): no agent-scope stores and no counting in the edge kernel (DIBS_FORK_PUB_EDGE=1: publish from the edge kernel)
+  const bool fork_pub_in_sample = flag_fork && do_lik && c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_SCORE &&
+                                  !getenv("DIBS_FORK_PUB_EDGE");
   auto launch_edge = [&](hipStream_t st, hipEvent_t stop_ev, bool copy2 = false) {
     KTimer tm(e, DIBS_K_EDGE, st);
     const size_t lds = (size_t)2 * e->dpad * e->ldk * 4;
@@ -902,7 +906,11 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
       if (copy2)  // (the second stream's own copy: scores / eas for the acyclicity kernel)
         hipLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, e->z, e->scores2, (uint32_t*)nullptr, (float*)nullptr, e->eas2, alpha,
                            e->d, e->k, e->dpad, e->ldk, none, none, 0u);
-      else if (flag_fork)  // (the last block publishes fork_seq: k_wait_flag on the second stream)
+      else if (flag_fork && fork_pub_in_sample) {
+        ++e->fork_seq;
+        hipLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, e->z, e->scores, e->thr, e->probs, e->eas, alpha, e->d,
+                           e->k, e->dpad, e->ldk, none, none, 0u);
+      } else if (flag_fork)  // (the last block publishes fork_seq: k_wait_flag on the second stream)
         hipLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, e->z, e->scores, e->thr, e->probs, e->eas, alpha, e->d,
                            e->k, e->dpad, e->ldk, e->fork_flag + 1, e->fork_flag, ++e->fork_seq);
       else if (stop_ev)
@@ -1008,12 +1016,16 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
     const BgeParams bp = e->bge.params();
     {  // (queue counters: zero at creation, reset by k_particle_grad at the end of every step)
       KTimer tm(e, DIBS_K_BGE_NODES);
-      KmatFuse kf{nullptr, nullptr, 0, 0, 0, 0.f, 0.f};
+      KmatFuse kf{nullptr, nullptr, 0, 0, 0, 0.f, 0.f, nullptr, 0u};
       e->kmat_fused = false;
       // single rank, vector fits one LDS chunk: the latent kernel matrix rides along (see KmatFuse)
       if (!tile_in_grad && !kmat_tiled_on(e) && !xk && !e->kmat_early && !e->kmat_ext && e->Mloc == e->M && e->D <= KMAT_CH && (size_t)e->D * 4 + 64 <= 80 * 1024 && !getenv("DIBS_NO_KMAT_FUSE")) {
-        kf = KmatFuse{e->z, e->kz, (int)e->D, e->M, (e->d + 3) / 4, (float)c.scale_latent, (float)c.h_latent};
+        kf = KmatFuse{e->z, e->kz, (int)e->D, e->M, (e->d + 3) / 4, (float)c.scale_latent, (float)c.h_latent, nullptr, 0u};
         e->kmat_fused = true;
+      }
+      if (fork_pub_in_sample) {  // (the edge kernel stored plainly and published nothing: this launch's first block does, see KmatFuse)
+        kf.pub_flag = e->fork_flag;
+        kf.pub_seq = e->fork_seq;
       }
       bge_launch_sample(true, e->stream, e->thr, e->masks, e->node_scores, bp, carry_lik, e->m0, Mg, e->Mloc, e->d, e->S, e->W, L,
                         e->bq, kf);
@@ -1727,7 +1739,7 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
       HIP_OK(hipMemcpy(d_masks.p, hm.data(), (size_t)d * S * W * 8, hipMemcpyHostToDevice));
       HIP_OK(hipMemsetAsync(sq.counts, 0, BGE_NQ * sizeof(unsigned int), e->stream));
       bge_launch_sample(false, e->stream, nullptr, d_masks.p, d_ns.p, bp, Key2{0, 0}, 0, 1, 1, d, S, W, 0, sq,
-                        KmatFuse{nullptr, nullptr, 0, 0, 0, 0.f, 0.f});
+                        KmatFuse{nullptr, nullptr, 0, 0, 0, 0.f, 0.f, nullptr, 0u});
       bge_launch_chol(e->stream, d_ns.p, bp, sq, d, S, nullptr);
       bge_launch_sum_nodes(e->stream, d_ns.p, d_out.p + q0, d, S);
       HIP_OK(hipStreamSynchronize(e->stream));

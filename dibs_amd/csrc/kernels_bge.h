@@ -119,6 +119,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_bge_sample(const uint32_t* __res
     return;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (kf.pub_flag && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)  // (see KmatFuse: the fork flag of the step)
+    __hip_atomic_store(kf.pub_flag, kf.pub_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int m = blockIdx.y;
   const int j = blockIdx.x * WAVES + wave;
   const bool active = j < d;

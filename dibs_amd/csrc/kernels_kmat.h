@@ -12,6 +12,11 @@ struct KmatFuse {
   float* kout;      // [M, M]
   int len, M, nbx;  // nbx: first blockIdx.x of the kernel-matrix range
   float scale, h;
+  // (round 5) fork flag published by this launch: its first block can only start when the edge kernel in front of it has ended -- stores
+  // released -- so block (0, 0) stores pub_seq to *pub_flag at agent scope and the second stream's waiter (k_wait_flag) lets the acyclicity
+  // chain go.  null: nothing to publish
+  unsigned int* pub_flag;
+  unsigned int pub_seq;
 };
 
 // ------------------------------------------------------------------------------------------------

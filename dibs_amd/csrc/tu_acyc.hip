@@ -138,11 +138,13 @@ void acyc_launch_power(const AcycLaunch& a) {
   if (acyc_use_bfw(a)) {
     // The two-piece f16 scheme carries a truncation bias inside the MFMA's dot products (measured against the f32-MFMA kernel,
     // test_acyclicity_f16_pipe_worst_cases): k_acyc_hf (K = 64) -9e-7 on M^(d-1) at d = 64; k_acyc_hfw (K = 96 / 128) ~-1.15e-7 per
-    // product level, i.e. -(d - 1) 1.15e-7 = -1.0e-5 at d = 80, which the kernel compensates to first order (residual 4e-6).  The
-    // wider sizes stay on the three-piece bf16 kernel.
+    // product level, i.e. -(d - 1) 1.15e-7 = -1.0e-5 at d = 80, which the kernel compensates to first order (residual 4e-6).  With the
+    // compensation the whole range 65 .. 112 runs on it (round 4 fenced it to d <= 80): against the f64 oracle it is as close as the
+    // f32-MFMA kernel at d = 96 / 100 / 112 (5.9e-6 / 7.0e-5 at alpha = 1000 / 5.9e-6 vs 5.9e-6 / 7.3e-5 / 8.8e-6); config 5 (d = 100)
+    // 116.6 -> 123.2 steps/s.  DIBS_ACYC_HFW_MAX=80 restores the fence, DIBS_ACYC_BF16=1 the three-piece bf16 kernel.
     static const bool bf16w = getenv("DIBS_ACYC_BF16") != nullptr;
     const char* hm = getenv("DIBS_ACYC_HFW_MAX");  // (tuning / test override, read per launch)
-    if (!bf16w && a.d <= (hm ? atoi(hm) : 80)) {
+    if (!bf16w && a.d <= (hm ? atoi(hm) : 112)) {
       switch ((a.d + 15) / 16) {
         case 5: launch_hfw<5>(a); break;
         case 6: launch_hfw<6>(a); break;
