@@ -784,6 +784,20 @@ static bool kmat_tiled_on(const dibs_engine* e) { return e->kmat_ns_max > 0 && e
 static void kmat_launch_tiled(dibs_engine* e, hipStream_t st, const float* x, size_t stride, size_t off, size_t len, float* kout, float scale, float h,
                               const float* kadd, float* ksum) {
   const int sym = e->Mloc == e->M;
+  // many particles: 64 x 64 tiles (half the bytes per pair; entries bit-identical to the 32 x 32 kernel's) -- from 512 particles, where
+  // there are enough of them for every CU (DIBS_KMAT_T64_MIN)
+  const char* t64 = getenv("DIBS_KMAT_T64_MIN");
+  if (e->M >= (t64 ? atoi(t64) : 512) && kmat_tile64_ok(x, stride, off, len)) {
+    const int nta = (e->Mloc + KT2_T - 1) / KT2_T, ntb = (e->M + KT2_T - 1) / KT2_T, tiles = kmat_tile_count(nta, ntb, sym);
+    const int nchunk = kmat_nchunk64((int)len), ns = kmat_pick_nsplit(tiles, nchunk, e->kmat_ns_max), cps = (nchunk + ns - 1) / ns;
+    const KmatTile kt{x, stride, off, (int)len, e->kpart, e->m0, e->Mloc, e->M, nchunk, nta, ntb, sym, ns, cps, scale, h, kout, kadd, ksum, nullptr};
+    dibs_allow_lds((const void*)k_kmat_tile64, kmat_tile64_lds_bytes());
+    const int units = tiles * ns;
+    hipLaunchKernelGGL(k_kmat_tile64, dim3((unsigned)(units < 256 ? units : 256)), dim3(KT2_NT), kmat_tile64_lds_bytes(), st, kt);
+    if (ns > 1)
+      hipLaunchKernelGGL(k_kmat_finish, dim3(e->Mloc), dim3(256), 0, st, (const double*)e->kpart, ns, e->Mloc, e->M, sym, scale, h, kout, kadd, ksum, KT2_T);
+    return;
+  }
   const int nta = (e->Mloc + KT_T - 1) / KT_T, ntb = (e->M + KT_T - 1) / KT_T, tiles = kmat_tile_count(nta, ntb, sym);
   const int nchunk = kmat_nchunk((int)len), ns = kmat_pick_nsplit(tiles, nchunk, e->kmat_ns_max), cps = (nchunk + ns - 1) / ns;
   const KmatTile kt{x, stride, off, (int)len, e->kpart, e->m0, e->Mloc, e->M, nchunk, nta, ntb, sym, ns, cps, scale, h, kout, kadd, ksum, nullptr};
@@ -791,7 +805,7 @@ static void kmat_launch_tiled(dibs_engine* e, hipStream_t st, const float* x, si
   // (persistent blocks, one per CU by their registers, looping over the units with the next step's rows prefetched)
   const int units = tiles * ns;
   hipLaunchKernelGGL(k_kmat_tile, dim3((unsigned)(units < 256 ? units : 256)), dim3(KT_NT), kmat_tile_lds_bytes(), st, kt);
-  if (ns > 1) hipLaunchKernelGGL(k_kmat_finish, dim3(e->Mloc), dim3(256), 0, st, (const double*)e->kpart, ns, e->Mloc, e->M, sym, scale, h, kout, kadd, ksum);
+  if (ns > 1) hipLaunchKernelGGL(k_kmat_finish, dim3(e->Mloc), dim3(256), 0, st, (const double*)e->kpart, ns, e->Mloc, e->M, sym, scale, h, kout, kadd, ksum, KT_T);
 }
 static bool edge_old_env() {
   static const bool v = getenv("DIBS_EDGE_OLD") != nullptr;  // (A/B switch: k_edge_scores with four blocks per particle also where k_edge_scores_p applies)

@@ -276,13 +276,158 @@ __device__ __forceinline__ void kmat_tile_block(float* __restrict__ smem, const 
     kmat_tile_loop<false>(smem, K, first, step, units, tid);
 }
 
+// ------------------------------------------------------------------------------------------------
+// K8a''  the same units on 64 x 64 tiles (many particles): half the bytes fetched per pair -- the 32 x 32 kernel is bound by the per-CU
+//     fetch rate.  512 threads; chunks of 128 elements (LDS 128 rows x 132 floats = 66 KB + 64 KB of partial sums); wave w takes the elements 16 w .. 16 w + 15
+//     of the chunk, lane (ag, bg) the 8 x 8 pairs (ag + 8 i, bg + 8 j): 16 LDS reads of 16 bytes feed 256 packed instructions.  A wave's
+//     16-element float sum covers the SAME 16 aligned elements in the same order as in the 32 x 32 kernel and everything above it is added in
+//     double, so the entries are bit-identical to that kernel's.  Needs float4-addressable rows (else the 32 x 32 kernel runs).
+// ------------------------------------------------------------------------------------------------
+#define KT2_T 64
+#define KT2_CH 128
+#define KT2_LD (KT2_CH + 4)
+#define KT2_NT 512
+#define KT2_RV (2 * KT2_T * KT2_CH / KT2_NT)  // staged floats per thread (32)
+__host__ __device__ inline size_t kmat_tile64_lds_bytes() { return (size_t)2 * KT2_T * KT2_LD * 4 + 8 * 2048 * 4; }  // (staged rows + partial sums)
+__host__ __device__ inline int kmat_nchunk64(int len) { return (len + KT2_CH - 1) / KT2_CH; }
+__host__ inline bool kmat_tile64_ok(const float* x, size_t stride, size_t off, size_t len) {
+  return ((stride | off | len) & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+}
+__device__ __forceinline__ void kt2_fetch(const KmatTile& K, int a0, int b0, int c0, int clen, int tid, float (&v)[KT2_RV]) {
+  const char* base = reinterpret_cast<const char*>(K.x + K.off + (size_t)c0);
+#pragma unroll
+  for (int u = 0; u < KT2_RV / 4; ++u) {
+    const int i = u * KT2_NT + tid, row = i / (KT2_CH / 4), e = (i - row * (KT2_CH / 4)) * 4;
+    const int gr = row < KT2_T ? K.m0 + (a0 + row < K.Mloc ? a0 + row : K.Mloc - 1) : (b0 + row - KT2_T < K.M ? b0 + row - KT2_T : K.M - 1);
+    const uint32_t bo = ((uint32_t)gr * (uint32_t)K.stride + (uint32_t)(e < clen ? e : 0)) * 4u;
+    const float4 t = *reinterpret_cast<const float4*>(base + bo);
+    v[4 * u] = t.x, v[4 * u + 1] = t.y, v[4 * u + 2] = t.z, v[4 * u + 3] = t.w;
+  }
+}
+__device__ __forceinline__ void kmat_tile64_block(float* __restrict__ smem, const KmatTile& K, int first, int step, int tid) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int units = kmat_tile_count(K.nta, K.ntb, K.symmetric) * K.nsplit;
+  if (first >= units) return;
+  const int lane = tid & 63, wave = tid >> 6, ag = lane >> 3, bg = lane & 7;
+  const float4* pa = reinterpret_cast<const float4*>(smem + ag * KT2_LD) + wave * (KT2_CH / 4 / 8);
+  const float4* pb = reinterpret_cast<const float4*>(smem + (KT2_T + bg) * KT2_LD) + wave * (KT2_CH / 4 / 8);
+  auto tile_of = [&](int tile, int& a0, int& b0) {
+    int ta, tb;
+    if (K.symmetric) {
+      ta = 0;
+      int t = tile;
+      while (t >= K.nta - ta) { t -= K.nta - ta; ++ta; }
+      tb = ta + t;
+    } else {
+      ta = tile / K.ntb;
+      tb = tile - ta * K.ntb;
+    }
+    a0 = ta * KT2_T;
+    b0 = tb * KT2_T;
+  };
+  float v[KT2_RV];
+  int u = first, c = (u % K.nsplit) * K.cps, a0, b0;
+  tile_of(u / K.nsplit, a0, b0);
+  int clen = K.len - c * KT2_CH < KT2_CH ? K.len - c * KT2_CH : KT2_CH;
+  kt2_fetch(K, a0, b0, c * KT2_CH, clen, tid, v);
+  double tot[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) tot[r] = 0.0;
+  for (;;) {
+#pragma unroll
+    for (int w = 0; w < KT2_RV / 4; ++w) {
+      const int i = w * KT2_NT + tid, row = i / (KT2_CH / 4), e = (i - row * (KT2_CH / 4)) * 4;
+      const bool in = e < clen;
+      *reinterpret_cast<float4*>(smem + row * KT2_LD + e) =
+          make_float4(in ? v[4 * w] : 0.f, in ? v[4 * w + 1] : 0.f, in ? v[4 * w + 2] : 0.f, in ? v[4 * w + 3] : 0.f);
+    }
+    __syncthreads();
+    const int ca0 = a0, cb0 = b0;
+    const int sp = u % K.nsplit, c_hi = (sp + 1) * K.cps < K.nchunk ? (sp + 1) * K.cps : K.nchunk;
+    int un = u, cn = c + 1;
+    if (cn >= c_hi) {
+      un = u + step;
+      cn = (un % K.nsplit) * K.cps;
+    }
+    const bool more = un < units;  // (block-uniform)
+    if (more) {
+      if (un != u) tile_of(un / K.nsplit, a0, b0);
+      clen = K.len - cn * KT2_CH < KT2_CH ? K.len - cn * KT2_CH : KT2_CH;
+      kt2_fetch(K, a0, b0, cn * KT2_CH, clen, tid, v);
+    }
+    // two halves of the a-rows (i < 4, i >= 4: 32 accumulators each); the 8 waves' partial sums of a half meet in their own LDS area
+    // (8 x 2048 floats behind the staged rows); thread tid owns the pairs tid + 512 r of each half
+    float* const red = smem + 2 * KT2_T * KT2_LD;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      f32x2 acc[32];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) acc[q] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int it = 0; it < KT2_CH / 4 / 8; ++it) {
+        float4 x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = pa[(hh * 4 + i) * 8 * (KT2_LD / 4) + it];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float4 y = pb[j * 8 * (KT2_LD / 4) + it];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            f32x2 t = f32x2{x[i].x, x[i].y} - f32x2{y.x, y.y};
+            acc[i * 8 + j] = __builtin_elementwise_fma(t, t, acc[i * 8 + j]);
+            t = f32x2{x[i].z, x[i].w} - f32x2{y.z, y.w};
+            acc[i * 8 + j] = __builtin_elementwise_fma(t, t, acc[i * 8 + j]);
+          }
+        }
+      }
+      if (hh) __syncthreads();  // (the first half's sums have been read)
+#pragma unroll
+      for (int q = 0; q < 32; ++q) red[wave * 2048 + q * 64 + lane] = acc[q].x + acc[q].y;
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t += (double)red[w * 2048 + r * 512 + tid];
+        tot[hh * 4 + r] += t;
+      }
+    }
+    if (un != u) {  // (block-uniform) last chunk of the unit
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) {
+        const int hh = r8 >> 2, idx = (r8 & 3) * 512 + tid, q = idx >> 6, ln = idx & 63;
+        const int a = ca0 + (ln >> 3) + 8 * (hh * 4 + (q >> 3)), b = cb0 + (ln & 7) + 8 * (q & 7);
+        if (a < K.Mloc && b < K.M) {
+          if (K.nsplit > 1) {
+            K.part[((size_t)sp * K.Mloc + a) * K.M + b] = tot[r8];
+          } else {
+            const float kv = (float)((double)K.scale * exp(-tot[r8] / (double)K.h));
+            const bool mirror = K.symmetric && cb0 > ca0;
+            K.kout[(size_t)a * K.M + b] = kv;
+            if (mirror) K.kout[(size_t)b * K.M + a] = kv;
+            if (K.ksum) {
+              K.ksum[(size_t)a * K.M + b] = K.kadd[(size_t)a * K.M + b] + kv;
+              if (mirror) K.ksum[(size_t)b * K.M + a] = K.kadd[(size_t)b * K.M + a] + kv;
+            }
+          }
+        }
+        tot[r8] = 0.0;
+      }
+    }
+    if (!more) break;
+    u = un;
+    c = cn;
+    __syncthreads();
+  }
+}
+
 // row a of the matrix from the pieces: threads tid, tid + nthr, ... take the columns b
 __device__ __forceinline__ void kmat_finish_row(const double* __restrict__ part, int nsplit, int Mloc, int M, int symmetric, float scale, float h,
                                                 float* __restrict__ kout, const float* __restrict__ kadd, float* __restrict__ ksum, int a, int tid,
-                                                int nthr) {
+                                                int nthr, int tile = KT_T) {
   for (int b = tid; b < M; b += nthr) {
     // (symmetric: only tiles tb >= ta exist; below them the transposed entry is the same sum)
-    const bool up = !symmetric || (b / KT_T) >= (a / KT_T);
+    const bool up = !symmetric || (b / tile) >= (a / tile);
     const double* p = part + (up ? (size_t)a * M + b : (size_t)b * M + a);
     const size_t cs = (size_t)Mloc * M;
     double tot = 0.0;

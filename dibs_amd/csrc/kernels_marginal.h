@@ -215,8 +215,13 @@ __global__ __launch_bounds__(KT_NT) void k_kmat_tile(KmatTile kt) {
   kmat_tile_block(smem, kt, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x);
 }
 __global__ __launch_bounds__(256) void k_kmat_finish(const double* __restrict__ part, int nchunk, int Mloc, int M, int symmetric, float scale, float h,
-                                                     float* __restrict__ kout, const float* __restrict__ kadd, float* __restrict__ ksum) {
-  kmat_finish_row(part, nchunk, Mloc, M, symmetric, scale, h, kout, kadd, ksum, (int)blockIdx.x, (int)threadIdx.x, 256);
+                                                     float* __restrict__ kout, const float* __restrict__ kadd, float* __restrict__ ksum, int tile) {
+  kmat_finish_row(part, nchunk, Mloc, M, symmetric, scale, h, kout, kadd, ksum, (int)blockIdx.x, (int)threadIdx.x, 256, tile);
+}
+// 64 x 64 tiles (kernels_kmat.h, K8a''): grid <= tiles * pieces, block = 512; dynamic LDS = kmat_tile64_lds_bytes()
+__global__ __launch_bounds__(KT2_NT) void k_kmat_tile64(KmatTile kt) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  kmat_tile64_block(smem, kt, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x);
 }
 
 __global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, size_t pack_stride, size_t seg_off, int len,

@@ -1132,7 +1132,7 @@ def test_kernel_matrix_fusion_is_transparent(monkeypatch):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("mode,n,seed", [("", 25, 101), ("FUZZ_BIG", 6, 102), ("FUZZ_SCALE", 12, 103)])
+@pytest.mark.parametrize("mode,n,seed", [("", 25, 101), ("FUZZ_BIG", 6, 102), ("FUZZ_SCALE", 12, 103), ("FUZZ_PARTICLES", 8, 104)])
 def test_randomised_differential(monkeypatch, mode, n, seed):
     """A fixed-seed slice of tests/tools/gpu_fuzz.py (random sizes, priors, estimators, optimizers, interventions, PRNG layouts and model
     families, one or two steps each against the f64 oracle) as a regression net: the full runs found two defects this round."""
@@ -1171,3 +1171,28 @@ def test_kernel_matrix_units_in_particle_grad_launch(monkeypatch):
         assert rel_err(a.get_state()["z"], b.get_state()["z"]) < 1e-5
     monkeypatch.delenv("DIBS_NO_KMAT_GRAD", raising=False)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("joint,d,M", [(False, 8, 520), (True, 6, 260), (False, 20, 130), (True, 12, 1024)])
+def test_kernel_matrix_tile64_equals_tile32(monkeypatch, joint, d, M):
+    """The 64 x 64-tile kernel-matrix kernel (default from 512 particles) against the 32 x 32-tile one on the same particles: a wave's float
+    sums cover the same 16 aligned elements in the same order and everything above them is added in double, so the entries are
+    bit-identical -- ragged tile counts (520 = 8 x 64 + 8, 260, 130), symmetric single-rank slabs, the joint models' second matrix and
+    their sum included (the trajectory is compared bit for bit as well).  kernel.py:20-30, svgd.py:165-176 / 537-551"""
+    data, _, _ = make_data(d, seed=1, joint=joint)
+    kw = dict(joint=True, likelihood="lingauss") if joint else {}
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=100, n_grad_mc_samples=4, n_acyclicity_mc_samples=2, edges_per_node=1, **kw)
+    outs = []
+    for t64 in ("1", "1000000"):
+        monkeypatch.setenv("DIBS_KMAT_T64_MIN", t64)
+        monkeypatch.setenv("DIBS_NO_KMAT_GRAD", "1")   # (the units riding in k_particle_grad are 32 x 32 in both runs: take the launch of its own)
+        eng = _engine(cfg, data.x)
+        eng.init_particles(prng.PRNGKey(4))
+        eng.run(0, 3)
+        st = eng.get_state()
+        outs.append((eng.read("KXX").copy(), st["z"].copy(), None if st.get("theta") is None else st["theta"].copy()))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    if joint:
+        assert np.array_equal(outs[0][2], outs[1][2])
