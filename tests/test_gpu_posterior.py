@@ -186,10 +186,10 @@ TOL_JOINT = {
     # equals the oracle's -- for the oracle's own float32 build neither (seed 0: E-SHD f32 - f64 = -3.08 at step 500, -1.73 at step 1000; its Z is
     # 0.7 of max |Z| away from the f64 build's already at step 100, where the device is at 2e-5: the device keeps the softmax / log-sum-exp
     # stages in double, an all-float32 evaluation does not survive 100 steps of this model) -- device seed 0: +0.72 / +1.15 / +0.03, seed 1: -0.73 / +0.63 / -1.41, seed 2: +0.73 / +0.27 / -1.78.
-    # Round 5, 8 seeds (5 of them to step 2000, `ncp_f64` in the fixture): device dE-SHD per seed
+    # Round 5, 8 seeds (7 of them to step 2000, seed 7 to step 1000: `ncp_f64` in the fixture): device dE-SHD per seed
     #   step 500:  -1.15 +0.63 -0.09 -3.50 -0.09 -0.13 +0.43 -2.07   mean -0.74, sd 1.41 (2 SE = 1.00)
-    #   step 1000: -0.31 +0.59 +0.28 -0.89 +4.56 +0.35                mean +0.76, sd 1.93 (2 SE = 1.58)
-    #   step 2000: -0.97 -1.96 -0.22 +6.14 +0.97                      mean +0.79, sd 3.12 (2 SE = 2.79)
+    #   step 1000: -0.31 +0.59 +0.28 -0.89 +4.56 -0.30 +0.35 -1.01   mean +0.41, sd 1.79 (2 SE = 1.27; calibrated on the first six: sd 1.93)
+    #   step 2000: -0.97 -1.96 -0.22 +6.14 +0.97 +0.25 -0.21         mean +0.57, sd 2.63 (2 SE = 1.99; calibrated on the first five: sd 3.12)
     # Once the trajectories have separated a seed's difference is a draw from the spread of nearby posteriors (the float32 build of the
     # oracle: -3.08 / -1.73 on its one seed); what parity can assert is that the device is UNBIASED against the f64 oracle -- the rule of
     # config 2 / the headline: |mean over seeds| <= 2 SE, SE from the seed-to-seed spread measured here (sd / sqrt(n), sd as listed) -- and
