@@ -198,6 +198,15 @@ def main():
                     e, note = min(e, 0.0), note + f" ({nflip} Bernoulli boundary flips of {gg.size}: Z not compared)"
             lp_d, lp_o = eng.read("LOGPROBS_Z").reshape(M, S), np.asarray(dbg["logprobs_z"], np.float64).reshape(M, S)
             sel = np.ones((M, S), bool) if same_s is None else same_s
+            if fam != "bge" and kw.get("grad_estimator_z") == "score" and np.isfinite(lp_o).all():
+                # the joint models' score estimator draws hard graphs as well (threshold from the float32 sigmoid on the device, the float64 one in
+                # the oracle) and those graphs cannot be read back: a handful of samples whose log-probability is off while all others agree to
+                # 1e-3 of the largest are Bernoulli boundary flips, as above (seed 902 trial 6 of FUZZ_BIG: one of 5 120 samples, on every
+                # device kernel and on round 4's library alike)
+                off = np.abs(lp_d - lp_o) > 1e-3 * max(np.abs(lp_o).max(), 1e-300)
+                if 0 < off.sum() <= max(2, 1e-5 * M * S * d * d):
+                    sel = sel & ~off
+                    e, note = min(e, 0.0), note + f" ({int(off.sum())} of {M * S} samples off in log-probability: Bernoulli boundary flips, Z not compared)"
             if sel.any() and np.isfinite(lp_o[sel]).all():
                 # (a net for gross errors in trials whose Z is not compared: the suite holds 2e-5 on ordinary states; a state 30 steps into a
                 #  badly scaled run -- phi ~ 1e10 -- showed 2.5e-4 with phi itself at 3e-6)
