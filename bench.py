@@ -204,14 +204,23 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # DIBS_COMM=ipc: the exchange through mapped peer memory (dibs_engine_comm_init_ipc) instead of RCCL -- the ranks may then SHARE devices
+    # (rank r on device r mod #devices): `--gpus 4` on a one-GPU box executes the whole N > 1 path, rank != 0 included.  The harness's own
+    # barrier / max-over-ranks go through gloo then (RCCL refuses a group with a duplicate GPU).
+    comm_ipc = os.environ.get("DIBS_COMM", "rccl").lower() == "ipc"
+    dev_id = local_rank % torch.cuda.device_count() if comm_ipc else local_rank
+    torch.cuda.set_device(dev_id)
     sharded = N > 1 or args.dist_smoke
     dist = None
     if sharded:
         os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if comm_ipc:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ctl_dev = "cpu" if comm_ipc else "cuda"   # where the harness's own small reductions live
 
     def fence():
         if dist is not None:
@@ -222,7 +231,7 @@ def main():
 
     def measure(cfgname, M_, reps_min, min_seconds):
         """Engine + runner for one workload; returns (engine, run, snapshot at t = W, per-repetition seconds)."""
-        cfg, x, mask = make_workload(cfgname, M_, rank, N, local_rank)
+        cfg, x, mask = make_workload(cfgname, M_, rank, N, dev_id)
         # N > 1: the step loop runs INSIDE the engine (dibs_engine_run_sharded): RCCL communicators created by libdibs_hip.so from unique
         # ids (torch.distributed only carries those bytes and provides the barrier / max-over-ranks of this harness), ncclAllGather issued
         # on the engine's own streams.  DIBS_BENCH_TORCH_LOOP=1: the Python-driven loop over torch collectives (the test harness).
@@ -251,21 +260,26 @@ def main():
             # unusable cannot leave the others stuck inside the bring-up; (2) the bring-up itself.  A failure INSIDE ncclCommInitRank on a
             # subset of the ranks is fatal by RCCL's own rules (the other ranks block until its timeout aborts the job) -- not recoverable here.
             err = ""
-            try:
-                if os.environ.get("DIBS_BENCH_FAIL_NATIVE"):   # (tests: exercise the agreement + fallback below)
-                    raise RuntimeError("DIBS_BENCH_FAIL_NATIVE is set")
-                eng.comm_unique_ids(1)
-            except Exception as ex_:   # noqa: BLE001
-                err = f"{type(ex_).__name__}: {ex_}"
-            flag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
+            if comm_ipc:
+                from dibs_amd.distributed import init_ipc_comm
+                init_ipc_comm(eng)   # (no fallback: the torch loop needs RCCL, which cannot serve ranks that share a device)
+                flag = torch.tensor([1], dtype=torch.int32)
+            else:
                 try:
-                    init_native_comm(eng, None, 2 if overlapped else 1)
+                    if os.environ.get("DIBS_BENCH_FAIL_NATIVE"):   # (tests: exercise the agreement + fallback below)
+                        raise RuntimeError("DIBS_BENCH_FAIL_NATIVE is set")
+                    eng.comm_unique_ids(1)
                 except Exception as ex_:   # noqa: BLE001
                     err = f"{type(ex_).__name__}: {ex_}"
                 flag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 1:
+                    try:
+                        init_native_comm(eng, None, 2 if overlapped else 1)
+                    except Exception as ex_:   # noqa: BLE001
+                        err = f"{type(ex_).__name__}: {ex_}"
+                    flag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 if rank == 0:
                     print(f"bench: in-engine RCCL communicator failed ({err or 'on another rank'}); using the torch.distributed loop", file=sys.stderr)
@@ -321,7 +335,7 @@ def main():
             fence()
             el = time.perf_counter() - t_begin
             if dist is not None:
-                tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+                tt = torch.tensor([el], dtype=torch.float64, device=ctl_dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
             rep_s.append(el)
@@ -341,7 +355,7 @@ def main():
         "config": {"workload": c["label"], "name": args.config, "n_vars": d, "n_particles": M, "n_observations": N_OBS,
                    "n_grad_mc_samples": S_MC, "n_acyclicity_mc_samples": SA_MC,
                    "timed_steps": f"t={W}..{W + K - 1} of one trajectory from PRNGKey(1)",
-                   "parallelism": (f"particles sharded over {N} rank(s), step loop and RCCL all-gathers inside the engine (dibs_engine_run_sharded); "
+                   "parallelism": (f"particles sharded over {N} rank(s), step loop and {'mapped-memory' if comm_ipc else 'RCCL'} all-gathers inside the engine (dibs_engine_run_sharded); "
                                    + ("ONE all-gather of the packed rows [z | grad_z | theta | grad_theta] per step" if M < 512 and os.environ.get("DIBS_BENCH_EXCHANGE") != "overlapped" else
                                       "gradients all-gathered between the phases, values beside phase A")) if sharded else "single GPU"},
         "reps": len(rep_s), "timed_seconds_total": float(np.sum(rep_s)),
@@ -349,6 +363,8 @@ def main():
                             "first5": [1e3 * r / K for r in rep_s[:5]]},
         "rep_spread": (float(np.percentile(rep_s, 90)) - float(np.percentile(rep_s, 10))) / elapsed,
     }
+    if comm_ipc and sharded:
+        out["n_devices"] = min(N, torch.cuda.device_count())   # (ranks share devices: n_gpus is the number of RANKS here)
     if loop_note:
         out["config"]["parallelism"] = f"particles sharded over {N} rank(s), step loop driven from Python, collectives by " + loop_note["loop"]
 
@@ -363,17 +379,21 @@ def main():
         eng.set_profiling(False)
         allk = [None] * N
         dist.all_gather_object(allk, mine)
-        with torch.cuda.stream(tstream):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for _ in range(5):
-                dist.all_gather_into_tensor(recv, send)
-            e0.record(tstream)
-            for _ in range(50):
-                dist.all_gather_into_tensor(recv, send)
-            e1.record(tstream)
-        fence()
-        ag_us = e0.elapsed_time(e1) / 50 * 1e3
+        ag_us = None
+        if not comm_ipc:   # (the collective alone through torch.distributed: RCCL only)
+            with torch.cuda.stream(tstream):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(5):
+                    dist.all_gather_into_tensor(recv, send)
+                e0.record(tstream)
+                for _ in range(50):
+                    dist.all_gather_into_tensor(recv, send)
+                e1.record(tstream)
+            fence()
+            ag_us = e0.elapsed_time(e1) / 50 * 1e3
         out["sharded"] = {
+            "comm": ("mapped peer memory (dibs_engine_comm_init_ipc): %d rank(s) on %d device(s)" % (N, min(N, torch.cuda.device_count()))) if comm_ipc
+                    else "RCCL (dibs_engine_comm_init)",
             "kernel_us_per_step_by_rank": allk, "allgather_us": ag_us, "allgather_bytes_per_rank": int(send.numel() * 4),
             "exchange": "allgather_us / allgather_bytes_per_rank: the collective on the critical path of a step, timed alone through torch.distributed "
                         "(packed protocol: the rows [z | grad_z | theta | grad_theta]; overlapped protocol: the gradient rows -- the values travel on a "

@@ -20,7 +20,8 @@ EXPORTS = [
     "dibs_engine_get_timers", "dibs_engine_reset_timers", "dibs_engine_get_counters", "dibs_score_graphs",
     "dibs_engine_plane_elems_per_rank", "dibs_engine_export_values", "dibs_engine_step_local_grads", "dibs_engine_step_update_planes",
     "dibs_engine_kmat_values", "dibs_engine_eval_gradients", "dibs_comm_unique_id", "dibs_engine_comm_init",
-    "dibs_engine_comm_destroy", "dibs_engine_run_sharded", "dibs_engine_gather_particles",
+    "dibs_engine_comm_destroy", "dibs_engine_run_sharded", "dibs_engine_gather_particles", "dibs_engine_ipc_export",
+    "dibs_engine_comm_init_ipc",
 ]
 
 
@@ -88,6 +89,8 @@ def load():
     lib.dibs_comm_unique_id.argtypes = [vp]
     lib.dibs_engine_comm_init.argtypes = [vp, vp, i32]
     lib.dibs_engine_comm_destroy.argtypes = [vp]
+    lib.dibs_engine_ipc_export.argtypes = [vp, vp]
+    lib.dibs_engine_comm_init_ipc.argtypes = [vp, vp]
     lib.dibs_engine_run_sharded.argtypes = [vp, i32, i32, i32]
     lib.dibs_engine_gather_particles.argtypes = [vp, vp, vp]
     lib.dibs_score_graphs.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp]

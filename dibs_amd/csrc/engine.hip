@@ -22,6 +22,8 @@
 #include "kernels_joint.h"
 #include "kernels_nn.h"
 #include "kernels_bge_soft.h"
+#include "exchange_ipc.h"
+#include <unistd.h>
 
 #define LDS_LIMIT ((size_t)160 * 1024)
 // profiling counters (dibs_engine_get_counters): [0] executed Cholesky flops, [1..4] phases of k_particle_grad (100 MHz ticks of block 0),
@@ -133,6 +135,7 @@ struct dibs_engine {
   hipEvent_t ev_exported = nullptr, ev_vals = nullptr;
   bool vals_fresh = false;  // plane 0 (and the kernel slab computed from it) belongs to the engine's current particles
   bool loopback = false;    // comm_init(NULL): collectives skipped (per-rank timing on one GPU)
+  IpcComm ipc;              // the exchange through mapped peer memory instead of RCCL (exchange_ipc.h; dibs_engine_comm_init_ipc)
   struct ScoreCache {
     std::vector<float> x;
     std::vector<int32_t> mask;
@@ -1456,6 +1459,15 @@ extern "C" int dibs_engine_comm_destroy(dibs_engine* e) {
       e->comm[i] = nullptr;
     }
   e->n_comms = 0;
+  if (e->ipc.arena || e->ipc.err) {
+    // (the peers must have left their last exchange: every rank returns from dibs_engine_run_sharded / gather_particles only after it has seen
+    //  all of its peers' rows, and nobody writes into an arena outside an exchange)
+    for (int r = 0; r < IPC_MAX_RANKS; ++r)
+      if (e->ipc.opened[r]) hipIpcCloseMemHandle(e->ipc.peers.base[r]);
+    if (e->ipc.arena) hipFree(e->ipc.arena);
+    if (e->ipc.err) hipHostFree(e->ipc.err);
+    e->ipc = IpcComm{};
+  }
   if (e->planes) hipFree(e->planes);
   if (e->vsend) hipFree(e->vsend);
   e->planes = e->vsend = nullptr;
@@ -1495,6 +1507,100 @@ extern "C" int dibs_engine_comm_init(dibs_engine* e, const void* ids, int32_t n_
   return 0;
 }
 
+// ---- the exchange through mapped peer memory (exchange_ipc.h): ranks that share a device, or devices with peer access ------------------
+static_assert(DIBS_IPC_HANDLE_BYTES == sizeof(IpcBlob), "include/dibs_hip.h: DIBS_IPC_HANDLE_BYTES");
+
+// allocates this rank's exchange arena (zeroed: no exchange has arrived) and writes the blob its peers need to map it
+extern "C" int dibs_engine_ipc_export(dibs_engine* e, void* blob_out) {
+  if (!e || !blob_out) return fail("null argument");
+  if (e->cfg.n_ranks > IPC_MAX_RANKS) return fail("the mapped-memory exchange supports at most " + std::to_string(IPC_MAX_RANKS) + " ranks");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  dibs_engine_comm_destroy(e);
+  IpcComm& c = e->ipc;
+  c.n_ranks = e->cfg.n_ranks;
+  c.rank = e->cfg.rank;
+  c.pack_elems = (size_t)e->M * e->E;
+  c.set_elems = (size_t)2 * e->M * e->Ev;
+  c.arena_bytes = IPC_FLAG_BYTES + (2 * c.pack_elems + 2 * c.set_elems) * 4;
+  HIP_OK(hipMalloc((void**)&c.arena, c.arena_bytes));
+  HIP_OK(hipMemset(c.arena, 0, c.arena_bytes));
+  HIP_OK(hipDeviceSynchronize());
+  IpcBlob b;
+  memset(&b, 0, sizeof b);
+  b.magic = IPC_MAGIC;
+  b.abi = DIBS_ABI_VERSION;
+  b.rank = (uint32_t)c.rank;
+  b.n_ranks = (uint32_t)c.n_ranks;
+  b.arena_bytes = c.arena_bytes;
+  b.pack_elems = c.pack_elems;
+  b.set_elems = c.set_elems;
+  b.device_id = e->cfg.device_id;
+  b.pid = (int32_t)getpid();
+  HIP_OK(hipIpcGetMemHandle(&b.handle, c.arena));
+  memcpy(blob_out, &b, sizeof b);
+  return 0;
+}
+
+// blobs_all: the n_ranks blobs of dibs_engine_ipc_export in rank order (every rank passes the same bytes)
+extern "C" int dibs_engine_comm_init_ipc(dibs_engine* e, const void* blobs_all) {
+  if (!e || !blobs_all) return fail("null argument");
+  IpcComm& c = e->ipc;
+  if (!c.arena) return fail("dibs_engine_ipc_export has not been called on this engine");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  const IpcBlob* B = reinterpret_cast<const IpcBlob*>(blobs_all);
+  for (int r = 0; r < c.n_ranks; ++r) {
+    IpcBlob b;
+    memcpy(&b, B + r, sizeof b);
+    if (b.magic != IPC_MAGIC || b.abi != DIBS_ABI_VERSION) return fail("blob of rank " + std::to_string(r) + ": not a dibs_engine_ipc_export blob of this ABI version");
+    if ((int)b.rank != r || (int)b.n_ranks != c.n_ranks) return fail("blob " + std::to_string(r) + " belongs to rank " + std::to_string(b.rank) + " of " + std::to_string(b.n_ranks));
+    if (b.arena_bytes != c.arena_bytes || b.pack_elems != c.pack_elems || b.set_elems != c.set_elems)
+      return fail("rank " + std::to_string(r) + " was created with a different configuration (exchange arena sizes differ)");
+    if (r == c.rank) {
+      c.peers.base[r] = c.arena;
+      continue;
+    }
+    if (b.pid == (int32_t)getpid()) return fail("the mapped-memory exchange needs one PROCESS per rank (rank " + std::to_string(r) + " lives in this process)");
+    void* p = nullptr;
+    HIP_OK(hipIpcOpenMemHandle(&p, b.handle, hipIpcMemLazyEnablePeerAccess));
+    c.peers.base[r] = (char*)p;
+    c.opened[r] = true;
+  }
+  HIP_OK(hipHostMalloc((void**)&c.err, 4, hipHostMallocDefault));
+  *c.err = 0u;
+  if (const char* tm = getenv("DIBS_IPC_TIMEOUT_MS")) {  // (read once per communicator: how long a rank waits for its peers' rows)
+    const long ms = atol(tm);
+    if (ms > 0) c.wait_ticks = (unsigned long long)ms * 100000ull;
+  }
+  HIP_OK(dalloc(&e->vsend, (size_t)e->Mloc * e->Ev));
+  HIP_OK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+  HIP_OK(hipEventCreateWithFlags(&e->ev_exported, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&e->ev_vals, hipEventDisableTiming));
+  HIP_OK(hipDeviceSynchronize());
+  c.on = true;
+  e->loopback = false;
+  e->n_comms = 2;  // (both protocols: the arena holds the packed rows and the planes)
+  e->vals_fresh = false;
+  return 0;
+}
+
+// one all-gather through the arenas on stream `st`: `n` floats at `src` (this rank's rows) -> byte offset dst_off of every peer's arena
+// (include_self: and of the own one), then the announcement + wait of this exchange on `channel`
+static int ipc_all_gather(dibs_engine* e, int channel, hipStream_t st, const float* src, size_t dst_off, size_t n, bool include_self) {
+  IpcComm& c = e->ipc;
+  if ((n & 3) || (dst_off & 15) || (reinterpret_cast<uintptr_t>(src) & 15)) return fail("internal: exchange rows are not 16-byte aligned");
+  const size_t n4 = n / 4;
+  const int ndst = include_self ? c.n_ranks : c.n_ranks - 1;
+  if (ndst > 0 && n4 > 0) {
+    const unsigned bx = (unsigned)((n4 + 255) / 256 < 256 ? (n4 + 255) / 256 : 256);
+    hipLaunchKernelGGL(k_ipc_push, dim3(bx, (unsigned)ndst), dim3(256), 0, st, c.peers, c.rank, c.n_ranks, include_self ? 1 : 0,
+                       reinterpret_cast<const float4*>(src), dst_off, n4);
+  }
+  const unsigned int seq = ++c.seq[channel];
+  if (c.n_ranks > 1) hipLaunchKernelGGL(k_ipc_signal_wait, dim3(1), dim3(64), 0, st, c.peers, c.rank, c.n_ranks, channel, seq, c.wait_ticks, c.err);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int dibs_engine_kmat_values(dibs_engine* e, const void* vals_all_dev, void* stream);
 // Loopback stand-in for the all-gather of the values (per-rank timing on one GPU).  A plain copy KERNEL: hipMemcpyAsync(DeviceToDevice) on the
 // side stream made the un-profiled loop of a 4-way rank take 380 us per step instead of 103 (and 107 under rocprofv3, which turns the copy
@@ -1514,16 +1620,31 @@ static int exchange_values(dibs_engine* e, bool exported) {
   }
   HIP_OK(hipEventRecord(e->ev_exported, e->stream));
   HIP_OK(hipStreamWaitEvent(e->side, e->ev_exported, 0));
-  if (e->loopback) {  // (own rows only; a kernel of our own, not hipMemcpyAsync: see k_copy_rows)
+  const float* plane0 = e->planes;
+  if (e->ipc.on) {  // value exchange n goes to plane set n & 1 of every arena (the own one included); the gradient rows of that step follow it there
+    e->ipc.vset = (int)((e->ipc.seq[1] + 1u) & 1u);
+    if (ipc_all_gather(e, 1, e->side, e->vsend, e->ipc.set_off(e->ipc.vset) + (size_t)e->m0 * e->Ev * 4, (size_t)e->Mloc * e->Ev, true)) return 1;
+    plane0 = e->ipc.set(e->ipc.vset);
+  } else if (e->loopback) {  // (own rows only; a kernel of our own, not hipMemcpyAsync: see k_copy_rows)
     const size_t n4 = (size_t)e->Mloc * e->Ev / 4;  // (Ev is a multiple of 4)
     hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, e->side, reinterpret_cast<const float4*>(e->vsend),
                        reinterpret_cast<float4*>(e->planes + (size_t)e->m0 * e->Ev), n4);
   }
   else
     RCCL_OK(rccl().all_gather(e->vsend, e->planes, (size_t)e->Mloc * e->Ev, ncclFloat, e->comm[1], e->side));
-  if (dibs_engine_kmat_values(e, e->planes, e->side)) return 1;
+  if (dibs_engine_kmat_values(e, plane0, e->side)) return 1;
   HIP_OK(hipEventRecord(e->ev_vals, e->side));
   e->vals_fresh = true;
+  return 0;
+}
+
+// after the streams have been synchronised: did a rank give up waiting for its peers' rows?
+static int ipc_check(dibs_engine* e) {
+  if (e->ipc.err && *e->ipc.err) {
+    *e->ipc.err = 0u;
+    return fail("mapped-memory exchange: the rows of a peer rank did not arrive within the time-out (a rank that died, or ranks that did not "
+                "call the same sequence of runs); the results of this chunk are invalid");
+  }
   return 0;
 }
 
@@ -1540,17 +1661,27 @@ extern "C" int dibs_engine_run_sharded(dibs_engine* e, int32_t t_start, int32_t 
   if (overlapped && !e->vals_fresh && exchange_values(e, false)) return 1;
   for (int t = t_start; t < t_start + n_steps; ++t) {
     if (!overlapped) {
-      if (step_local(e, t, packed_rows(e, e->pack))) return 1;
-      if (!e->loopback)
-        RCCL_OK(rccl().all_gather(e->pack + (size_t)e->m0 * e->E, e->pack, (size_t)e->Mloc * e->E, ncclFloat, e->comm[0], e->stream));
-      if (step_update(e, t, packed_source(e, e->pack))) return 1;
+      const int pp = (int)(e->ipc.pack_seq & 1u);
+      float* const pk = e->ipc.on ? e->ipc.pack(pp) : e->pack;
+      if (step_local(e, t, packed_rows(e, pk))) return 1;
+      if (e->ipc.on) {
+        if (ipc_all_gather(e, 0, e->stream, pk + (size_t)e->m0 * e->E, e->ipc.pack_off(pp) + (size_t)e->m0 * e->E * 4, (size_t)e->Mloc * e->E, false)) return 1;
+        ++e->ipc.pack_seq;
+      } else if (!e->loopback)
+        RCCL_OK(rccl().all_gather(pk + (size_t)e->m0 * e->E, pk, (size_t)e->Mloc * e->E, ncclFloat, e->comm[0], e->stream));
+      if (step_update(e, t, packed_source(e, pk))) return 1;
     } else {
-      float* const gplane = e->planes + grad_plane;  // rows [grad_z | grad_theta], indexed by global particle id
+      float* const planes = e->ipc.on ? e->ipc.set(e->ipc.vset) : e->planes;  // (the set the values of this step were gathered into)
+      float* const gplane = planes + grad_plane;  // rows [grad_z | grad_theta], indexed by global particle id
       if (step_local(e, t, RowTarget{gplane, (size_t)e->Ev, 0, 0, (size_t)e->D, 0})) return 1;
-      if (!e->loopback)
+      if (e->ipc.on) {
+        if (ipc_all_gather(e, 0, e->stream, gplane + (size_t)e->m0 * e->Ev, e->ipc.set_off(e->ipc.vset) + (grad_plane + (size_t)e->m0 * e->Ev) * 4,
+                           (size_t)e->Mloc * e->Ev, false))
+          return 1;
+      } else if (!e->loopback)
         RCCL_OK(rccl().all_gather(gplane + (size_t)e->m0 * e->Ev, gplane, (size_t)e->Mloc * e->Ev, ncclFloat, e->comm[0], e->stream));
       HIP_OK(hipStreamWaitEvent(e->stream, e->ev_vals, 0));  // values + kernel slab of this step (gathered during the step before)
-      if (step_update(e, t, plane_source(e, e->planes), e->vsend)) return 1;
+      if (step_update(e, t, plane_source(e, planes), e->vsend)) return 1;
       if (exchange_values(e, true)) return 1;  // values of step t + 1, beside its phase A
     }
     if (e->profiling && e->pending.size() > 4096) drain_timers(e);
@@ -1559,6 +1690,7 @@ extern "C" int dibs_engine_run_sharded(dibs_engine* e, int32_t t_start, int32_t 
   if (overlapped) HIP_OK(hipStreamSynchronize(e->side));
   if (e->profiling) drain_timers(e);
   HIP_OK(hipGetLastError());
+  if (ipc_check(e)) return 1;
   return check_join(e);
 }
 
@@ -1575,7 +1707,8 @@ extern "C" int dibs_engine_gather_particles(dibs_engine* e, float* z_all, float*
     if (!e->vals_fresh && exchange_values(e, false)) return 1;
     HIP_OK(hipStreamSynchronize(e->stream));
     HIP_OK(hipStreamSynchronize(e->side));
-    vals = e->planes;
+    if (ipc_check(e)) return 1;
+    vals = e->ipc.on ? e->ipc.set(e->ipc.vset) : e->planes;
   } else {
     HIP_OK(tmp_all.alloc((size_t)e->M * e->Ev));
     HIP_OK(tmp_send.alloc((size_t)e->Mloc * e->Ev));

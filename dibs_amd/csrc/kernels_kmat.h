@@ -204,7 +204,7 @@ __device__ __forceinline__ void kmat_tile_loop(float* __restrict__ smem, const K
       const int q = tid >> 6, a = Ucur.a0 + ag + 8 * (q >> 2), b = Ucur.b0 + bg + 8 * (q & 3);
       if (a < K.Mloc && b < K.M) {
         if (K.nsplit > 1) {
-          // (tile_ctr: agent-scope store -- written through, complete at agent scope once the block's barrier below has drained vmcnt --
+          // (tile_ctr: agent-scope store -- written through, complete at agent scope once its wave has waited for vmcnt(0) below --
           //  instead of a plain store + release fence: the fence writes the XCD's whole L2 back, +2 us on the launch the units ride in)
           if (K.tile_ctr)
             __hip_atomic_store(K.part + ((size_t)sp * K.Mloc + a) * K.M + b, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -225,7 +225,11 @@ __device__ __forceinline__ void kmat_tile_loop(float* __restrict__ smem, const K
       if (K.nsplit > 1 && K.tile_ctr) {  // (block-uniform)
         unsigned int* const ctr = K.tile_ctr + u / K.nsplit;
         unsigned int* const last = reinterpret_cast<unsigned int*>(smem + 16 * 1024);  // (first word behind the partial sums)
-        __syncthreads();  // (every piece store of the block has completed: the barrier's release drains vmcnt)
+        // every wave drains its OWN piece stores before the barrier: a workgroup-scope barrier does not wait for vmcnt on gfx950 (the
+        // compiler emits store sc1 -> s_barrier -> atomic with no wait in between), and the counter must not run ahead of the pieces
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (tid == 0) {
           const unsigned int done = atomicAdd(ctr, 1u) + 1u;
           if (done == (unsigned int)K.nsplit) atomicExch(ctr, 0u);

@@ -198,8 +198,11 @@ __global__ __launch_bounds__(1024) void k_edge_scores_p(const float* __restrict_
     }
   }
   // done_ctr != null: the fork to the engine's second stream without an event (k_wait_flag there polls done_flag): scores / eas were stored at
-  // agent scope (complete once the barrier has drained vmcnt), every block counts itself, the last one publishes the step's sequence number
+  // agent scope (complete once the storing wave has waited for vmcnt(0): the barrier alone does not), every block counts itself, the last one
+  // publishes the step's sequence number
   if (done_ctr) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0 && atomicAdd(done_ctr, 1u) == gridDim.x - 1u) {
       atomicExch(done_ctr, 0u);  // (the next launch of this kernel is behind this one in its stream)
@@ -229,6 +232,27 @@ __global__ __launch_bounds__(256) void k_kmat(const float* __restrict__ pack, si
                                               const float* __restrict__ kadd, float* __restrict__ ksum) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   kmat_block(smem, pack, pack_stride, seg_off, len, kout, m0, M, scale, h, symmetric, blockIdx.x, blockIdx.y, kadd, ksum);
+}
+
+// rmsprop of jax.example_libraries.optimizers (svgd.py:117-120, 265): v <- 0.9 v + (1 - 0.9) phi^2, x <- x - step phi / sqrt(v + 1e-8).
+// Every operation rounded on its own (no contraction into FMAs): the instantiations of k_phi_update / k_phi_gemm are chosen from the SHARD
+// size, and the compiler contracted `v * 0.9f + phi * phi * 0.1f` differently in them -- a 128-particle run on 4 ranks (TA = 4) differed
+// from the single-rank run (TA = 8) in the last bit of z from the third step on (found by tests/test_gpu_ipc.py).
+// (`#pragma clang fp contract(off)`: HIP's __fmul_rn / __fadd_rn are plain operators to the compiler and contract like them.)
+__device__ __forceinline__ float rmsprop_moment(float v, float phi) {
+#pragma clang fp contract(off)
+  const float a = v * 0.9f, p2 = phi * phi, b = p2 * 0.1f;
+  return a + b;
+}
+__device__ __forceinline__ float rmsprop_step(float x, float vv, float phi, float stepsize) {
+#pragma clang fp contract(off)
+  const float num = stepsize * phi, den = sqrtf(vv + 1e-8f), q = num / den;
+  return x - q;
+}
+__device__ __forceinline__ float gd_step(float x, float phi, float stepsize) {
+#pragma clang fp contract(off)
+  const float q = stepsize * phi;
+  return x - q;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -408,11 +432,11 @@ __global__ __launch_bounds__(256) void k_phi_update(const float* __restrict__ pa
       if (phi_out) phi_out[o] = phi;
       float xn;
       if (rmsprop) {
-        const float vv = ve[qq] * 0.9f + phi * phi * 0.1f;
+        const float vv = rmsprop_moment(ve[qq], phi);
         v[o] = vv;
-        xn = xv - stepsize * phi / sqrtf(vv + 1e-8f);
+        xn = rmsprop_step(xv, vv, phi, stepsize);
       } else {
-        xn = xv - stepsize * phi;
+        xn = gd_step(xv, phi, stepsize);
       }
       x[o] = xn;
       // overlapped exchange: the new value also goes straight into this rank's send rows [Mloc][Ev] (no separate export pass)
@@ -601,11 +625,11 @@ __global__ __launch_bounds__(256) void k_phi_gemm(const float* __restrict__ pack
         if (phi_out) phi_out[o] = phi;
         float xn;
         if (rmsprop) {
-          const float vv = v[o] * 0.9f + phi * phi * 0.1f;
+          const float vv = rmsprop_moment(v[o], phi);
           v[o] = vv;
-          xn = xv - stepsize * phi / sqrtf(vv + 1e-8f);
+          xn = rmsprop_step(xv, vv, phi, stepsize);
         } else {
-          xn = xv - stepsize * phi;
+          xn = gd_step(xv, phi, stepsize);
         }
         x[o] = xn;
         if (vout) vout[(size_t)a * vout_stride + vout_off + i] = xn;

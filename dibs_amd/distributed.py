@@ -165,6 +165,16 @@ def _all_particles(eng, buf, n_particles, group):
     return np.ascontiguousarray(v[:, :D]).reshape(n_particles, eng.d, eng.k, 2), (np.ascontiguousarray(v[:, D:D + P]) if P else None)
 
 
+def init_ipc_comm(engine, group=None):
+    """The engine's exchange through mapped peer memory (``dibs_engine_comm_init_ipc``) for the ranks of ``group``: several ranks on ONE
+    device (RCCL refuses that) or devices with peer access.  torch.distributed (any backend, gloo included) only carries the 128-byte
+    blobs; the data path never touches it."""
+    import torch.distributed as dist
+    blobs = [None] * dist.get_world_size(group)
+    dist.all_gather_object(blobs, engine.ipc_export(), group=group)
+    engine.comm_init_ipc(blobs)
+
+
 def init_native_comm(engine, group=None, n_comms=2):
     """RCCL communicator(s) INSIDE the engine (dibs_engine_comm_init): rank 0 draws the unique ids, torch.distributed carries the bytes
     to the other ranks (control plane only -- the data path of ``engine.run_sharded`` never touches torch).

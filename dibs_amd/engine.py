@@ -123,6 +123,21 @@ class Engine:
         assert len(ids) in (self.COMM_ID_BYTES, 2 * self.COMM_ID_BYTES)
         _lib.check(self.lib.dibs_engine_comm_init(self._h, ids, len(ids) // self.COMM_ID_BYTES))
 
+    # the same loop over mapped peer memory (include/dibs_hip.h: ranks that share a device, one process per rank)
+    IPC_HANDLE_BYTES = 128
+
+    def ipc_export(self):
+        """allocate this rank's exchange arena; returns the 128 bytes its peers need to map it"""
+        buf = (C.c_char * self.IPC_HANDLE_BYTES)()
+        _lib.check(self.lib.dibs_engine_ipc_export(self._h, buf))
+        return bytes(buf)
+
+    def comm_init_ipc(self, blobs):
+        """blobs: the ipc_export() bytes of ALL ranks in rank order (a list of bytes or their concatenation)"""
+        blobs = b"".join(blobs) if isinstance(blobs, (list, tuple)) else bytes(blobs)
+        assert len(blobs) == self.IPC_HANDLE_BYTES * self.cfg.n_ranks, len(blobs)
+        _lib.check(self.lib.dibs_engine_comm_init_ipc(self._h, blobs))
+
     def comm_destroy(self):
         _lib.check(self.lib.dibs_engine_comm_destroy(self._h))
 

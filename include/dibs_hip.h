@@ -189,6 +189,21 @@ int dibs_engine_comm_destroy(dibs_engine* e);
 int dibs_engine_run_sharded(dibs_engine* e, int32_t t_start, int32_t n_steps, int32_t overlapped);
 int dibs_engine_gather_particles(dibs_engine* e, float* z_all, float* theta_all);
 
+/* The same loop with the exchange through MAPPED PEER MEMORY instead of RCCL (no reference counterpart; dibs_amd/csrc/exchange_ipc.h): ranks that
+ * share one device -- where RCCL refuses a communicator ("duplicate GPU") -- or devices with peer access.  One PROCESS per rank:
+ *   every rank:  dibs_engine_ipc_export(e, blob)          allocates the rank's exchange arena and writes DIBS_IPC_HANDLE_BYTES describing it
+ *                                                         (hipIpcMemHandle + sizes); the bytes of ALL ranks go to every rank, in rank order,
+ *                                                         by any means (a file, a pipe, torch.distributed.all_gather_object ...)
+ *                dibs_engine_comm_init_ipc(e, blobs_all)  maps the peers' arenas (n_ranks * DIBS_IPC_HANDLE_BYTES bytes)
+ *                dibs_engine_run_sharded / dibs_engine_gather_particles as above (both protocols); dibs_engine_comm_destroy unmaps.
+ * The all-gather of a step is every rank storing its rows into every peer's arena plus one sequence word per peer and exchange; buffers
+ * alternate between two copies, so no acknowledgement travels back.  A rank waits at most DIBS_IPC_TIMEOUT_MS (environment, read by
+ * dibs_engine_comm_init_ipc; default 10 000) for its peers' rows, then the run returns an error.  Results are bit-identical to
+ * dibs_engine_run of a single-rank engine and to the RCCL path. */
+#define DIBS_IPC_HANDLE_BYTES 128
+int dibs_engine_ipc_export(dibs_engine* e, void* blob_out);
+int dibs_engine_comm_init_ipc(dibs_engine* e, const void* blobs_all);
+
 /* debugging / parity: copy a device buffer to the host (nbytes must match); theta size query */
 int dibs_engine_read_buffer(dibs_engine* e, int32_t which, void* host, int64_t nbytes);
 int64_t dibs_engine_buffer_bytes(const dibs_engine* e, int32_t which);
