@@ -21,7 +21,7 @@ EXPORTS = [
     "dibs_engine_plane_elems_per_rank", "dibs_engine_export_values", "dibs_engine_step_local_grads", "dibs_engine_step_update_planes",
     "dibs_engine_kmat_values", "dibs_engine_eval_gradients", "dibs_comm_unique_id", "dibs_engine_comm_init",
     "dibs_engine_comm_destroy", "dibs_engine_run_sharded", "dibs_engine_gather_particles", "dibs_engine_ipc_export",
-    "dibs_engine_comm_init_ipc",
+    "dibs_engine_comm_init_ipc", "dibs_engine_flag_fallbacks", "dibs_engine_debug_drop_next_flag",
 ]
 
 
@@ -91,6 +91,8 @@ def load():
     lib.dibs_engine_comm_destroy.argtypes = [vp]
     lib.dibs_engine_ipc_export.argtypes = [vp, vp]
     lib.dibs_engine_comm_init_ipc.argtypes = [vp, vp]
+    lib.dibs_engine_flag_fallbacks.argtypes = [vp]
+    lib.dibs_engine_debug_drop_next_flag.argtypes = [vp]
     lib.dibs_engine_run_sharded.argtypes = [vp, i32, i32, i32]
     lib.dibs_engine_gather_particles.argtypes = [vp, vp, vp]
     lib.dibs_score_graphs.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp]

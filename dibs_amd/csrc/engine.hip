@@ -64,6 +64,7 @@ struct BgeStats {
 
 struct dibs_engine {
   dibs_config cfg;
+  DibsTuning tune;  // the environment switches (tuning.h), latched at creation
   int d, k, M, Mloc, m0, N, S, Sa, W;
   int64_t D, P, E, Ev;  // z elems / theta elems per particle, packed row stride [z | grad_z | theta | grad_theta], plane row stride [z | theta] (floats)
   int dpad, ldk, edge_kc, acyc_nt, acyc_cpb, acyc_nblk, acyc_units;
@@ -107,16 +108,20 @@ struct dibs_engine {
   // round 5: the fork of a step without a record packet on the main stream -- the event IS the edge kernel's completion signal
   // (hipExtLaunchKernel stop event; scripts/probe/stream_hop.hip: 5.7 -> 2.2 us between k_edge_scores and k_bge_sample) -- and, optionally,
   // the join as a flag polled inside k_particle_grad instead of an event wait in front of it (DIBS_FLAG_JOIN=1)
-  // ... and, where k_edge_scores_p applies, no signal between the edge kernel and k_bge_sample at all: the second stream runs its OWN copy of
-  // the edge kernel (6.6 us on an idle machine, into scores2 / eas2) as soon as the optimizer step has finished (ev_z = completion signal of the
-  // last k_phi_update launch)
-  hipEvent_t ev_z = nullptr;
-  bool ev_z_valid = false;
-  float *scores2 = nullptr, *eas2 = nullptr;
   unsigned int* join_flag = nullptr;   // device word: sequence number stored by the second stream's last kernel of a step (k_join_flag)
   unsigned int* join_err = nullptr;    // pinned host word: raised by tail_join_wait when the flag did not arrive (checked after every chunk)
   unsigned int join_seq = 0;
   bool streams_concurrent = false;     // kernels of the two streams run side by side (probed at creation): the in-kernel join is safe
+  // The in-kernel flags (fork: k_wait_flag, join: tail_join_wait) need the two streams to make progress side by side.  That is probed at
+  // creation and holds for an engine alone on its GPU; a masked-down device, a second process that fills the machine or a serialising tool
+  // can still starve the polled kernel.  The waits are bounded; a chunk that saw a time-out is REPEATED on events from a copy of its
+  // loop carry taken at the chunk's start, and the engine stays on events from then on (run_chunk_guarded).
+  bool flags_now = false;              // this chunk / call uses the flags (latch_flags)
+  bool flags_off = false;              // a wait timed out once: events for the rest of the engine's life
+  int flag_fallbacks = 0;              // chunks repeated on events (dibs_engine_flag_fallbacks)
+  bool debug_drop_flag = false;        // tests: the next step that would publish the join flag does not (dibs_engine_debug_drop_next_flag)
+  float* carry_bak = nullptr;          // [Mloc (2 D + 2 P + 1)] z | v_z | theta | v_theta | baseline at the start of the chunk
+  Key2 key_bak;
   bool kmat_early;  // this step's kernel matrices were launched on the second stream (behind the acyclicity kernel)
   bool kmat_ext;    // ... or by dibs_engine_kmat_values on a stream of the caller (overlapped exchange)
   double t_ms[DIBS_K_COUNT];
@@ -136,6 +141,8 @@ struct dibs_engine {
   bool vals_fresh = false;  // plane 0 (and the kernel slab computed from it) belongs to the engine's current particles
   bool loopback = false;    // comm_init(NULL): collectives skipped (per-rank timing on one GPU)
   IpcComm ipc;              // the exchange through mapped peer memory instead of RCCL (exchange_ipc.h; dibs_engine_comm_init_ipc)
+  uint32_t* agree_dev = nullptr;  // [4 + 4 n_ranks] this rank's error word of a chunk (16 bytes) | all ranks' (run_sharded's agreement)
+  uint32_t* agree_host = nullptr; // pinned mirror
   struct ScoreCache {
     std::vector<float> x;
     std::vector<int32_t> mask;
@@ -182,11 +189,6 @@ static int64_t theta_size(const dibs_config& c) {
   return 0;
 }
 
-// the tiled kernel matrix (k_kmat_tile + k_kmat_finish) from this many particles
-static int kmat_tiled_min() {
-  const char* v = getenv("DIBS_KMAT_TILED_MIN");  // (tuning / test override, read per engine and per step)
-  return v ? atoi(v) : 128;
-}
 template <typename T>
 static hipError_t dalloc(T** p, size_t n) {
   *p = nullptr;
@@ -207,6 +209,7 @@ extern "C" int dibs_engine_comm_destroy(dibs_engine* e);
 // sizes, stream, events and every device buffer of a new engine; on failure the caller destroys the half-built engine
 static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   e->cfg = c;
+  e->tune = dibs_tuning_from_env();
   e->d = c.n_vars;
   e->k = c.n_dim;
   e->M = c.n_particles;
@@ -250,7 +253,6 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
       if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cpb; }
     }
     e->acyc_cpb = best;
-    if (const char* ov = getenv("DIBS_ACYC_CPB")) e->acyc_cpb = atoi(ov) > 0 ? atoi(ov) : best;  // tuning override
   }
   e->acyc_nblk = (e->acyc_units + e->acyc_cpb - 1) / e->acyc_cpb;
   e->sigz = c.latent_prior_std > 0 ? (float)c.latent_prior_std : 1.0f / sqrtf((float)e->k);
@@ -259,11 +261,10 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
     e->own_stream = false;
   } else {
     // the engine's own main stream at the greatest priority (its chain -- sampling, factorisation, tail -- is the later one of a step):
-    // bench.py, same box, alternating: 5 336 / 5 349 steps/s against 5 328 / 5 321 at the normal priority (DIBS_MAIN_PRIO=0)
+    // bench.py, same box, alternating: 5 336 / 5 349 steps/s against 5 328 / 5 321 at the normal priority
     int lo = 0, hi = 0;
     hipDeviceGetStreamPriorityRange(&lo, &hi);
-    const char* mp = getenv("DIBS_MAIN_PRIO");
-    if ((mp && atoi(mp) == 0) || hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, hi) != hipSuccess) {
+    if (hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, hi) != hipSuccess) {
       (void)hipGetLastError();
       HIP_OK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     }
@@ -271,14 +272,13 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   }
   HIP_OK(hipEventCreate(&e->ev0));
   HIP_OK(hipEventCreate(&e->ev1));
-  if (!getenv("DIBS_NO_ACYC_STREAM2")) {
+  if (!e->tune.no_stream2) {
     int lo = 0, hi = 0;
     hipDeviceGetStreamPriorityRange(&lo, &hi);  // (lo = least, hi = greatest priority)
     // round 3, headline size: serial 3 906 steps/s; second stream at least / normal / greatest priority 3 906 / 3 964 / 4 001.
     // round 5 (fork by flag, both chains start together -- see flag_fork in step_local): least priority; with the event fork the three
     // priorities measure the same now (5 193-5 217), configs 3 / 5 gain 1-2 % at the least priority, config 4 is unchanged.
-    const char* pr = getenv("DIBS_ACYC_PRIO");
-    const int prio = pr ? (atoi(pr) > 0 ? hi : (atoi(pr) < 0 ? lo : (lo + hi) / 2)) : lo;
+    const int prio = lo;
     // (an optimisation only: without it every kernel goes to the engine stream)
     if (hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, prio) != hipSuccess &&
         hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess) {
@@ -291,7 +291,6 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
     HIP_OK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&e->ev_k0, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&e->ev_k1, hipEventDisableTiming));
-    HIP_OK(hipEventCreateWithFlags(&e->ev_z, hipEventDisableTiming));
     HIP_OK(dalloc(&e->join_flag, (size_t)4));
     HIP_OK(dalloc(&e->fork_flag, (size_t)4));
     HIP_OK(hipHostMalloc((void**)&e->join_err, 4, hipHostMallocDefault));
@@ -325,10 +324,6 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   HIP_OK(dalloc(&e->scores, Ml * dd));
   HIP_OK(dalloc(&e->probs, Ml * dd));
   if (e->d <= 112) HIP_OK(dalloc(&e->eas, Ml * dd));
-  if (e->stream2 && e->d <= 64 && e->k <= 64) {
-    HIP_OK(dalloc(&e->scores2, Ml * dd));
-    HIP_OK(dalloc(&e->eas2, Ml * dd));
-  }
   HIP_OK(dalloc(&e->thr, Ml * dd));
   HIP_OK(dalloc(&e->w_lik, Ml * dd));
   if (e->d > 112) {
@@ -355,7 +350,7 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
   HIP_OK(dalloc(&e->kz, Ml * e->M + kpad));
   if (c.joint) HIP_OK(dalloc(&e->kt, Ml * e->M + kpad));
   if (c.joint) HIP_OK(dalloc(&e->ksum, Ml * e->M + kpad));
-  if (e->M >= kmat_tiled_min() && !getenv("DIBS_KMAT_OLD")) {  // (the same rule on every rank: it depends on the global particle count only)
+  if (e->M >= e->tune.kmat_tiled_min) {  // (the same rule on every rank: it depends on the global particle count only)
     // room for up to 32 pieces per pair, less for many particles (<= 512 MiB); 1 = no buffer, every unit holds whole distances
     size_t ns = ((size_t)512 << 20) / (Ml * e->M * 8);
     ns = ns > 32 ? 32 : (ns < 1 ? 1 : ns);
@@ -475,7 +470,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (e->stream2) hipStreamSynchronize(e->stream2);
   void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->eas, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
-                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot, e->join_flag, e->fork_flag, e->scores2, e->eas2, e->ksum, e->kpart, e->kmat_ctr};
+                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot, e->join_flag, e->fork_flag, e->carry_bak, e->ksum, e->kpart, e->kmat_ctr};
   for (void* p : ptrs)
     if (p) hipFree(p);
   joint_free(&e->jw);
@@ -486,7 +481,6 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (e->ev_k0) hipEventDestroy(e->ev_k0);
   if (e->ev_k1) hipEventDestroy(e->ev_k1);
   if (e->join_err) hipHostFree(e->join_err);
-  if (e->ev_z) hipEventDestroy(e->ev_z);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
   for (auto& pe : e->pending) {
@@ -622,7 +616,7 @@ extern "C" int dibs_engine_set_data(dibs_engine* e, const float* x, const int32_
     if (bge_prepare(&e->bge, e->cfg, e->d, e->N, x, interv_mask, bge_mean_obs)) return 1;
   } else {
     if (joint_set_data(&e->jw, x, interv_mask, e->N, e->d)) return fail("joint_set_data failed");
-    if (e->cfg.likelihood == DIBS_LIK_LINGAUSS && !joint_lin_fast_path(e->d, e->N) && joint_lin_set_gram(&e->jw, x, interv_mask, e->N, e->d))
+    if (e->cfg.likelihood == DIBS_LIK_LINGAUSS && !joint_lin_fast_path(e->d, e->N, e->tune.lin_gram) && joint_lin_set_gram(&e->jw, x, interv_mask, e->N, e->d))
       return fail("LinearGaussian: Gram matrices: hipMalloc failed");
   }
   e->has_data = true;
@@ -657,7 +651,6 @@ extern "C" int dibs_engine_init_particles(dibs_engine* e, const uint32_t key[2])
   }
   e->kmat_ext = false;  // (a kernel slab computed by dibs_engine_kmat_values belonged to the particles that were just replaced)
   e->vals_fresh = false;
-  e->ev_z_valid = false;
   HIP_OK(hipMemsetAsync(e->vz, 0, (size_t)e->Mloc * e->D * 4, e->stream));
   if (e->P) HIP_OK(hipMemsetAsync(e->vtheta, 0, (size_t)e->Mloc * e->P * 4, e->stream));
   HIP_OK(hipMemsetAsync(e->baseline, 0, (size_t)e->Mloc * 4, e->stream));
@@ -673,7 +666,6 @@ extern "C" int dibs_engine_set_state(dibs_engine* e, const float* z, const float
   HIP_OK(hipStreamSynchronize(e->stream));
   const size_t nz = (size_t)e->Mloc * e->D * 4, nt = (size_t)e->Mloc * e->P * 4;
   if (z || theta) e->vals_fresh = false;
-  e->ev_z_valid = false;
   if (z || theta) e->kmat_ext = false;  // (an externally computed kernel slab belonged to the old values: phase B computes its own unless
                                         //  dibs_engine_kmat_values is called again for the new ones)
   if (z) HIP_OK(hipMemcpy(e->z, z, nz, hipMemcpyHostToDevice));
@@ -780,17 +772,16 @@ struct DevBuf {
   hipError_t alloc(size_t n) { return dalloc(&p, n); }
 };
 
-// One kernel-matrix algorithm per global particle count, on every rank and at every launch site: from kmat_tiled_min() particles the tiled
+// One kernel-matrix algorithm per global particle count, on every rank and at every launch site: from e->tune.kmat_tiled_min particles the tiled
 // kernel (whose entries do not depend on how the work was cut, kernels_kmat.h), below it the direct one.
-static bool kmat_tiled_on(const dibs_engine* e) { return e->kmat_ns_max > 0 && e->M >= kmat_tiled_min(); }
+static bool kmat_tiled_on(const dibs_engine* e) { return e->kmat_ns_max > 0 && e->M >= e->tune.kmat_tiled_min; }
 // rows of all M particles at x + m * stride + off (len floats); this engine's slab [Mloc][M] (symmetric when it holds every particle)
 static void kmat_launch_tiled(dibs_engine* e, hipStream_t st, const float* x, size_t stride, size_t off, size_t len, float* kout, float scale, float h,
                               const float* kadd, float* ksum) {
   const int sym = e->Mloc == e->M;
   // many particles: 64 x 64 tiles (half the bytes per pair; entries bit-identical to the 32 x 32 kernel's) -- from 512 particles, where
-  // there are enough of them for every CU (DIBS_KMAT_T64_MIN)
-  const char* t64 = getenv("DIBS_KMAT_T64_MIN");
-  if (e->M >= (t64 ? atoi(t64) : 512) && kmat_tile64_ok(x, stride, off, len)) {
+  // there are enough of them for every CU (DibsTuning::kmat_t64_min)
+  if (e->M >= e->tune.kmat_t64_min && kmat_tile64_ok(x, stride, off, len)) {
     const int nta = (e->Mloc + KT2_T - 1) / KT2_T, ntb = (e->M + KT2_T - 1) / KT2_T, tiles = kmat_tile_count(nta, ntb, sym);
     const int nchunk = kmat_nchunk64((int)len), ns = kmat_pick_nsplit(tiles, nchunk, e->kmat_ns_max), cps = (nchunk + ns - 1) / ns;
     const KmatTile kt{x, stride, off, (int)len, e->kpart, e->m0, e->Mloc, e->M, nchunk, nta, ntb, sym, ns, cps, scale, h, kout, kadd, ksum, nullptr};
@@ -809,10 +800,6 @@ static void kmat_launch_tiled(dibs_engine* e, hipStream_t st, const float* x, si
   const int units = tiles * ns;
   hipLaunchKernelGGL(k_kmat_tile, dim3((unsigned)(units < 256 ? units : 256)), dim3(KT_NT), kmat_tile_lds_bytes(), st, kt);
   if (ns > 1) hipLaunchKernelGGL(k_kmat_finish, dim3(e->Mloc), dim3(256), 0, st, (const double*)e->kpart, ns, e->Mloc, e->M, sym, scale, h, kout, kadd, ksum, KT_T);
-}
-static bool edge_old_env() {
-  static const bool v = getenv("DIBS_EDGE_OLD") != nullptr;  // (A/B switch: k_edge_scores with four blocks per particle also where k_edge_scores_p applies)
-  return v;
 }
 
 // ---- one SVGD step, split at the exchange point ----------------------------------------------
@@ -880,50 +867,40 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
   // (Until round 4 a small acyclicity launch -- <= 512 blocks: config 2, or a rank of a sharded headline run -- stayed on the main stream: the
   //  fork / join events cost 6 + 6 us of the critical path, more than such a launch could hide.  With the fork as the edge kernel's completion
   //  signal and the join polled inside k_particle_grad the second stream pays at every size: config 2 18 460 -> 20 440 steps/s, a rank of
-  //  a 4- / 8-way headline run 101.0 -> 91.4 / 85.8 -> 78.0 us per step.  DIBS_FORK_MIN_BLOCKS=512 restores the old rule.)
-  static const long fork_min = getenv("DIBS_FORK_MIN_BLOCKS") ? atol(getenv("DIBS_FORK_MIN_BLOCKS")) : 0;  // (tuning override)
-  const bool fork = do_prior && do_lik && e->stream2 != nullptr && (long)e->acyc_nblk * e->Mloc > fork_min, join_now = e->profiling && !e->profiling_concurrent;
-  static const bool want_flag_join = getenv("DIBS_NO_FLAG_JOIN") == nullptr, no_ext_fork = getenv("DIBS_NO_EXT_FORK") != nullptr;
+  //  a 4- / 8-way headline run 101.0 -> 91.4 / 85.8 -> 78.0 us per step.)
+  const bool fork = do_prior && do_lik && e->stream2 != nullptr, join_now = e->profiling && !e->profiling_concurrent;
   // the join inside k_particle_grad (tail_join_wait, agent-scope loads of a flag word the second stream's last kernel stores) instead of an
   // event wait in front of it: -7 us per step.  The polling blocks hold their CUs while the second stream still has kernels to place, so
-  // the flag is used only while they cannot fill the machine (<= 128 particles: one block each on half of the CUs) and the two streams
-  // were seen to run concurrently (streams_concurrent; not under a serialising profiler); otherwise the event.  The wait is bounded
-  // (join_err).  Per-kernel timing always uses the event.
-  static const bool flags_multi = getenv("DIBS_FLAGS_MULTI") != nullptr;
-  const bool flag_join = fork && !join_now && want_flag_join && e->join_flag != nullptr && e->streams_concurrent && e->Mloc <= 128 &&
-                         (flags_multi || g_live_engines.load() == 1);
+  // the flag is used only while they cannot fill the machine (<= 128 particles: one block each on half of the CUs) and the engine's flags
+  // are on for this chunk (flags_now: latch_flags).  The wait is bounded (join_err; a chunk that saw a time-out is run again on events:
+  // run_chunk_guarded).  Per-kernel timing always uses the event.
+  const bool flag_join = fork && !join_now && e->flags_now && e->Mloc <= 128;
   // where this step's kernel matrices come from (single rank): the joint models and many particles put them on the second stream behind the
   // acyclicity chain (kmat_on_s2, see below); otherwise the latent matrix rides inside k_bge_sample
   const bool kmat_on_s2 = c.joint || (long)e->M * e->D > 4L * e->S * e->d * e->d;
-  const bool kmat_early_now = fork && !xk && kmat_on_s2 && e->Mloc == e->M && !e->kmat_ext && !getenv("DIBS_NO_KMAT_EARLY");
+  const bool kmat_early_now = fork && !xk && kmat_on_s2 && e->Mloc == e->M && !e->kmat_ext;
   // marginal models, single rank, 128+ particles: the latent matrix as tile units riding in the k_particle_grad launch (TailArgs::kt)
   const bool tile_in_grad = !c.joint && !xk && !kmat_early_now && !e->kmat_ext && e->Mloc == e->M && e->kmat_ns_max > 1 && e->kmat_ctr != nullptr &&
-                            e->M >= kmat_tiled_min() && e->Mloc < 256 && e->w_tot == nullptr && !getenv("DIBS_NO_KMAT_FUSE") &&
-                            !getenv("DIBS_NO_KMAT_GRAD");
-  // fork without an event (marginal models; DIBS_NO_FLAG_FORK=1: the edge kernel's completion signal as before): k_edge_scores_p stores what
+                            e->M >= e->tune.kmat_tiled_min && e->Mloc < 256 && e->w_tot == nullptr && !e->tune.no_kmat_fuse && !e->tune.no_kmat_grad;
+  // fork without an event (marginal models): k_edge_scores_p stores what
   // the second stream reads (scores, exp(-alpha s)) at agent scope, every block counts itself and the last one publishes a sequence number;
   // one polling wave (k_wait_flag) heads the second stream's chain.  The completion signal cost the NEXT kernel of the main stream 4.7 us
   // (edge -> sample gap; 1.0 us between plain launches).  With the two chains starting together the acyclicity stream must not have
   // priority over the sampling kernel (it took the machine: sampling 130 us, the factorisation then alone for 33): the stream is created
-  // with the LOWEST priority now.  bench.py, same box: event fork 5 193-5 217 steps/s; flag fork with greatest / normal / lowest priority
+  // with the LOWEST priority.  bench.py, same box: event fork 5 193-5 217 steps/s; flag fork with greatest / normal / lowest priority
   // 5 218-5 226 / 5 296 / 5 341; config 2 20 560 -> 22 200.  Joint models keep the event (config 3: 2 345 vs 2 311 with the flag).
-  static const bool want_flag_fork = getenv("DIBS_NO_FLAG_FORK") == nullptr;
-  const bool flag_fork = flag_join && want_flag_fork && !c.joint && !e->profiling && !no_ext_fork && e->fork_flag != nullptr && !edge_old_env() &&
-                         e->d <= 64 && e->k <= 64 && e->edge_kc >= e->k && e->ldk <= 128 && getenv("DIBS_DUP_EDGE") == nullptr;
+  const bool edge_p = e->d <= 64 && e->k <= 64 && e->edge_kc >= e->k && e->ldk <= 128;  // one 16-wave block per particle (k_edge_scores_p)
+  const bool flag_fork = flag_join && !c.joint && !e->profiling && e->fork_flag != nullptr && edge_p;
   // BGe with the score estimator: the flag is published by the FIRST BLOCK OF k_bge_sample instead (it starts when the edge kernel has ended and
-  // released its plain stores): no agent-scope stores and no counting in the edge kernel (DIBS_FORK_PUB_EDGE=1: publish from the edge kernel)
-  const bool fork_pub_in_sample = flag_fork && do_lik && c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_SCORE &&
-                                  !getenv("DIBS_FORK_PUB_EDGE");
-  auto launch_edge = [&](hipStream_t st, hipEvent_t stop_ev, bool copy2 = false) {
+  // released its plain stores): no agent-scope stores and no counting in the edge kernel
+  const bool fork_pub_in_sample = flag_fork && do_lik && c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_SCORE;
+  auto launch_edge = [&](hipStream_t st, hipEvent_t stop_ev) {
     KTimer tm(e, DIBS_K_EDGE, st);
     const size_t lds = (size_t)2 * e->dpad * e->ldk * 4;
-    if (!edge_old_env() && e->d <= 64 && e->k <= 64 && e->edge_kc >= e->k && e->ldk <= 128) {  // one 16-wave block per particle (k_edge_scores_p)
+    if (edge_p) {
       allow_lds(k_edge_scores_p, lds);
       unsigned int* const none = nullptr;
-      if (copy2)  // (the second stream's own copy: scores / eas for the acyclicity kernel)
-        hipLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, e->z, e->scores2, (uint32_t*)nullptr, (float*)nullptr, e->eas2, alpha,
-                           e->d, e->k, e->dpad, e->ldk, none, none, 0u);
-      else if (flag_fork && fork_pub_in_sample) {
+      if (flag_fork && fork_pub_in_sample) {
         ++e->fork_seq;
         hipLaunchKernelGGL(k_edge_scores_p, dim3(e->Mloc), dim3(1024), lds, st, e->z, e->scores, e->thr, e->probs, e->eas, alpha, e->d,
                            e->k, e->dpad, e->ldk, none, none, 0u);
@@ -957,29 +934,19 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
 #undef EDGE_LAUNCH
   };
   // fork without a record packet on the main stream: the event is the edge kernel's own completion signal (hipExtLaunchKernel stop event)
-  const bool ext_fork = fork && !e->profiling && !no_ext_fork;
-  // no fork signal at all: the second stream computes its own scores from Z as soon as the previous optimizer step is done (see ev_z)
-  static const bool no_dup_edge = getenv("DIBS_DUP_EDGE") == nullptr;  // (measured slower: the acyclicity kernel starts 6 us earlier and takes them from k_bge_sample; off unless DIBS_DUP_EDGE=1)
-  const bool dup_edge = ext_fork && !xk && !no_dup_edge && e->ev_z_valid && e->scores2 && !edge_old_env() && e->d <= 64 && e->k <= 64 &&
-                        e->edge_kc >= e->k && e->ldk <= 128;
-  launch_edge(e->stream, (ext_fork && !dup_edge) ? e->ev_fork : nullptr);
+  const bool ext_fork = fork && !e->profiling;
+  launch_edge(e->stream, ext_fork ? e->ev_fork : nullptr);
   bool score_lik = false;
   if (fork) {
-    if (dup_edge) {
-      hipStreamWaitEvent(e->stream2, e->ev_z, 0);
-      launch_edge(e->stream2, nullptr, true);
+    if (flag_fork) {
+      hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, e->stream2, (const unsigned int*)e->fork_flag, e->fork_seq, 0u, e->join_err);
     } else {
-      if (flag_fork) {
-        const unsigned int delay = getenv("DIBS_FORK_DELAY") ? (unsigned int)atoi(getenv("DIBS_FORK_DELAY")) : 0u;
-        hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, e->stream2, (const unsigned int*)e->fork_flag, e->fork_seq, delay, e->join_err);
-      } else {
-        if (!ext_fork) hipEventRecord(e->ev_fork, e->stream);
-        hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
-      }
+      if (!ext_fork) hipEventRecord(e->ev_fork, e->stream);
+      hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
     }
-    const AcycLaunch al{e->stream2, dup_edge ? e->scores2 : e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, Mg, e->Mloc, e->d, e->Sa,
+    const AcycLaunch al{e->stream2, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, Mg, e->Mloc, e->d, e->Sa,
                         e->acyc_cpb, e->acyc_units, e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr,
-                        dup_edge ? e->eas2 : e->eas};
+                        e->eas, e->tune.acyc_pipe, e->tune.acyc_hfw_max};
     acyc_power_timed(e, al, e->stream2);
     {
       KTimer tm(e, DIBS_K_ACYC_REDUCE, e->stream2);
@@ -1018,7 +985,11 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
     e->kmat_early = true;
   }
   if (fork) {
-    if (flag_join) hipLaunchKernelGGL(k_join_flag, dim3(1), dim3(1), 0, e->stream2, e->join_flag, ++e->join_seq);
+    if (flag_join) {
+      ++e->join_seq;
+      if (e->debug_drop_flag) e->debug_drop_flag = false;  // (dibs_engine_debug_drop_next_flag: this step's flag is never stored)
+      else hipLaunchKernelGGL(k_join_flag, dim3(1), dim3(1), 0, e->stream2, e->join_flag, e->join_seq);
+    }
     else hipEventRecord(e->ev_join, e->stream2);
   }
   if (fork && join_now) hipStreamWaitEvent(e->stream, e->ev_join, 0);
@@ -1036,7 +1007,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
       KmatFuse kf{nullptr, nullptr, 0, 0, 0, 0.f, 0.f, nullptr, 0u};
       e->kmat_fused = false;
       // single rank, vector fits one LDS chunk: the latent kernel matrix rides along (see KmatFuse)
-      if (!tile_in_grad && !kmat_tiled_on(e) && !xk && !e->kmat_early && !e->kmat_ext && e->Mloc == e->M && e->D <= KMAT_CH && (size_t)e->D * 4 + 64 <= 80 * 1024 && !getenv("DIBS_NO_KMAT_FUSE")) {
+      if (!tile_in_grad && !kmat_tiled_on(e) && !xk && !e->kmat_early && !e->kmat_ext && e->Mloc == e->M && e->D <= KMAT_CH && (size_t)e->D * 4 + 64 <= 80 * 1024 && !e->tune.no_kmat_fuse) {
         kf = KmatFuse{e->z, e->kz, (int)e->D, e->M, (e->d + 3) / 4, (float)c.scale_latent, (float)c.h_latent, nullptr, 0u};
         e->kmat_fused = true;
       }
@@ -1056,7 +1027,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
     JointLaunch jl{e->stream, e->z, e->theta, e->scores, e->thr, e->w_lik, e->logprobs_z, e->logprobs_th, e->baseline,
                    e->baseline2, pack, rt.stride, rt.th_off, rt.gth_off, rt.copy_vals, e->m0, Mg, e->Mloc, e->d,
                    e->N, e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny, c.grad_estimator_z, c.score_function_baseline,
-                   (float)c.lin_obs_noise, (float)c.lin_mean_edge, (float)c.lin_sig_edge};
+                   (float)c.lin_obs_noise, (float)c.lin_mean_edge, (float)c.lin_sig_edge, e->tune.lin_f32, e->tune.nn_f32};
     {
       KTimer tm(e, DIBS_K_LIN_THETA);  // ("lin_logprobs": both log-prob launches)
       joint_lin_all_logprobs(&e->jw, jl, carry_theta, carry_lik);
@@ -1070,7 +1041,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
     JointLaunch jl{e->stream, e->z, e->theta, e->scores, e->thr, e->w_lik, e->logprobs_z, e->logprobs_th, e->baseline,
                    e->baseline2, pack, rt.stride, rt.th_off, rt.gth_off, rt.copy_vals, e->m0, Mg, e->Mloc, e->d,
                    e->N, e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny, c.grad_estimator_z, c.score_function_baseline,
-                   0.f, 0.f, 0.f};
+                   0.f, 0.f, 0.f, e->tune.lin_f32, e->tune.nn_f32};
     const NNParams np_ = nn_params(c);
     {
       KTimer tm(e, DIBS_K_NN_THETA);
@@ -1088,7 +1059,8 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
     if (!flag_join) hipStreamWaitEvent(e->stream, e->ev_join, 0);
   } else if (do_prior) {
     const AcycLaunch al{e->stream, e->scores, e->acyc_part, e->w_acyc, e->acyc_big, carry_prior, e->m0, Mg, e->Mloc, e->d, e->Sa, e->acyc_cpb, e->acyc_units,
-                        e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr, e->eas};
+                        e->acyc_nblk, alpha, (float)c.tau, c.rng_layout, c.logistic_minval_tiny, nullptr, nullptr, e->eas, e->tune.acyc_pipe,
+                        e->tune.acyc_hfw_max};
     acyc_power_timed(e, al, e->stream);
     {
       // (folding this reduction into k_particle_grad for small grids -- one dependent launch less -- was measured and dropped: the tail
@@ -1123,7 +1095,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
       const int nta = (e->M + KT_T - 1) / KT_T, tiles = kmat_tile_count(nta, nta, 1), nchunk = kmat_nchunk((int)e->D);
       // (pieces: enough units for the CUs the particles leave free, one round of them -- measured at the headline size, launch time on the
       //  event timer: no units 20.7 us; 100 units of 2 chunks 21.2; 70 of 3 chunks 25.2; 200 of 1 chunk on 128 blocks 25.8)
-      int ns = getenv("DIBS_KMAT_GRAD_NS") ? atoi(getenv("DIBS_KMAT_GRAD_NS")) : (256 - e->Mloc + tiles - 1) / tiles;  // (tuning override)
+      int ns = (256 - e->Mloc + tiles - 1) / tiles;
       ns = ns > nchunk ? nchunk : ns;
       ns = ns > e->kmat_ns_max ? e->kmat_ns_max : ns;
       const int cps = (nchunk + ns - 1) / ns;
@@ -1196,17 +1168,11 @@ static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_s
   }
   {
     KTimer tm(e, DIBS_K_PHI_UPDATE);
-    // the LAST optimizer launch of a step carries "the particles of the next step are final" as its own completion signal (ev_z)
-    static const bool dup_edge_on = getenv("DIBS_DUP_EDGE") != nullptr;
-    const bool mark_z = dup_edge_on && e->stream2 != nullptr && e->ev_z != nullptr && e->scores2 != nullptr && !e->profiling;
-    e->ev_z_valid = false;
     auto phi = [&](size_t val_off, size_t grad_off, size_t len, int is_theta, float* x, float* v, float* phi_out, float h) {
-      const hipEvent_t stop_ev = (mark_z && (is_theta || !c.joint)) ? e->ev_z : nullptr;
       // particles per block: as many as keep >= 1024 blocks in flight and the tables within the LDS budget
       // (headline size: TA = 16 / 8 / 4 measured 20.5 / 18.9 / 26.0 us)
       const long cols = (long)((len + 63) / 64);
-      static const bool phi_valu = getenv("DIBS_PHI_VALU") != nullptr;  // (A/B switch for measurements)
-      if (e->M >= 256 && !phi_valu) {  // many particles: the transform as one GEMM on the matrix pipe (a function of the GLOBAL count only)
+      if (e->M >= 256) {  // many particles: the transform as one GEMM on the matrix pipe (a function of the GLOBAL count only)
         const int nrb = (e->Mloc + PG_BM - 1) / PG_BM;
 #define PHI_GEMM(J_)                                                                                                                        \
         hipLaunchKernelGGL(k_phi_gemm<J_>, dim3((unsigned)(8 * nrb * ((cols + 7) / 8))), dim3(256), 0, e->stream, pack, rs.stride, val_off,   \
@@ -1218,8 +1184,6 @@ static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_s
       }
       int ta = 16;
       while (ta > 4 && (cols * ((e->Mloc + ta - 1) / ta) < 1024 || phi_update_lds_bytes(ta, e->M) > 56 * 1024)) ta >>= 1;
-      static const int ta_env = getenv("DIBS_PHI_TA") ? atoi(getenv("DIBS_PHI_TA")) : 0;  // (tuning override: 4, 8 or 16)
-      if ((ta_env == 4 || ta_env == 8 || ta_env == 16) && phi_update_lds_bytes(ta_env, e->M) <= LDS_LIMIT - 2048) ta = ta_env;
       const size_t lds = phi_update_lds_bytes(ta, e->M);
       const int ngroups = (e->Mloc + ta - 1) / ta;
       const dim3 g((unsigned)(8 * ngroups * ((cols + 7) / 8)));
@@ -1227,21 +1191,13 @@ static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_s
       const float* const kw = e->kt ? e->ksum : e->kz;
       const float* const kseg = e->kt ? (is_theta ? e->kt : e->kz) : nullptr;
       // FULL: whole 8-pair batches per wave and whole particle groups (no clamps inside the kernel)
-      static const bool no_full = getenv("DIBS_PHI_NOFULL") != nullptr;  // (A/B switch)
-      const bool full = !no_full && e->M % 64 == 0 && e->Mloc % ta == 0 && (size_t)e->M * rs.stride * 4 < ((size_t)1 << 32);  // (32-bit buffer offsets)
+      const bool full = e->M % 64 == 0 && e->Mloc % ta == 0 && (size_t)e->M * rs.stride * 4 < ((size_t)1 << 32);  // (32-bit buffer offsets)
 #define PHI_LAUNCH(TA_, F_, J_)                                                                                                \
       {                                                                                                                          \
         allow_lds(k_phi_update<TA_, F_, J_>, lds);                                                                               \
-        if (stop_ev)                                                                                                             \
-          hipExtLaunchKernelGGL((k_phi_update<TA_, F_, J_>), g, dim3(256), lds, e->stream, nullptr, stop_ev, 0, pack, rs.stride, val_off, grad_off, \
-                                (int)len, kw, kseg, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize,      \
-                                c.optimizer == DIBS_OPT_RMSPROP, (int)cols, ngroups, vals_send, (size_t)e->Ev,                    \
-                                is_theta ? (size_t)e->D : (size_t)0);                                                             \
-        else                                                                                                                     \
-          hipLaunchKernelGGL((k_phi_update<TA_, F_, J_>), g, dim3(256), lds, e->stream, pack, rs.stride, val_off, grad_off, (int)len, kw,   \
-                             kseg, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize, c.optimizer == DIBS_OPT_RMSPROP, \
-                             (int)cols, ngroups, vals_send, (size_t)e->Ev, is_theta ? (size_t)e->D : (size_t)0);             \
-        if (stop_ev) e->ev_z_valid = true;                                                                                       \
+        hipLaunchKernelGGL((k_phi_update<TA_, F_, J_>), g, dim3(256), lds, e->stream, pack, rs.stride, val_off, grad_off, (int)len, kw,     \
+                           kseg, is_theta, x, v, phi_out, e->m0, e->Mloc, e->M, h, (float)c.stepsize, c.optimizer == DIBS_OPT_RMSPROP,   \
+                           (int)cols, ngroups, vals_send, (size_t)e->Ev, is_theta ? (size_t)e->D : (size_t)0);               \
       }
 #define PHI_PICK(TA_)                                                                                                          \
       if (e->kt) { if (full) PHI_LAUNCH(TA_, true, true) else PHI_LAUNCH(TA_, false, true) }                                     \
@@ -1258,15 +1214,67 @@ static int step_update(dibs_engine* e, int t, const RowSource& rs, float* vals_s
   return 0;
 }
 
-// after a chunk has been synchronised: did a k_particle_grad give up waiting for the second stream (tail_join_wait)?
-static int check_join(dibs_engine* e) {
-  if (e->join_err && *e->join_err) {
-    const unsigned int code = *e->join_err;
-    *e->join_err = 0u;
-    if (code == 2u)
-      return fail("internal: the edge kernel's completion flag did not arrive (k_wait_flag on the second stream timed out; results of this chunk are invalid)");
-    return fail("internal: the acyclicity stream's completion flag did not arrive (k_particle_grad timed out waiting; results of this chunk are invalid)");
+// does this chunk / call use the in-kernel flags?  Decided here, once per chunk (not per step): the tuning switch, an earlier time-out,
+// the creation-time probe, and the engine being alone in its process (several engines share hardware queues: a polling kernel at the head
+// of a shared queue holds up the kernels behind it, possibly the one it waits for)
+static void latch_flags(dibs_engine* e) {
+  e->flags_now = !e->tune.no_flags && !e->flags_off && e->join_flag != nullptr && e->streams_concurrent &&
+                 (e->tune.flags_multi || g_live_engines.load() == 1);
+}
+
+// after a chunk has been synchronised: did a kernel give up waiting for a flag (tail_join_wait / k_wait_flag)?  Clears the word.
+static unsigned int take_join_err(dibs_engine* e) {
+  if (!e->join_err || !*e->join_err) return 0u;
+  const unsigned int code = *e->join_err;
+  *e->join_err = 0u;
+  return code;
+}
+static int join_failure(unsigned int code, const char* what) {
+  return fail(std::string(code == 2u ? "internal: the edge kernel's completion flag did not arrive (k_wait_flag on the second stream timed out)"
+                                     : "internal: the acyclicity stream's completion flag did not arrive (k_particle_grad timed out waiting)") + what);
+}
+
+// the loop carry of this rank (svgd.py:315: optimizer states, key, baselines) copied aside / back in ONE launch
+struct CopySegs {
+  const float* src[5];
+  float* dst[5];
+  size_t n[5];
+};
+__global__ __launch_bounds__(256) void k_copy_segs(CopySegs c) {
+  const int sg = (int)blockIdx.y;
+  const float* __restrict__ a = c.src[sg];
+  float* __restrict__ b = c.dst[sg];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < c.n[sg]; i += (size_t)gridDim.x * 256) b[i] = a[i];
+}
+static int carry_copy(dibs_engine* e, bool restore) {
+  const size_t nz = (size_t)e->Mloc * e->D, nt = (size_t)e->Mloc * e->P, nb = (size_t)e->Mloc;
+  if (!e->carry_bak) HIP_OK(dalloc(&e->carry_bak, 2 * nz + 2 * nt + nb));
+  float* const b = e->carry_bak;
+  float* live[5] = {e->z, e->vz, e->theta, e->vtheta, e->baseline};
+  float* bak[5] = {b, b + nz, b + 2 * nz, b + 2 * nz + nt, b + 2 * nz + 2 * nt};
+  const size_t n[5] = {nz, nz, nt, nt, nb};
+  CopySegs c;
+  for (int i = 0; i < 5; ++i) {
+    c.src[i] = restore ? bak[i] : live[i];
+    c.dst[i] = restore ? live[i] : bak[i];
+    c.n[i] = n[i];
   }
+  hipLaunchKernelGGL(k_copy_segs, dim3(256, 5), dim3(256), 0, e->stream, c);
+  if (restore) e->key = e->key_bak;
+  else e->key_bak = e->key;
+  return 0;
+}
+
+static int run_steps(dibs_engine* e, int t_start, int n_steps) {
+  for (int t = t_start; t < t_start + n_steps; ++t) {
+    if (step_local(e, t, packed_rows(e, e->pack))) return 1;
+    if (step_update(e, t, packed_source(e, e->pack))) return 1;
+    if (e->profiling && e->pending.size() > 4096) drain_timers(e);
+  }
+  HIP_OK(hipStreamSynchronize(e->stream));
+  if (e->stream2) HIP_OK(hipStreamSynchronize(e->stream2));
+  if (e->profiling) drain_timers(e);
+  HIP_OK(hipGetLastError());
   return 0;
 }
 
@@ -1275,21 +1283,37 @@ extern "C" int dibs_engine_run(dibs_engine* e, int32_t t_start, int32_t n_steps)
   if (!e->has_data) return fail("dibs_engine_set_data has not been called");
   if (e->cfg.n_ranks != 1) return fail("dibs_engine_run is single-rank; use step_local / step_update");
   HIP_OK(hipSetDevice(e->cfg.device_id));
-  for (int t = t_start; t < t_start + n_steps; ++t) {
-    if (step_local(e, t, packed_rows(e, e->pack))) return 1;
-    if (step_update(e, t, packed_source(e, e->pack))) return 1;
-    if (e->profiling && e->pending.size() > 4096) drain_timers(e);
+  latch_flags(e);
+  const bool guarded = e->flags_now && n_steps > 0;
+  if (guarded && carry_copy(e, false)) return 1;  // (one launch per chunk: 10 MB at the headline size, ~4 us)
+  if (run_steps(e, t_start, n_steps)) return 1;
+  unsigned int code = take_join_err(e);
+  if (code && guarded) {
+    // a polling kernel ran into its bound: its step, and every step behind it, used operands that were not complete.  Back to the
+    // chunk's start, flags off for good, the same steps again on events.
+    e->flags_off = true;
+    ++e->flag_fallbacks;
+    latch_flags(e);
+    if (carry_copy(e, true)) return 1;
+    if (run_steps(e, t_start, n_steps)) return 1;
+    code = take_join_err(e);
   }
-  HIP_OK(hipStreamSynchronize(e->stream));
-  if (e->profiling) drain_timers(e);
-  HIP_OK(hipGetLastError());
-  return check_join(e);
+  if (code) return join_failure(code, "; the results of this chunk are invalid");
+  return 0;
+}
+
+extern "C" int dibs_engine_flag_fallbacks(const dibs_engine* e) { return e ? e->flag_fallbacks : -1; }
+extern "C" int dibs_engine_debug_drop_next_flag(dibs_engine* e) {
+  if (!e) return fail("null engine");
+  e->debug_drop_flag = true;
+  return 0;
 }
 
 extern "C" int dibs_engine_step_local(dibs_engine* e, int32_t t, void* send_dev) {
   if (!e || !send_dev) return fail("null argument");
   if (!e->has_data) return fail("dibs_engine_set_data has not been called");
   HIP_OK(hipSetDevice(e->cfg.device_id));
+  latch_flags(e);
   // send_dev holds only this rank's rows: [Mloc, E]; kernels index rows by global particle id
   float* base = (float*)send_dev - (size_t)e->m0 * e->E;
   return step_local(e, t, packed_rows(e, base));
@@ -1313,6 +1337,7 @@ extern "C" int dibs_engine_step_local_grads(dibs_engine* e, int32_t t, void* gra
   if (!e || !grads_send_dev) return fail("null argument");
   if (!e->has_data) return fail("dibs_engine_set_data has not been called");
   HIP_OK(hipSetDevice(e->cfg.device_id));
+  latch_flags(e);
   // rows [grad_z | grad_theta] of this rank's particles, stride Ev; kernels index rows by global particle id
   float* base = (float*)grads_send_dev - (size_t)e->m0 * e->Ev;
   return step_local(e, t, RowTarget{base, (size_t)e->Ev, 0, 0, (size_t)e->D, 0});
@@ -1459,6 +1484,9 @@ extern "C" int dibs_engine_comm_destroy(dibs_engine* e) {
       e->comm[i] = nullptr;
     }
   e->n_comms = 0;
+  if (e->agree_dev) hipFree(e->agree_dev);
+  if (e->agree_host) hipHostFree(e->agree_host);
+  e->agree_dev = e->agree_host = nullptr;
   if (e->ipc.arena || e->ipc.err) {
     // (the peers must have left their last exchange: every rank returns from dibs_engine_run_sharded / gather_particles only after it has seen
     //  all of its peers' rows, and nobody writes into an arena outside an exchange)
@@ -1495,6 +1523,8 @@ extern "C" int dibs_engine_comm_init(dibs_engine* e, const void* ids, int32_t n_
     RCCL_OK(rccl().comm_init_rank(&e->comm[i], e->cfg.n_ranks, id, e->cfg.rank));
   }
   e->n_comms = n_ids;
+  HIP_OK(dalloc(&e->agree_dev, (size_t)4 + 4 * e->cfg.n_ranks));
+  HIP_OK(hipHostMalloc((void**)&e->agree_host, ((size_t)4 + 4 * e->cfg.n_ranks) * 4, hipHostMallocDefault));
   if (n_ids == 2) {
     HIP_OK(dalloc(&e->planes, (size_t)2 * e->M * e->Ev));
     HIP_OK(dalloc(&e->vsend, (size_t)e->Mloc * e->Ev));
@@ -1567,10 +1597,9 @@ extern "C" int dibs_engine_comm_init_ipc(dibs_engine* e, const void* blobs_all) 
   }
   HIP_OK(hipHostMalloc((void**)&c.err, 4, hipHostMallocDefault));
   *c.err = 0u;
-  if (const char* tm = getenv("DIBS_IPC_TIMEOUT_MS")) {  // (read once per communicator: how long a rank waits for its peers' rows)
-    const long ms = atol(tm);
-    if (ms > 0) c.wait_ticks = (unsigned long long)ms * 100000ull;
-  }
+  if (e->tune.ipc_timeout_ms > 0) c.wait_ticks = (unsigned long long)e->tune.ipc_timeout_ms * 100000ull;  // (100 MHz ticks; tuning.h)
+  HIP_OK(dalloc(&e->agree_dev, (size_t)4 + 4 * e->cfg.n_ranks));
+  HIP_OK(hipHostMalloc((void**)&e->agree_host, ((size_t)4 + 4 * e->cfg.n_ranks) * 4, hipHostMallocDefault));
   HIP_OK(dalloc(&e->vsend, (size_t)e->Mloc * e->Ev));
   HIP_OK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
   HIP_OK(hipEventCreateWithFlags(&e->ev_exported, hipEventDisableTiming));
@@ -1648,15 +1677,8 @@ static int ipc_check(dibs_engine* e) {
   return 0;
 }
 
-// replaces _svgd_loop for a particle-sharded run: every rank calls it with the same (t_start, n_steps).  overlapped = 0: phase A -> ONE
-// ncclAllGather of the packed rows [z | grad_z | theta | grad_theta] (in place in the engine's row buffer, on the engine stream) ->
-// phase B.  overlapped = 1: values gathered on the side stream beside phase A, only the gradient rows between the phases.
-extern "C" int dibs_engine_run_sharded(dibs_engine* e, int32_t t_start, int32_t n_steps, int32_t overlapped) {
-  if (!e) return fail("null engine");
-  if (!e->has_data) return fail("dibs_engine_set_data has not been called");
-  if (e->n_comms < 1) return fail("dibs_engine_comm_init has not been called");
-  if (overlapped && e->n_comms < 2) return fail("the overlapped exchange needs two communicators (dibs_engine_comm_init with n_ids = 2)");
-  HIP_OK(hipSetDevice(e->cfg.device_id));
+// the steps of one sharded chunk, enqueued and synchronised
+static int run_sharded_steps(dibs_engine* e, int t_start, int n_steps, int overlapped) {
   const size_t grad_plane = (size_t)e->M * e->Ev;
   if (overlapped && !e->vals_fresh && exchange_values(e, false)) return 1;
   for (int t = t_start; t < t_start + n_steps; ++t) {
@@ -1687,11 +1709,65 @@ extern "C" int dibs_engine_run_sharded(dibs_engine* e, int32_t t_start, int32_t 
     if (e->profiling && e->pending.size() > 4096) drain_timers(e);
   }
   HIP_OK(hipStreamSynchronize(e->stream));
+  if (e->stream2) HIP_OK(hipStreamSynchronize(e->stream2));
   if (overlapped) HIP_OK(hipStreamSynchronize(e->side));
   if (e->profiling) drain_timers(e);
   HIP_OK(hipGetLastError());
+  return ipc_check(e);
+}
+
+// Every rank learns whether ANY rank's chunk saw a flag time-out (the rows such a rank exchanged were computed from incomplete operands, so
+// all ranks' results are invalid together): one all-gather of the ranks' error words, through the same backend as the rows.  *any = the
+// largest word.  Costs one tiny collective + a host round trip per CHUNK.
+static int agree_on_error(dibs_engine* e, unsigned int mine, unsigned int* any) {
+  *any = mine;
+  if (e->loopback || e->cfg.n_ranks == 1) return 0;
+  const int R = e->cfg.n_ranks;
+  for (int i = 0; i < 4; ++i) e->agree_host[i] = mine;
+  HIP_OK(hipMemcpyAsync(e->agree_dev, e->agree_host, 16, hipMemcpyHostToDevice, e->stream));
+  if (e->ipc.on) {
+    const size_t off = IPC_AGREE_OFF + (size_t)(e->ipc.agree_seq & 1u) * IPC_MAX_RANKS * 16;
+    ++e->ipc.agree_seq;
+    if (ipc_all_gather(e, 0, e->stream, reinterpret_cast<const float*>(e->agree_dev), off + (size_t)e->cfg.rank * 16, 4, true)) return 1;
+    HIP_OK(hipMemcpyAsync(e->agree_host + 4, e->ipc.arena + off, (size_t)R * 16, hipMemcpyDeviceToHost, e->stream));
+  } else {
+    RCCL_OK(rccl().all_gather(e->agree_dev, e->agree_dev + 4, 4, ncclUint32, e->comm[0], e->stream));
+    HIP_OK(hipMemcpyAsync(e->agree_host + 4, e->agree_dev + 4, (size_t)R * 16, hipMemcpyDeviceToHost, e->stream));
+  }
+  HIP_OK(hipStreamSynchronize(e->stream));
   if (ipc_check(e)) return 1;
-  return check_join(e);
+  for (int r = 0; r < R; ++r)
+    if (e->agree_host[4 + 4 * r] > *any) *any = e->agree_host[4 + 4 * r];
+  return 0;
+}
+
+// replaces _svgd_loop for a particle-sharded run: every rank calls it with the same (t_start, n_steps).  overlapped = 0: phase A -> ONE
+// all-gather of the packed rows [z | grad_z | theta | grad_theta] (in place in the row buffer, on the engine stream) -> phase B.
+// overlapped = 1: values gathered on the side stream beside phase A, only the gradient rows between the phases.
+// A flag time-out on ANY rank (see latch_flags) makes ALL ranks repeat the chunk on events from their chunk-start copies of the carry.
+extern "C" int dibs_engine_run_sharded(dibs_engine* e, int32_t t_start, int32_t n_steps, int32_t overlapped) {
+  if (!e) return fail("null engine");
+  if (!e->has_data) return fail("dibs_engine_set_data has not been called");
+  if (e->n_comms < 1) return fail("dibs_engine_comm_init has not been called");
+  if (overlapped && e->n_comms < 2) return fail("the overlapped exchange needs two communicators (dibs_engine_comm_init with n_ids = 2)");
+  HIP_OK(hipSetDevice(e->cfg.device_id));
+  latch_flags(e);
+  if (n_steps > 0 && carry_copy(e, false)) return 1;
+  if (run_sharded_steps(e, t_start, n_steps, overlapped)) return 1;
+  if (n_steps <= 0) return 0;
+  unsigned int any = 0u;
+  if (agree_on_error(e, take_join_err(e), &any)) return 1;
+  if (any) {
+    e->flags_off = true;
+    ++e->flag_fallbacks;
+    latch_flags(e);
+    if (carry_copy(e, true)) return 1;
+    e->vals_fresh = false;  // (the overlapped protocol gathers the restored values again: every rank does)
+    if (run_sharded_steps(e, t_start, n_steps, overlapped)) return 1;
+    if (agree_on_error(e, take_join_err(e), &any)) return 1;
+    if (any) return join_failure(any, " on a rank of this run, twice; the results of this chunk are invalid");
+  }
+  return 0;
 }
 
 // z (and theta) of ALL ranks' particles after a sharded run, on every rank: [M][d][k][2] and [M][P] host buffers (either may be NULL).
@@ -1734,7 +1810,11 @@ extern "C" int dibs_engine_sync(dibs_engine* e) {
   HIP_OK(hipSetDevice(e->cfg.device_id));
   HIP_OK(hipStreamSynchronize(e->stream));
   if (e->profiling) drain_timers(e);
-  return check_join(e);
+  if (const unsigned int code = take_join_err(e)) {
+    e->flags_off = true;  // (a loop driven step by step from outside cannot be repeated here: the caller's steps since the last sync are lost)
+    return join_failure(code, "; the steps since the last dibs_engine_sync are invalid (the engine uses events from now on)");
+  }
+  return 0;
 }
 
 extern "C" int64_t dibs_engine_theta_size(const dibs_engine* e) { return e ? e->P : 0; }
@@ -1897,7 +1977,7 @@ extern "C" int dibs_score_graphs(dibs_engine* e, const int32_t* g, const float* 
     struct { JointWork& jw; } jg{sc.jw};
     if (!cached) {
       if (joint_set_data(&jg.jw, x_ho, mask_ho, n_ho, d)) return fail("joint_set_data failed");
-      if (!nn && !joint_lin_fast_path(d, n_ho) && joint_lin_set_gram(&jg.jw, x_ho, mask_ho, n_ho, d)) return fail("LinearGaussian: Gram matrices: hipMalloc failed");
+      if (!nn && !joint_lin_fast_path(d, n_ho, e->tune.lin_gram) && joint_lin_set_gram(&jg.jw, x_ho, mask_ho, n_ho, d)) return fail("LinearGaussian: Gram matrices: hipMalloc failed");
       sc.remember(x_ho, mask_ho, n_x);
     }
     const size_t P = nn ? (size_t)e->P : dd;

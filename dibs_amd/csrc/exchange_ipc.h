@@ -7,7 +7,8 @@
 // peer access work the same way (hipIpcOpenMemHandle maps the peer's memory; the stores travel over xGMI).
 //
 // Arena of a rank (one hipMalloc, one handle):
-//   [ flags: u32 [2 channels][IPC_MAX_RANKS], 256 B ] [ pack[0] | pack[1] : M x E floats each ] [ set[0] | set[1] : 2 x M x Ev floats each ]
+//   [ flags: u32 [2 channels][IPC_MAX_RANKS] | error words of the chunk agreement: 2 x [IPC_MAX_RANKS] x 16 B; 1 KB in all ]
+//   [ pack[0] | pack[1] : M x E floats each ] [ set[0] | set[1] : 2 x M x Ev floats each ]
 //   pack[p]   packed rows [z | grad_z | theta | grad_theta] of ALL particles (one exchange per step)
 //   set[p]    planes of the overlapped protocol: plane 0 = values [z | theta], plane 1 = gradients, of ALL particles
 // Every buffer exists twice.  Exchange number n of a channel writes into copy n & 1: a rank that is already in exchange n has passed its wait
@@ -25,7 +26,8 @@
 #include <stdint.h>
 
 #define IPC_MAX_RANKS 16
-#define IPC_FLAG_BYTES 256
+#define IPC_FLAG_BYTES 1024
+#define IPC_AGREE_OFF 256  /* [2 copies][IPC_MAX_RANKS] x 16 bytes: the ranks' error words of a chunk (run_sharded's agreement) */
 #define IPC_MAGIC 0x43504944u /* "DIPC" */
 
 struct IpcPeers {
@@ -52,6 +54,7 @@ struct IpcComm {
   bool opened[IPC_MAX_RANKS] = {};
   uint32_t seq[2] = {0u, 0u};    // exchanges issued so far per channel
   uint32_t pack_seq = 0;          // packed-row exchanges (selects pack[0 / 1])
+  uint32_t agree_seq = 0;         // chunk agreements (selects the copy of the error words)
   int vset = 0;                   // plane set of the latest value exchange (the gradient rows of that step go to the same set)
   unsigned int* err = nullptr;    // pinned host word raised by k_ipc_signal_wait on a time-out
   unsigned long long wait_ticks = 1000000000ull;  // 10 s of the 100 MHz clock

@@ -244,153 +244,6 @@ __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scor
   if (tid == 0) logprobs[(size_t)m * S + s] = (float)(red[0] + red[1] + red[2] + red[3]);
 }
 
-// ------------------------------------------------------------------------------------------------
-// d <= 64: the same computation with this lane's matrix row in REGISTERS.  The generic kernel above reads both operands of every FMA
-// from LDS (own row + broadcast row): 256 B of LDS traffic per wave-FMA against 128 B per clock and CU -- LDS-bound at a quarter of the
-// vector rate, at one or two waves per SIMD.  Here lane r keeps L[r][0..kk) (factorisation) and then its column of L^-1 (forward
-// substitution) in registers; only the broadcast operand -- row kk of L, four values per ds_read_b128 -- comes from LDS.  Register
-// arrays need compile-time indices: the kernel is instantiated for DP = d rounded up to 8 and every loop is unrolled (rows / columns
-// d .. DP-1 are identity padding, p = 0).
-// LDS per wave: L row-major [DP][DP + 4] | b, w, p, y, dinv [DP] each
-// ------------------------------------------------------------------------------------------------
-template <int DP>
-__host__ __device__ inline size_t bge_softr_wave_bytes() { return ((size_t)DP * (DP + 4) + 5 * DP) * 4; }
-template <int DP>
-__host__ __device__ inline size_t bge_softr_lds_bytes(int d, bool r_in_lds) { return bge_soft_shared_bytes(d, r_in_lds) + 4 * bge_softr_wave_bytes<DP>(); }
-
-template <int DP, bool R_LDS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_bge_soft_reg(const float* __restrict__ scores, BgeSoftParams bp, Key2 carry, int m0, int M_global,
-                                                      int d, int S, float alpha, float tau, int layout, int tiny,
-                                                      float* __restrict__ ds_out, float* __restrict__ logprobs) {
-  constexpr int LDL = DP + 4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int s = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int dd = d * d;
-  float* Rs = reinterpret_cast<float*>(smem_raw);
-  double* red = reinterpret_cast<double*>(smem_raw + bge_soft_shared_bytes(d, R_LDS) - 256);
-  float* Lr = reinterpret_cast<float*>(smem_raw + bge_soft_shared_bytes(d, R_LDS) + (size_t)wave * bge_softr_wave_bytes<DP>());
-  float* bv = Lr + DP * LDL;
-  float* wv = bv + DP;
-  float* pv = wv + DP;
-  float* yv = pv + DP;
-  float* dinv = yv + DP;
-  const float* sc_m = scores + (size_t)m * dd;
-  const Key2 key = lin_mode_key(LIN_MODE_Z_REPARAM, carry, M_global, m0 + m, layout);  // dibs.py:430-431
-  const uint64_t nbits = (uint64_t)S * dd;
-  if (R_LDS)
-    for (int e = tid; e < dd; e += 256) Rs[e] = bp.R[e];
-  if (tid < 4) red[tid] = 0.0;
-  __syncthreads();
-  float* out = ds_out + ((size_t)m * S + s) * dd;
-  double lp_wave = 0.0;
-  const bool act = lane < d, inrow = lane < DP;
-  for (int j = wave; j < d; j += 4) {
-    const float* R = R_LDS ? Rs : bp.R + (bp.n_mats > 1 ? (size_t)j * dd : 0);
-    const float* Rrow = R + (act ? lane : 0) * d;
-    const float g = act ? lin_sample_g(LIN_MODE_Z_REPARAM, key, nbits, (uint64_t)dd, s, lane, j, d, nullptr, sc_m, alpha, tau, layout, tiny) : 0.f;
-    const float p = g;  // column j of the soft graph (dibs.py:121-140); 0 on the diagonal and on the padding rows
-    const double l = wave_sum_d((double)p);
-    if (inrow) {
-      pv[lane] = p;
-      bv[lane] = act ? p * R[j * d + lane] : 0.f;
-    }
-    wave_lds_fence();
-    // ---- Cholesky of M_pa = I + D R~ D, column by column; lane = row, row in registers ------------------------------------
-    float row[DP];
-    float dm1 = 0.f;  // L_rr^2 - 1 of this lane's row (kept without the 1: no cancellation for small p)
-#pragma unroll
-    for (int kk = 0; kk < DP; ++kk) {
-      const float rk = (act && kk < d) ? Rrow[kk < d ? kk : 0] : 0.f;
-      // (four independent partial sums: at one or two waves per SIMD a single dependent FMA chain would issue every ~8 cycles)
-      float acc = p * pv[kk] * (rk - (lane == kk ? 1.f : 0.f)), acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-#pragma unroll
-      for (int q0 = 0; q0 < kk; q0 += 4) {
-        const float4 lk = *reinterpret_cast<const float4*>(Lr + kk * LDL + q0);  // row kk of L: broadcast
-        acc = fmaf(-row[q0], lk.x, acc);
-        if (q0 + 1 < kk) acc1 = fmaf(-row[q0 + 1], lk.y, acc1);
-        if (q0 + 2 < kk) acc2 = fmaf(-row[q0 + 2], lk.z, acc2);
-        if (q0 + 3 < kk) acc3 = fmaf(-row[q0 + 3], lk.w, acc3);
-      }
-      acc = (acc + acc1) + (acc2 + acc3);
-      const float pivm1 = __shfl(acc, kk, 64);
-      const float piv = 1.0f + pivm1;
-      const float inv = rsqrtf(piv);
-      const float lv = lane == kk ? piv * inv : (lane > kk ? acc * inv : 0.f);
-      row[kk] = lv;
-      if (lane == kk) {
-        dm1 = pivm1;
-        dinv[kk] = inv;
-      }
-      if (inrow) Lr[lane * LDL + kk] = lv;
-      wave_lds_fence();
-    }
-    const double ld_pa = wave_sum_d(inrow ? log((double)(1.0f + dm1)) : 0.0);
-    // ---- forward substitution: lane c solves L u = e_c (column c of L^-1), lane j solves L w = b -----------------------------
-    float u[DP];
-    const bool isj = lane == j;
-#pragma unroll
-    for (int k = 0; k < DP; ++k) {
-      float v = isj ? bv[k] : (lane == k ? 1.f : 0.f), v1 = 0.f, v2 = 0.f, v3 = 0.f;
-#pragma unroll
-      for (int q0 = 0; q0 < k; q0 += 4) {
-        const float4 lk = *reinterpret_cast<const float4*>(Lr + k * LDL + q0);
-        v = fmaf(-lk.x, u[q0], v);
-        if (q0 + 1 < k) v1 = fmaf(-lk.y, u[q0 + 1], v1);
-        if (q0 + 2 < k) v2 = fmaf(-lk.z, u[q0 + 2], v2);
-        if (q0 + 3 < k) v3 = fmaf(-lk.w, u[q0 + 3], v3);
-      }
-      v = (v + v1) + (v2 + v3);
-      u[k] = v * dinv[k];
-      if (isj) wv[k] = u[k];
-    }
-    wave_lds_fence();
-    // (M_pa^-1)_cc = |column c of L^-1|^2 (its off-diagonal part here), y_c = column c . w, |w|^2 for the Schur complement
-    float offd = 0.f, y = 0.f, w2 = 0.f;
-#pragma unroll
-    for (int k0 = 0; k0 < DP; k0 += 4) {
-      const float4 w4 = *reinterpret_cast<const float4*>(wv + k0);
-      const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float uk = u[k0 + i];
-        offd = fmaf(k0 + i > lane ? uk : 0.f, uk, offd);
-        y = fmaf(uk, ws[i], y);
-        w2 = fmaf(ws[i], ws[i], w2);
-      }
-    }
-    if (isj) y = 0.f;  // row j of M_pa is the identity and b_j = 0
-    if (inrow) yv[lane] = y;
-    const double sch = (double)R[j * d + j] - (double)w2;  // s = R_jj - b^T M_pa^-1 b = R_jj - |L^-1 b|^2
-    wave_lds_fence();
-    const double Nn = bp.Nj[j], al = bp.alpha_lambd;
-    double lj = 0.0, gprime = 0.0, ls = 0.0, c2 = 0.0;
-    if (Nn > 0.0) {  // linearGaussian.py:118: a node without observations scores 0
-      const double a1 = 0.5 * (Nn + al - d + l + 1.0), a2 = 0.5 * (al - d + l + 1.0);
-      c2 = a1;
-      const double gam = 0.5 * (log(bp.alpha_mu) - log(Nn + bp.alpha_mu)) + lgamma(a1) - lgamma(a2) - 0.5 * Nn * log(M_PI) +
-                         0.5 * (al - d + 2.0 * l + 1.0) * bp.log_t;
-      gprime = 0.5 * digamma_d(a1) - 0.5 * digamma_d(a2) + bp.log_t;
-      ls = log(sch);
-      lj = gam - 0.5 * ld_pa - c2 * ls;
-    }
-    lp_wave += lj;
-    if (act) {
-      float t_r = 0.f;
-#pragma unroll 8
-      for (int bb = 0; bb < d; ++bb) t_r = fmaf(Rrow[bb] - (bb == lane ? 1.f : 0.f), pv[bb] * yv[bb], t_r);
-      t_r -= R[j * d + lane];
-      // 1 - (M_pa^-1)_rr = (L_rr^2 - 1) / L_rr^2 - |off-diagonal part of column r of L^-1|^2, each term O(p_r^2)
-      const float h_r = p > 0.f ? (dm1 / (1.0f + dm1) - offd) / p : 0.f;
-      const double dl = Nn > 0.0 ? gprime - 0.5 * ls - (double)h_r - (2.0 * c2 / sch) * (double)y * (double)t_r : 0.0;
-      out[lane * d + j] = isj ? 0.f : (float)dl * tau * alpha * g * (1.0f - g);
-    }
-    wave_lds_fence();
-  }
-  if (lane == 0) red[wave] = lp_wave;
-  __syncthreads();
-  if (tid == 0) logprobs[(size_t)m * S + s] = (float)(red[0] + red[1] + red[2] + red[3]);
-}
-
 #ifdef DIBS_TU_BGE_SOFT
 #include "kernels_bge_soft_mf.h"
 // softmax over the samples and W = sum_s w_s dS_s (samples with w_s == 0 in float are skipped, in sample order)
@@ -441,7 +294,7 @@ void bge_soft_launch(const BgeSoftParams& sp, const float* scores, Key2 carry, i
     hipLaunchKernelGGL((k_bge_soft<RL_, RPL_>), dim3(S, Mloc), dim3(256), lds, stream, scores, sp, carry, m0, M, d, S, alpha, tau, layout, \
                        tiny, soft_ds, logprobs);                                                                                        \
   }
-  if (d <= 64 && !getenv("DIBS_SOFT_GENERIC") && !getenv("DIBS_SOFT_REG")) {
+  if (d <= 64) {
     // blocked factorisation on the matrix pipe (kernels_bge_soft_mf.h)
     const bool rr = sp.n_mats == 1;
     const size_t l2 = bsm_lds_bytes(d, rr);
@@ -451,42 +304,14 @@ void bge_soft_launch(const BgeSoftParams& sp, const float* scores, Key2 carry, i
     hipLaunchKernelGGL((k_bge_soft_mf<NB_, RL_, W_>), dim3(S, Mloc), dim3(256), l2, stream, scores, sp, carry, m0, M, d, S, alpha, tau, layout, \
                        tiny, soft_ds, logprobs);                                                                                        \
   }
-    const bool w3 = getenv("DIBS_SOFT_W2") == nullptr;  // three waves per SIMD (165 registers, no scratch): 4.6 ms against 5.4 at two
+    // (three waves per SIMD: 165 registers, no scratch -- 4.6 ms against 5.4 at two)
     switch ((d + 15) / 16) {
       case 1: if (rr) SOFTM(1, true, 3) else SOFTM(1, false, 3) break;
       case 2: if (rr) SOFTM(2, true, 3) else SOFTM(2, false, 3) break;
-      case 3: if (rr) { if (w3) SOFTM(3, true, 3) else SOFTM(3, true, 2) } else { if (w3) SOFTM(3, false, 3) else SOFTM(3, false, 2) } break;
-      default: if (rr) { if (w3) SOFTM(4, true, 3) else SOFTM(4, true, 2) } else { if (w3) SOFTM(4, false, 3) else SOFTM(4, false, 2) } break;
+      case 3: if (rr) SOFTM(3, true, 3) else SOFTM(3, false, 3) break;
+      default: if (rr) SOFTM(4, true, 3) else SOFTM(4, false, 3) break;
     }
 #undef SOFTM
-  } else if (d <= 64 && !getenv("DIBS_SOFT_GENERIC")) {
-    const bool rr = sp.n_mats == 1;
-#define SOFTR(DP_)                                                                                                                     \
-  {                                                                                                                                     \
-    const size_t l2 = bge_softr_lds_bytes<DP_>(d, rr);                                                                                  \
-    if (rr) {                                                                                                                           \
-      if (l2 > 48 * 1024) hipFuncSetAttribute((const void*)k_bge_soft_reg<DP_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2); \
-      hipLaunchKernelGGL((k_bge_soft_reg<DP_, true>), dim3(S, Mloc), dim3(256), l2, stream, scores, sp, carry, m0, M, d, S, alpha, tau, layout, \
-                         tiny, soft_ds, logprobs);                                                                                      \
-    } else {                                                                                                                            \
-      if (l2 > 48 * 1024) hipFuncSetAttribute((const void*)k_bge_soft_reg<DP_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2); \
-      hipLaunchKernelGGL((k_bge_soft_reg<DP_, false>), dim3(S, Mloc), dim3(256), l2, stream, scores, sp, carry, m0, M, d, S, alpha, tau, layout, \
-                         tiny, soft_ds, logprobs);                                                                                      \
-    }                                                                                                                                   \
-  }
-    switch ((d + 7) / 8) {
-      case 1: SOFTR(8) break;
-      case 2: SOFTR(16) break;
-      case 3: SOFTR(24) break;
-      case 4: SOFTR(32) break;
-      case 5: SOFTR(40) break;
-      case 6: SOFTR(48) break;
-      case 7: SOFTR(56) break;
-      default: SOFTR(64) break;
-    }
-#undef SOFTR
-  } else if (d <= 64) {
-    if (rl) SOFT_LAUNCH(true, 1) else SOFT_LAUNCH(false, 1)
   } else {
     if (rl) SOFT_LAUNCH(true, 2) else SOFT_LAUNCH(false, 2)
   }

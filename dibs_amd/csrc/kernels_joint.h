@@ -73,6 +73,7 @@ struct JointLaunch {
   int layout, tiny, est_z;
   double sf_baseline;
   float obs_noise, mean_edge, sig_edge;
+  int lin_f32 = 0, nn_f32 = 0;  // the engine's DibsTuning (tuning.h): keep the f32-MFMA log-probability kernels (A/B runs)
 };
 
 struct LinGeom {
@@ -397,178 +398,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NT <= 4 ? 3
   }
 }
 
-// Same pairing, 33 <= d <= 64, on the bf16 MFMA with three-way split operands (the arithmetic of k_acyc_bf, kernels_acyc_bf16.h: a float
-// is carried as h + m + l, a product as six v_mfma_f32_16x16x32_bf16 -- 96 MFMA cycles for a 16 x 16 x 64 block where the f32 MFMA needs
-// 512).  x's row fragments (left operand, split once per block) stay in registers; the per-sample operand g o theta is split as it is
+// Same pairing, 33 <= d <= 64, on the f16 matrix pipe with TWO block-scaled pieces per operand (the arithmetic of k_acyc_hf,
+// kernels_acyc_f16.h: x 2^e = h + m, a product three v_mfma_f32_16x16x32_f16 -- 48 MFMA cycles for a 16 x 16 x 64 block where the f32 MFMA
+// needs 512).  x's row fragments (left operand, split once per block) stay in registers; the per-sample operand g o theta is split as it is
 // built -- both samples of the pair in ONE packed split, low halves to the first image, high halves to the second -- and written with
-// 2-byte stores into the transposing-read image layout of k_acyc_bf ([piece][column tile][row k][16 columns], chunk swizzle
-// (c + (k >> 2)) % 4).  The MFMA is issued with swapped operands as there, so lane (g, r) holds pred[n = 16 ti + r][j = 16 tj + 4 g + i].
-// grid = (ceil(S / 2 / ppb), Mloc), block = 256, dynamic LDS = 2 * ABF_IMG_BYTES + 64
-template <int EPQ, bool FOUR, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 3, NW == 8 ? 4 : 3))) void k_lin_logprobs_bf(
-    const float* __restrict__ x, const int32_t* __restrict__ mask, const float* __restrict__ theta, const float* __restrict__ scores,
-    const uint32_t* __restrict__ thr, float* __restrict__ logprobs, Key2 carry, int mode, int m0, int M_global, int d, int N, int S, int ppb,
-    float alpha, float tau, int layout, int tiny, float obs_noise, float mu, float sig, int any_mask) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  unsigned char* const sb = reinterpret_cast<unsigned char*>(smem);
-  double* red = reinterpret_cast<double*>(sb + 2 * ABF_IMG_BYTES);
-  constexpr int NU = 8 / NW, NTHR = 64 * NW;
-  const int nrt = (N + 15) >> 4;
-  const int m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g4 = lane >> 4, r = lane & 15;
-  const int dd = d * d;
-  const float* __restrict__ TH = theta + (size_t)m * dd;
-  const uint32_t* __restrict__ thr_m = thr + (size_t)m * dd;
-  const float* __restrict__ sc_m = scores + (size_t)m * dd;
-  // row n = (wave + 4 u) * 16 + r of x: the same 16 values (columns 16 tj + 4 g + i) are the lane's left-operand fragment and the x of its
-  // output elements
-  AbfFrag XA[NU];
-  float xe[NU][ABF_NT][4];
-  uint32_t ok[NU];
-  float nvalid = 0.f;
-#pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    const int n = (wave + NW * u) * 16 + r;
-    f32x4 v[ABF_NT];
-    ok[u] = 0u;
-#pragma unroll
-    for (int tj = 0; tj < ABF_NT; ++tj)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = 16 * tj + 4 * g4 + i;
-        const bool inb = n < N && j < d;
-        const float xv = inb ? x[(size_t)n * d + j] : 0.f;
-        const bool valid = inb && !(any_mask && mask[(size_t)n * d + j]);
-        v[tj][i] = xv;
-        xe[u][tj][i] = valid ? xv : 0.f;
-        ok[u] |= (uint32_t)valid << (tj * 4 + i);
-        nvalid += valid ? 1.0f : 0.0f;
-      }
-    abf_make_frag(v, XA[u]);
-  }
-  const TfKeys tk = tf_keys(lin_mode_key(mode, carry, M_global, m0 + m, layout));
-  const uint32_t half = (uint32_t)(((uint64_t)S * dd) >> 1);
-  const int hS = S >> 1;
-  const float inv2 = 0.5f / obs_noise;
-  const float lognorm_x = -0.5f * logf(obs_noise) - 0.918938533204672742f;
-  const bool soft = mode == LIN_MODE_Z_REPARAM, fast = tau == 1.0f;
-  const float ulo = tiny ? 1.17549435e-38f : 1.1920929e-07f;
-  const int rd_off = (4 * g4 + (r >> 2)) * 32 + (((r & 3) + g4) & 3) * 8;
-  const float inv_d = 1.0f / (float)d;
-  for (int e = tid; e < 2 * ABF_IMG_BYTES / 16; e += NTHR) reinterpret_cast<float4*>(sb)[e] = make_float4(0.f, 0.f, 0.f, 0.f);  // padding, diagonal
-  // sample-independent factors of element e = (i, j): byte offset of W[i][j] inside a piece, theta, logN(theta), aux (as k_lin_logprobs_pair)
-  auto factors = [&](int e, int& off, float& th, float& ln, float& aux) {
-    const int i = (int)(((float)e + 0.5f) * inv_d), j = e - i * d;  // exact for e < 2^20
-    off = (i == j) ? -1 : (j >> 4) * ABF_TILE_BYTES + i * 32 + ((((j & 15) >> 2) + (i >> 2)) & 3) * 8 + (j & 3) * 2;
-    th = TH[e];
-    ln = lin_logn(th, mu, sig);
-    if (soft) {
-      const float as = alpha * sc_m[e];
-      aux = fast ? expf(-as) : as;
-    } else {
-      aux = __uint_as_float(thr_m[e]);
-    }
-  };
-  int offs[EPQ > 0 ? EPQ : 1];
-  float ths[EPQ > 0 ? EPQ : 1], lns[EPQ > 0 ? EPQ : 1], auxs[EPQ > 0 ? EPQ : 1];
-  if constexpr (EPQ > 0) {
-#pragma unroll
-    for (int q = 0; q < EPQ; ++q) {
-      const int e = tid + NTHR * q;
-      offs[q] = -1;
-      ths[q] = lns[q] = auxs[q] = 0.f;
-      if (e < dd) factors(e, offs[q], ths[q], lns[q], auxs[q]);
-    }
-  }
-  float part[2];
-  auto element = [&](int e, uint32_t cbase, int off, float th, float ln, float aux) {
-    if (off < 0) return;
-    uint32_t y0, y1;
-    threefry2x32_uk(tk, cbase + (uint32_t)e, cbase + (uint32_t)e + half, y0, y1);
-    float g0, g1;
-    if (soft) {
-      if (fast) {
-        const float u0 = rng_uniform(y0, ulo, 1.0f), u1 = rng_uniform(y1, ulo, 1.0f);
-        g0 = u0 * __builtin_amdgcn_rcpf(fmaf(1.0f - u0, aux, u0));  // (v_rcp_f32: 1 ulp; an IEEE division is ten instructions)
-        g1 = u1 * __builtin_amdgcn_rcpf(fmaf(1.0f - u1, aux, u1));
-      } else {
-        g0 = 1.0f / (1.0f + expf(-tau * (rng_logistic(y0, tiny) + aux)));
-        g1 = 1.0f / (1.0f + expf(-tau * (rng_logistic(y1, tiny) + aux)));
-      }
-    } else {
-      const uint32_t ta = __float_as_uint(aux);
-      g0 = (y0 >> 9) < ta ? 1.0f : 0.0f;
-      g1 = (y1 >> 9) < ta ? 1.0f : 0.0f;
-    }
-    uint32_t ph, pm, pl;
-    abf_split(g0 * th, g1 * th, ph, pm, pl);
-    unsigned char* const w0 = sb + off;
-    *reinterpret_cast<uint16_t*>(w0) = (uint16_t)ph;
-    *reinterpret_cast<uint16_t*>(w0 + ABF_PIECE_BYTES) = (uint16_t)pm;
-    *reinterpret_cast<uint16_t*>(w0 + 2 * ABF_PIECE_BYTES) = (uint16_t)pl;
-    *reinterpret_cast<uint16_t*>(w0 + ABF_IMG_BYTES) = (uint16_t)(ph >> 16);
-    *reinterpret_cast<uint16_t*>(w0 + ABF_IMG_BYTES + ABF_PIECE_BYTES) = (uint16_t)(pm >> 16);
-    *reinterpret_cast<uint16_t*>(w0 + ABF_IMG_BYTES + 2 * ABF_PIECE_BYTES) = (uint16_t)(pl >> 16);
-    part[0] = fmaf(g0, ln, part[0]);
-    part[1] = fmaf(g1, ln, part[1]);
-  };
-  for (int c = 0; c < ppb; ++c) {
-    const int s0 = blockIdx.x * ppb + c;
-    if (s0 >= hS) break;
-    __syncthreads();
-    part[0] = part[1] = nvalid * lognorm_x;
-    const uint32_t cbase = (uint32_t)((uint64_t)s0 * (uint64_t)dd);
-    if constexpr (EPQ > 0) {
-#pragma unroll
-      for (int q = 0; q < EPQ; ++q) element(tid + NTHR * q, cbase, offs[q], ths[q], lns[q], auxs[q]);
-    } else {
-      for (int e = tid; e < dd; e += NTHR) {
-        int off;
-        float th, ln, aux;
-        factors(e, off, th, ln, aux);
-        element(e, cbase, off, th, ln, aux);
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int hsel = 0; hsel < 2; ++hsel) {
-      const unsigned char* img = sb + hsel * ABF_IMG_BYTES;
-      float sq = 0.f;
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        if (wave + NW * u >= nrt) continue;
-        f32x4 acc[ABF_NT];
-        abf_matmul<FOUR>(acc, XA[u], img, rd_off);
-#pragma unroll
-        for (int tj = 0; tj < ABF_NT; ++tj)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float pv = acc[tj][i];
-            asm volatile("" : "+v"(pv));
-            const float er = ((ok[u] >> (tj * 4 + i)) & 1u) ? xe[u][tj][i] - pv : 0.f;
-            sq = fmaf(er, er, sq);
-          }
-      }
-      part[hsel] = fmaf(-inv2, sq, part[hsel]);
-    }
-    const double t0 = wave_sum_d((double)part[0]), t1 = wave_sum_d((double)part[1]);
-    if (lane == 0) {
-      red[wave] = t0;
-      red[NW + wave] = t1;
-    }
-    __syncthreads();
-    if (tid < 2) {
-      double tot = 0.0;
-      for (int w8 = 0; w8 < NW; ++w8) tot += red[tid * NW + w8];
-      logprobs[(size_t)m * S + s0 + tid * hS] = (float)tot;
-    }
-  }
-}
-
-// The same kernel on the f16 matrix pipe with TWO block-scaled pieces per operand (the arithmetic of k_acyc_hf, kernels_acyc_f16.h:
-// x 2^e = h + m, a product three v_mfma_f32_16x16x32_f16): half the matrix instructions of k_lin_logprobs_bf, four instead of nine vector
-// instructions per split, four instead of six 2-byte stores per element.  Scales: x by the exponent of max |x| (block reduction, once),
+// 2-byte stores into the transposing-read image layout ([piece][column tile][row k][16 columns], chunk swizzle (c + (k >> 2)) % 4).  The
+// MFMA is issued with swapped operands, so lane (g, r) holds pred[n = 16 ti + r][j = 16 tj + 4 g + i].  Scales: x by the exponent of max |x| (block reduction, once),
 // theta by the exponent of max |theta_m| (block reduction, once; |g| <= 1) -- the pieces stay below 2^14, the product is unscaled once
-// per output element.  Replaces k_lin_logprobs_bf at 33 <= d <= 64 (DIBS_LIN_BF16=1 keeps that one for A/B runs).
+// per output element.  (Round 3's three-piece bf16 variant of this kernel was retired in round 6: profiles/HISTORY.md.)
 // grid = (ceil(S / 2 / ppb), Mloc), block = 64 NW, dynamic LDS = 2 * AHF_IMG_BYTES + 256
 template <int EPQ, bool FOUR, int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 3, NW == 8 ? 4 : 3))) void k_lin_logprobs_hf(
@@ -931,7 +768,7 @@ int joint_alloc(JointWork* w, int Mloc, int d, int N, int S);
 void joint_free(JointWork* w);
 int joint_set_data(JointWork* w, const float* x, const int32_t* mask, int N, int d);
 // true: x fits the LDS-resident MFMA kernels; false: the Gram-matrix path of kernels_lin_gram.h runs (joint_lin_set_gram builds C)
-bool joint_lin_fast_path(int d, int N);
+bool joint_lin_fast_path(int d, int N, bool force_gram);
 int joint_lin_set_gram(JointWork* w, const float* x, const int32_t* mask, int N, int d);
 void joint_lin_all_logprobs(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z);
 void joint_lin_all_grads(JointWork* w, const JointLaunch& jl, Key2 carry_theta, Key2 carry_z);
@@ -944,9 +781,9 @@ void joint_lin_score_given(const JointWork& jw, const float* theta, const int32_
 #include <vector>
 #include "kernels_lin_gram.h"
 
-bool joint_lin_fast_path(int d, int N) {
-  // (the MFMA kernels are instantiated for up to 7 tiles of 16 variables)
-  return !getenv("DIBS_LIN_GRAM") && d <= 112 && lin_lds_bytes(d, N, (d + 15) / 16, true) <= (size_t)160 * 1024;
+bool joint_lin_fast_path(int d, int N, bool force_gram) {
+  // (the MFMA kernels are instantiated for up to 7 tiles of 16 variables; force_gram: DibsTuning::lin_gram)
+  return !force_gram && d <= 112 && lin_lds_bytes(d, N, (d + 15) / 16, true) <= (size_t)160 * 1024;
 }
 
 int joint_lin_set_gram(JointWork* w, const float* x, const int32_t* mask, int N, int d) {
@@ -1077,8 +914,7 @@ static void joint_lin_logprobs(JointWork* w, const JointLaunch& jl, Key2 carry, 
   float* lp = mode == LIN_MODE_THETA ? jl.logprobs_th : jl.logprobs_z;
   const bool paired = jl.layout == 0 && (jl.S & 1) == 0 && (uint64_t)jl.S * jl.d * jl.d < 0xFFFFFFFFull && jl.N <= 128;
   if (paired) {
-    static const bool lin_f32 = getenv("DIBS_LIN_F32") != nullptr;  // (A/B switch for measurements: the f32-MFMA kernel at 33 <= d <= 64)
-    const bool use_bf = NT <= 4 && jl.d > 32 && !lin_f32;
+    const bool use_bf = NT <= 4 && jl.d > 32 && !jl.lin_f32;  // (lin_f32: tuning.h, the f32-MFMA kernel at 33 <= d <= 64 for A/B runs)
     // pairs per block: the block's prologue (x fragments, operand factors, zeroed images) is ~a third of a pair's work; 8 pairs when that
     // still leaves two full rounds of blocks (config 3: 1 914 -> 1 964 steps/s; 16 pairs: 1 856)
     const int ppb = (use_bf && (jl.S / 2 / 8) * jl.Mloc >= 1024) ? 8 : 4;
@@ -1086,8 +922,7 @@ static void joint_lin_logprobs(JointWork* w, const JointLaunch& jl, Key2 carry, 
     const dim3 grid((jl.S / 2 + ppb - 1) / ppb, jl.Mloc);
     const int epq = (jl.d * jl.d + 255) / 256;
     if (use_bf) {
-      static const bool lin_bf16 = getenv("DIBS_LIN_BF16") != nullptr;  // (A/B: the three-piece bf16 kernel instead of the two-piece f16 one)
-      const int ldsb = lin_bf16 ? 2 * ABF_IMG_BYTES + 128 : 2 * AHF_IMG_BYTES + 256;
+      const int ldsb = 2 * AHF_IMG_BYTES + 256;
       const int epq8 = (jl.d * jl.d + 511) / 512;
 #define LIN_HF_LAUNCH(EPQ_, FOUR_, NW_)                                                                                                      \
       {                                                                                                                                      \
@@ -1096,24 +931,10 @@ static void joint_lin_logprobs(JointWork* w, const JointLaunch& jl, Key2 carry, 
                            jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, ppb, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise,  \
                            jl.mean_edge, jl.sig_edge, w->any_mask);                                                                          \
       }
-      if (!lin_bf16) {
-        if (jl.d <= 48) LIN_HF_LAUNCH(5, false, 8)
-        else if (epq8 <= 5) LIN_HF_LAUNCH(5, true, 8)
-        else LIN_HF_LAUNCH(8, true, 8)
-        return;
-      }
+      if (jl.d <= 48) LIN_HF_LAUNCH(5, false, 8)
+      else if (epq8 <= 5) LIN_HF_LAUNCH(5, true, 8)
+      else LIN_HF_LAUNCH(8, true, 8)
 #undef LIN_HF_LAUNCH
-#define LIN_BF_LAUNCH(EPQ_, FOUR_, NW_)                                                                                                      \
-      {                                                                                                                                      \
-        hipFuncSetAttribute((const void*)k_lin_logprobs_bf<EPQ_, FOUR_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);             \
-        hipLaunchKernelGGL((k_lin_logprobs_bf<EPQ_, FOUR_, NW_>), grid, dim3(64 * NW_), ldsb, jl.stream, w->x, w->mask, jl.theta, jl.scores, \
-                           jl.thr, lp, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S, ppb, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise,  \
-                           jl.mean_edge, jl.sig_edge, w->any_mask);                                                                          \
-      }
-      if (jl.d <= 48) LIN_BF_LAUNCH(5, false, 8)
-      else if (epq8 <= 5) LIN_BF_LAUNCH(5, true, 8)
-      else LIN_BF_LAUNCH(8, true, 8)
-#undef LIN_BF_LAUNCH
       return;
     }
 #define LIN_PAIR_LAUNCH(EPQ_)                                                                                                      \

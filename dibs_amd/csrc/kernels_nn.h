@@ -640,25 +640,23 @@ static bool joint_nn_logprobs_hf(JointWork* w, const JointLaunch& jl, Key2 carry
   if constexpr (NT < 3) {
     return false;
   } else {
-    static const bool off = getenv("DIBS_NN_F32") != nullptr;
+    const bool off = jl.nn_f32 != 0;  // (tuning.h)
     const bool paired = jl.layout == 0 && (jl.S & 1) == 0 && (uint64_t)jl.S * jl.d * jl.d < 0xFFFFFFFFull;
     const bool soft = mode == LIN_MODE_Z_REPARAM;
     const size_t lds = nhf_lds_bytes(jl.d, NT, np_.H, soft);
     if (mode == LIN_MODE_THETA) w->nhf_valid = w->nhx_valid = false;  // (theta moved since the last step)
     if (off || !paired || jl.N > 128 || !w->ln_tab) return false;
-    static const int ppb_env = getenv("DIBS_NN_PPB") ? atoi(getenv("DIBS_NN_PPB")) : 0;
-    const int hS = jl.S / 2, ppb = ppb_env > 0 ? ppb_env : ((hS / 4) * jl.Mloc >= 1024 ? 4 : (hS >= 2 ? 2 : 1));
+    const int hS = jl.S / 2, ppb = (hS / 4) * jl.Mloc >= 1024 ? 4 : (hS >= 2 ? 2 : 1);
     if (!w->nhf_ew && hipMalloc((void**)&w->nhf_ew, (size_t)jl.Mloc * 4) != hipSuccess) {
       (void)hipGetLastError();
       w->nhf_ew = nullptr;
       return false;
     }
-    // d >= 65: the per-sample operand in REGISTERS against an x^T image (k_nn_logprobs_hx: no block barrier per hidden unit); below, and
-    // with DIBS_NN_HF_IMG=1, the image variant (k_nn_logprobs_hf: smaller blocks, several per CU)
-    static const bool img_env = getenv("DIBS_NN_HF_IMG") != nullptr;
+    // d >= 65: the per-sample operand in REGISTERS against an x^T image (k_nn_logprobs_hx: no block barrier per hidden unit); below
+    // the image variant (k_nn_logprobs_hf: smaller blocks, several per CU)
     if constexpr (NT >= 5) {
       const size_t ldsx = nhx_lds_bytes(jl.d, NT, jl.N, np_.H, soft);
-      if (!img_env && ldsx <= (size_t)160 * 1024 - 512) {
+      if (ldsx <= (size_t)160 * 1024 - 512) {
         const size_t quads = (size_t)jl.Mloc * np_.H * ((jl.d + 3) / 4) * jl.d;
         if (w->nhx_quads < quads) {
           if (w->nhx_w1s) hipFree(w->nhx_w1s);
@@ -741,8 +739,7 @@ template <int NT>
 static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int mode, const NNParams& np_, size_t P) {
   // samples per block: the block's prologue (x and the small leaves into LDS, validity bits) is shared by them; 4 while that leaves at least
   // four rounds of blocks (config 5: spb 2 / 4 / 8 -> 51.2 / 53.0 / 53.1 steps/s)
-  static const int spb_env = getenv("DIBS_NN_SPB") ? atoi(getenv("DIBS_NN_SPB")) : 0;
-  const int spb = spb_env > 0 ? spb_env : ((jl.S / 4) * jl.Mloc >= 1024 ? 4 : 2);
+  const int spb = (jl.S / 4) * jl.Mloc >= 1024 ? 4 : 2;
   const size_t lds1 = nn_lds_bytes_logprobs(jl.d, jl.N, NT, np_.H), lds2 = nn_lds_bytes(jl.d, jl.N, NT, true);
   if (lds2 > 48 * 1024) {
     hipFuncSetAttribute((const void*)k_nn_grad<NT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);

@@ -4,6 +4,7 @@
 #include "common.h"
 #include "kernels_kmat.h"
 #include "kernels_bge.h"
+#include "tuning.h"
 
 // kernels that may need more than the default 64 KiB of dynamic LDS: raises hipFuncAttributeMaxDynamicSharedMemorySize once per
 // (device, kernel) and size increase (engine.hip; thread-safe -- engines on several devices / host threads share the table)
@@ -31,6 +32,7 @@ struct AcycLaunch {
   int layout, tiny;
   hipEvent_t ev_start, ev_stop;  // profiling: kernel-level start / stop time stamps of the matrix-power kernel (see acyc_power_takes_events); else null
   const float* eas;       // [Mloc][d*d] exp(-alpha scores) (k_edge_scores), read by k_acyc_hf when tau == 1; may be null (then it is evaluated in place)
+  int pipe = DIBS_PIPE_DEFAULT, hfw_max = 112;  // the engine's DibsTuning::acyc_pipe / acyc_hfw_max
 };
 // true: acyc_launch_power is ONE kernel and stamps a.ev_start / a.ev_stop around it (hipExtLaunchKernelGGL: the kernel's own start and
 // end as the profiler sees them, without the dispatch latency an event pair recorded around the launch includes)

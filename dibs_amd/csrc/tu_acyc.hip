@@ -25,19 +25,13 @@ static void launch_nt(const AcycLaunch& a) {
   }
 }
 
-// 33 <= d <= 64 with paired chains: split-bf16 MFMA kernel (kernels_acyc_bf16.h); DIBS_ACYC_F32=1 keeps the f32-MFMA kernel (A/B runs)
+// 33 <= d <= 64 with paired chains: the split-operand kernels on the 16-bit matrix pipe (kernels_acyc_f16.h, kernels_acyc_bf16.h);
+// a.pipe == DIBS_PIPE_F32 keeps the f32-MFMA kernel (tuning.h: A/B runs)
 // (d <= 32 stays on k_acyc<NT>: measured at config 2 (d = 20, 32 particles) the 64-padded k_acyc_hf takes 17.4 us against 14.3 us for
-//  k_acyc<2> -- its element-order draws do not make up for products that are 3 x 3 instead of 2 x 2 tiles; DIBS_ACYC_SMALL_HF=1 selects it)
-static bool acyc_use_bf16(const AcycLaunch& a) {
-  static const bool small_hf = getenv("DIBS_ACYC_SMALL_HF") != nullptr;
-  const bool off = getenv("DIBS_ACYC_F32") != nullptr;  // (read per launch: the tests compare the two pipes in one process)
-  return !off && a.units != a.Sa && a.d >= (small_hf ? 4 : 33) && a.d <= 64;
-}
-// 65 <= d <= 112 with paired chains: the same scheme with NT = 5 .. 7 tiles and waves (k_acyc_bfw)
-static bool acyc_use_bfw(const AcycLaunch& a) {
-  const bool off = getenv("DIBS_ACYC_F32") != nullptr;
-  return !off && a.units != a.Sa && a.d > 64 && a.d <= 112;
-}
+//  k_acyc<2> -- its element-order draws do not make up for products that are 3 x 3 instead of 2 x 2 tiles)
+static bool acyc_use_bf16(const AcycLaunch& a) { return a.pipe != DIBS_PIPE_F32 && a.units != a.Sa && a.d >= 33 && a.d <= 64; }
+// 65 <= d <= 112 with paired chains: the same schemes with NT = 5 .. 7 tiles and waves (k_acyc_hfw / k_acyc_bfw)
+static bool acyc_use_bfw(const AcycLaunch& a) { return a.pipe != DIBS_PIPE_F32 && a.units != a.Sa && a.d > 64 && a.d <= 112; }
 // two-piece f16 operands for 65 <= d <= 112 (k_acyc_hfw, kernels_acyc_f16.h); DIBS_ACYC_BF16=1 keeps k_acyc_bfw (A/B runs)
 template <int NT>
 static void launch_hfw(const AcycLaunch& a) {
@@ -100,9 +94,8 @@ void acyc_launch_power(const AcycLaunch& a) {
     return;
   }
   if (acyc_use_bf16(a)) {
-    // two-piece f16 operands (kernels_acyc_f16.h: half the matrix instructions); DIBS_ACYC_BF16=1 keeps the three-piece bf16 kernel (A/B runs)
-    static const bool bf16_env = getenv("DIBS_ACYC_BF16") != nullptr;
-    const bool bf16 = bf16_env && a.d > 32;
+    // two-piece f16 operands (kernels_acyc_f16.h: half the matrix instructions); DIBS_PIPE_BF16: the three-piece bf16 kernel (A/B runs)
+    const bool bf16 = a.pipe == DIBS_PIPE_BF16;
     const size_t lds = bf16 ? (size_t)2 * ABF_IMG_BYTES : (size_t)AHF_LDS_BYTES;
     const dim3 grid(a.nblk, (a.Mloc + 7) & ~7);
 #define ACYC_BF_LAUNCH(KERNEL_)                                                                                                            \
@@ -121,15 +114,8 @@ void acyc_launch_power(const AcycLaunch& a) {
     } else {
 #undef ACYC_SRC
 #define ACYC_SRC a.scores, a.eas
-      // three waves per SIMD (no spills, M's fragments kept); DIBS_ACYC_WPE=2 / 4: two / four (A/B runs)
-      static const int wpe = getenv("DIBS_ACYC_WPE") ? atoi(getenv("DIBS_ACYC_WPE")) : (getenv("DIBS_ACYC_WPE4") ? 4 : 3);
-      if (wpe == 3) {
-        if (a.d > 48) ACYC_BF_LAUNCH((k_acyc_hf<true, 3>)) else ACYC_BF_LAUNCH((k_acyc_hf<false, 3>))
-      } else if (wpe == 2) {
-        if (a.d > 48) ACYC_BF_LAUNCH((k_acyc_hf<true, 2>)) else ACYC_BF_LAUNCH((k_acyc_hf<false, 2>))
-      } else {
-        if (a.d > 48) ACYC_BF_LAUNCH((k_acyc_hf<true, 4>)) else ACYC_BF_LAUNCH((k_acyc_hf<false, 4>))
-      }
+      // three waves per SIMD (no spills, M's fragments kept)
+      if (a.d > 48) ACYC_BF_LAUNCH((k_acyc_hf<true, 3>)) else ACYC_BF_LAUNCH((k_acyc_hf<false, 3>))
     }
 #undef ACYC_BF_LAUNCH
 #undef ACYC_SRC
@@ -141,10 +127,8 @@ void acyc_launch_power(const AcycLaunch& a) {
     // product level, i.e. -(d - 1) 1.15e-7 = -1.0e-5 at d = 80, which the kernel compensates to first order (residual 4e-6).  With the
     // compensation the whole range 65 .. 112 runs on it (round 4 fenced it to d <= 80): against the f64 oracle it is as close as the
     // f32-MFMA kernel at d = 96 / 100 / 112 (5.9e-6 / 7.0e-5 at alpha = 1000 / 5.9e-6 vs 5.9e-6 / 7.3e-5 / 8.8e-6); config 5 (d = 100)
-    // 116.6 -> 123.2 steps/s.  DIBS_ACYC_HFW_MAX=80 restores the fence, DIBS_ACYC_BF16=1 the three-piece bf16 kernel.
-    static const bool bf16w = getenv("DIBS_ACYC_BF16") != nullptr;
-    const char* hm = getenv("DIBS_ACYC_HFW_MAX");  // (tuning / test override, read per launch)
-    if (!bf16w && a.d <= (hm ? atoi(hm) : 112)) {
+    // 116.6 -> 123.2 steps/s.  a.hfw_max = 80 restores the fence, DIBS_PIPE_BF16 selects the three-piece bf16 kernel (tuning.h).
+    if (a.pipe != DIBS_PIPE_BF16 && a.d <= a.hfw_max) {
       switch ((a.d + 15) / 16) {
         case 5: launch_hfw<5>(a); break;
         case 6: launch_hfw<6>(a); break;

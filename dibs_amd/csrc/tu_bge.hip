@@ -40,8 +40,7 @@ void bge_launch_chol(hipStream_t stream, double* node_scores, const BgeParams& b
   bool rl = bp.n_mats == 1;
   if (rl && bge_chol_lds_bytes(d, true) > (size_t)150 * 1024) rl = false;
   const size_t lds = bge_chol_lds_bytes(d, rl);
-  static const int grid_env = getenv("DIBS_CHOL_GRID") ? atoi(getenv("DIBS_CHOL_GRID")) : 0;  // (tuning override)
-  const dim3 grid(grid_env > 0 ? grid_env : 512), block(256);  // (512 = the resident blocks at two waves per SIMD: R / Q are staged once per slot; 1024: +2 us)
+  const dim3 grid(512), block(256);  // (512 = the resident blocks at two waves per SIMD: R / Q are staged once per slot; 1024: +2 us)
 #define CHOL(RL_, W2_)                                                                                                  \
   {                                                                                                                     \
     allow_lds(k_bge_chol<RL_, W2_>, lds);                                                                               \

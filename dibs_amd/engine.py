@@ -165,6 +165,13 @@ class Engine:
         _lib.check(self.lib.dibs_engine_eval_gradients(self._h, int(t), _ptr(kt), _ptr(kl), _ptr(kp), _ptr(gz), _ptr(bl), _ptr(gt), _ptr(gp)))
         return dict(grad_z_lik=gz, baseline=bl, grad_theta=gt, grad_z_prior=gp)
 
+    def flag_fallbacks(self):
+        """chunks this engine had to repeat on events after an in-kernel flag wait timed out (include/dibs_hip.h)"""
+        return int(self.lib.dibs_engine_flag_fallbacks(self._h))
+
+    def debug_drop_next_flag(self):
+        _lib.check(self.lib.dibs_engine_debug_drop_next_flag(self._h))
+
     def sync(self):
         _lib.check(self.lib.dibs_engine_sync(self._h))
 

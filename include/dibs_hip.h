@@ -142,6 +142,16 @@ int dibs_engine_get_state(dibs_engine* e, float* z, float* v_z, float* theta, fl
  * t_start+n_steps-1 entirely on the device, blocking until done.  Single-rank engines only. */
 int dibs_engine_run(dibs_engine* e, int32_t t_start, int32_t n_steps);
 
+/* Inside a chunk the engine synchronises its two streams through flag words polled by kernels (cheaper than events by ~10 us per step).  The
+ * waits are bounded; should one run into its bound (a device masked down to a few CUs, another process filling the GPU, a serialising tool),
+ * dibs_engine_run / dibs_engine_run_sharded restore the loop carry they copied at the start of the chunk, switch this engine to events for
+ * good and run the same steps again -- callers see only the delay.  (In a sharded run the ranks agree on this with one tiny all-gather per
+ * chunk and repeat together.)  Returns how many chunks were repeated so far (-1: null handle). */
+int dibs_engine_flag_fallbacks(const dibs_engine* e);
+/* fault injection for the tests of that path: the next step that would publish the second stream's completion flag does not, so the polling
+ * kernel runs into its bound (0.2 s) exactly once.  No effect on an engine that is not using the flags. */
+int dibs_engine_debug_drop_next_flag(dibs_engine* e);
+
 /* multi-rank split of one _svgd_step (svgd.py:226-267): phase A = per-particle estimators for the local
  * shard + packing of [z | grad_z (| theta | grad_theta)] into the send buffer; the caller all-gathers
  * (RCCL, torch.distributed) send -> recv; phase B = kernel matrix slab, phi and optimizer step for the

@@ -62,6 +62,8 @@ def main():
     out = {}
     for i, (t0, n) in enumerate(case["chunks"]):
         ov = case["overlapped"] if not isinstance(case["overlapped"], list) else case["overlapped"][i]
+        if case.get("drop_flag") == [rank, i]:   # fault injection: this rank loses a completion flag in this chunk
+            eng.debug_drop_next_flag()
         eng.run_sharded(t0, n, bool(ov))
         z, th = eng.gather_particles()
         out[f"z_{i}"] = z
@@ -69,6 +71,7 @@ def main():
             out[f"theta_{i}"] = th
     st = eng.get_state()
     out["own_z"], out["key"] = st["z"], st["key"]
+    out["flag_fallbacks"] = np.int64(eng.flag_fallbacks())
     np.savez(os.path.join(rdv, f"out_{rank}.npz"), **out)
     # nobody unmaps while a peer may still be inside its last exchange: leave together
     open(os.path.join(rdv, f"done_{rank}"), "w").close()
