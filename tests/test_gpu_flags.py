@@ -23,6 +23,13 @@ pytestmark = pytest.mark.gpu
 CASE = dict(d=50, M=128, S=64, Sa=16, chunks=[[0, 3], [3, 3], [6, 2]], seed=5, data_seed=1)
 
 
+@pytest.fixture(autouse=True)
+def _flags_even_with_other_engines_alive(monkeypatch):
+    # (an engine uses the flags only while it is alone in its process; earlier tests of a session may have left engines behind -- the
+    #  facade keeps its scoring engines.  DIBS_FLAGS_MULTI is latched at creation: tuning.h)
+    monkeypatch.setenv("DIBS_FLAGS_MULTI", "1")
+
+
 def _run_here(case, drop_in_chunk=None):
     from dibs_amd.engine import Engine
     from ipc_rank_worker import case_config, case_data
