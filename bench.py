@@ -182,6 +182,9 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=8.0, help="repeat the timed window until the timed regions add up to this much")
     ap.add_argument("--n-particles", type=int, default=None, help="override the particle count of the config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--steady-t", type=int, default=300,
+                    help="also time the same K-step window from this step of the trajectory (sample() runs thousands of steps: the sampled parent "
+                         "sets shrink as the particles sharpen and a step gets cheaper); 0: skip.  Reported as `steady_state`, never as `value`")
     ap.add_argument("--dist-smoke", action="store_true",
                     help="with --gpus 1: run the sharded code path (process group of ONE rank, real RCCL calls, overlapped exchange) instead of "
                          "dibs_engine_run -- exercises on one GPU what --gpus N > 1 executes")
@@ -409,6 +412,23 @@ def main():
             out["config4"] = {"metric": "SVGD steps/sec (d=50, n_particles=1024, BGe)", "value": K / el4, "ms_per_step": 1e3 * el4 / K,
                               "n_gpus": N, "particles_per_rank": 1024 // N, "scaling": "weak vs the 1-GPU headline (128 particles per rank at 8 GPUs)"}
             eng = e4
+
+    if not sharded and args.steady_t > W + K:
+        # ---- the same K-step window late in the trajectory (untimed run-up from the snapshot at t = W, then the window repeated from a snapshot)
+        eng.set_state(**snap)
+        eng.run(W, args.steady_t - W)
+        snap_late = {k_: v for k_, v in eng.get_state().items() if v is not None}
+        late = []
+        while len(late) < 5 or (sum(late) < 1.0 and len(late) < 500):
+            eng.set_state(**snap_late)
+            fence()
+            t_begin = time.perf_counter()
+            eng.run(args.steady_t, K)
+            fence()
+            late.append(time.perf_counter() - t_begin)
+        el_late = float(np.median(late))
+        out["steady_state"] = {"value": K / el_late, "unit": "steps/s", "ms_per_step": 1e3 * el_late / K, "reps": len(late),
+                               "timed_steps": f"t={args.steady_t}..{args.steady_t + K - 1} of the same trajectory"}
 
     if rank == 0 and not sharded:
         # ---- roofline of the dominant kernel: the same K steps replayed with per-kernel HIP events on the engine's stream ----

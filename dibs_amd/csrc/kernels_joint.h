@@ -15,6 +15,15 @@
 
 enum { LIN_MODE_THETA = 0, LIN_MODE_Z_SCORE = 1, LIN_MODE_Z_REPARAM = 2, LIN_MODE_GIVEN = 3 };
 
+#define GRAD_NS 8   // (16 measured: config 3 at step 1 500 281 us against 271, at step 5 54 against 49)
+#define GRAD_NS_NN 16  // DenseNonlinearGaussian: a sample's gradient takes ~0.7 ms of a block -- finer shares balance the CUs better
+#define GRAD_WCH 256  // weights are evaluated in chunks of this many samples (one double-precision exp per thread and chunk)
+struct GradSplit {
+  float* part;         // [jobs][GRAD_NS][stride] partial sums
+  unsigned int* ctr;   // [jobs] arrivals (zero between launches: the last block resets it)
+  size_t stride;
+};
+
 struct JointWork {
   float* x;        // [N, d] device copy
   int32_t* mask;   // [N, d]
@@ -42,6 +51,11 @@ struct JointWork {
   // sampled graph (and the masked weights) of a block live here instead of in LDS; grown on first use
   float* gs_scratch;
   size_t gs_scratch_floats;
+  // gradient kernels with several blocks per (particle, estimator) (GradSplit below): partial sums and arrival counters, grown on first use
+  float* gpart;
+  size_t gpart_floats;
+  unsigned int* gctr;
+  size_t gctr_n;
 };
 static inline float* joint_gs_scratch(JointWork* w, size_t floats) {
   if (w->gs_scratch_floats < floats) {
@@ -52,6 +66,28 @@ static inline float* joint_gs_scratch(JointWork* w, size_t floats) {
     w->gs_scratch_floats = floats;
   }
   return w->gs_scratch;
+}
+// partial-sum area of the split gradient kernels: `jobs` (particle, estimator) pairs x GRAD_NS blocks x `stride` floats; counters zeroed once
+static inline bool joint_grad_split(JointWork* w, size_t jobs, size_t stride, GradSplit* out, int ns = GRAD_NS) {
+  const size_t need = jobs * (size_t)ns * stride;
+  if (w->gpart_floats < need) {
+    if (w->gpart) hipFree(w->gpart);
+    w->gpart = nullptr;
+    w->gpart_floats = 0;
+    if (hipMalloc((void**)&w->gpart, need * 4) != hipSuccess) return false;
+    w->gpart_floats = need;
+  }
+  if (w->gctr_n < jobs) {
+    if (w->gctr) hipFree(w->gctr);
+    w->gctr = nullptr;
+    w->gctr_n = 0;
+    if (hipMalloc((void**)&w->gctr, jobs * 4) != hipSuccess) return false;
+    if (hipMemset(w->gctr, 0, jobs * 4) != hipSuccess) return false;
+    if (hipDeviceSynchronize() != hipSuccess) return false;  // (the engine's streams do not wait for the null stream)
+    w->gctr_n = jobs;
+  }
+  *out = GradSplit{w->gpart, w->gctr, stride};
+  return true;
 }
 
 struct JointLaunch {
@@ -605,6 +641,81 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
 //   mode Z_SCORE   : W = scale * alpha (sum_s w_s G_s - P), off-diagonal                                 -> w_lik
 // grid = Mloc, block = 256
 // ------------------------------------------------------------------------------------------------
+// ---- the samples of one (particle, estimator) over several blocks ------------------------------------------------------------------
+// Early in a run the softmax over the S samples is one-hot in float32 (the log-probabilities differ by hundreds) and one gradient per
+// particle is evaluated; once the particles have sharpened, many samples keep a non-zero weight (config 3 at step 1 500: 13 on average,
+// 53 for the worst particle; config 5 at step 300: 15 / 123) and ONE block per particle walked them one after the other -- the worst
+// particle set the time of the launch (k_lin_grad 62 -> 1 070 us, k_nn_grad 3.2 -> 53 ms).  Now GRAD_NS blocks share a particle: the
+// samples with non-zero weight are dealt round-robin in sample order (ordinal q -> block q mod GRAD_NS), every block accumulates its
+// share, and the block that finishes LAST adds the partial sums in block order (a counter per (particle, estimator); partial sums stored
+// at agent scope, as the kernel-matrix tiles do) and runs the epilogue.  The grouping is a function of the weights only -- not of the shard
+// -- so the result does not depend on the rank count; with one non-zero weight block 0 does everything as before and nothing is exchanged.
+// softmax statistics of a particle's S log-probabilities in double (as the oracle: dibs.py:376-382 through logsumexp): maximum, sum of
+// exponentials, sum of the log-probabilities, and the number of samples whose weight is non-zero in float.  `red`: 16 doubles of LDS.
+__device__ __forceinline__ void grad_softmax_stats(const float* __restrict__ lp, int S, double* red, double& mx, double& den, double& sm, int& nnz) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  mx = -INFINITY;
+  for (int s = tid; s < S; s += 256) mx = (double)lp[s] > mx ? (double)lp[s] : mx;
+  mx = wave_max_d(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = red[0];
+  for (int w = 1; w < 4; ++w) mx = red[w] > mx ? red[w] : mx;
+  den = 0.0;
+  sm = 0.0;
+  for (int s = tid; s < S; s += 256) {
+    den += exp((double)lp[s] - mx);
+    sm += (double)lp[s];
+  }
+  den = wave_sum_d(den);
+  sm = wave_sum_d(sm);
+  __syncthreads();
+  if (lane == 0) {
+    red[wave] = den;
+    red[4 + wave] = sm;
+  }
+  __syncthreads();
+  den = red[0] + red[1] + red[2] + red[3];
+  sm = red[4] + red[5] + red[6] + red[7];
+  double cnt = 0.0;
+  for (int s = tid; s < S; s += 256) cnt += ((float)(exp((double)lp[s] - mx) / den) != 0.f) ? 1.0 : 0.0;
+  cnt = wave_sum_d(cnt);
+  if (lane == 0) red[8 + wave] = cnt;
+  __syncthreads();
+  nnz = (int)(red[8] + red[9] + red[10] + red[11]);
+}
+// the partial sums of this block are complete (stored with grad_part_store): count this block; true for the LAST of `nact` blocks, which
+// then reads all of them with grad_part_load.  `flag`: one int of LDS.
+__device__ __forceinline__ void grad_part_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float grad_part_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// element `idx` of the partial rows 0 .. nact-1 (row stride `stride`), added in row order; all loads are issued before the first addition
+// (a rolled loop over the rows has ONE load in flight per thread: 4 480 dependent trips past the L2 for a k_nn_grad row -- the last block
+// of a particle took milliseconds)
+template <int NSMAX, bool ATOMIC>
+__device__ __forceinline__ float grad_part_sum(const float* base, size_t stride, size_t idx, int nact) {
+  float v[NSMAX];
+#pragma unroll
+  for (int b = 0; b < NSMAX; ++b) {
+    const float* p = base + (size_t)(b < nact ? b : 0) * stride + idx;
+    v[b] = ATOMIC ? grad_part_load(p) : *p;
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int b = 0; b < NSMAX; ++b) t += b < nact ? v[b] : 0.f;
+  return t;
+}
+__device__ __forceinline__ bool grad_last_block(unsigned int* ctr, int nact, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every wave: its own partial stores are complete before the block counts itself)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int done = atomicAdd(ctr, 1u) + 1u;
+    if (done == (unsigned int)nact) atomicExch(ctr, 0u);
+    *flag = done == (unsigned int)nact;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+
 // one estimator's inputs / outputs; the theta and the Z estimator of a step run as blockIdx.y = 0 / 1 of ONE launch (each has
 // only Mloc blocks -- half the CUs -- and they are independent once both sets of log-probs exist)
 struct LinGradJob {
@@ -622,8 +733,8 @@ __global__ __launch_bounds__(256) void k_lin_grad(const float* __restrict__ x, c
                                                   const uint32_t* __restrict__ thr, LinGradJob job0, LinGradJob job1,
                                                   const float* __restrict__ baseline, int m0, int M_global, int d, int N, int S,
                                                   float alpha, float tau, int layout, int tiny, float obs_noise, float mu, float sig,
-                                                  double sf_baseline, int any_mask) {
-  const LinGradJob job = blockIdx.y ? job1 : job0;
+                                                  double sf_baseline, int any_mask, GradSplit gs) {
+  const LinGradJob job = blockIdx.y ? job1 : job0;  // (grid = (Mloc, 2 estimators, shares); particle = (x + z) mod Mloc: see k_nn_grad)
   const float* __restrict__ logprobs = job.logprobs;
   float* __restrict__ out = job.out;
   const size_t out_stride = job.out_stride;
@@ -637,37 +748,22 @@ __global__ __launch_bounds__(256) void k_lin_grad(const float* __restrict__ x, c
   float* WG = X + (size_t)g.np * g.ldx;
   float* RS = WG + (size_t)g.kp * g.ldw;  // residuals [np][ldw]
   double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)g.kp * g.ldw + (size_t)g.np * g.ldw) + 3) & ~(size_t)3));
-  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = (int)((blockIdx.x + blockIdx.z) % gridDim.x), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t dd = (size_t)d * d;
   const float* __restrict__ TH = theta + (size_t)m * dd;
-  lin_load_common<NT>(X, x, g, tid);
-  for (int e = tid; e < g.np * g.ldw; e += 256) RS[e] = 0.f;
   const Key2 key = lin_mode_key(mode, carry, M_global, m0 + m, layout);
   const uint64_t nbits = (uint64_t)S * dd;
   const float* lp = logprobs + (size_t)m * S;
-  // softmax statistics (double)
-  double mx = -INFINITY;
-  for (int s = tid; s < S; s += 256) mx = (double)lp[s] > mx ? (double)lp[s] : mx;
-  mx = wave_max_d(mx);
-  if (lane == 0) red[wave] = mx;
-  __syncthreads();
-  mx = red[0];
-  for (int w = 1; w < 4; ++w) mx = red[w] > mx ? red[w] : mx;
-  double den = 0.0, sm = 0.0;
-  for (int s = tid; s < S; s += 256) {
-    den += exp((double)lp[s] - mx);
-    sm += (double)lp[s];
-  }
-  den = wave_sum_d(den);
-  sm = wave_sum_d(sm);
-  __syncthreads();
-  if (lane == 0) {
-    red[wave] = den;
-    red[4 + wave] = sm;
-  }
-  __syncthreads();
-  den = red[0] + red[1] + red[2] + red[3];
-  sm = red[4] + red[5] + red[6] + red[7];
+  // softmax statistics (double), number of samples with a non-zero weight; this block's share of them: ordinals q = bz, bz + NS, ...
+  __shared__ float wch[GRAD_WCH];
+  __shared__ int last_flag;
+  double mx, den, sm;
+  int nnz;
+  grad_softmax_stats(lp, S, red, mx, den, sm, nnz);
+  const int NS = gridDim.z, bz = blockIdx.z, nact = nnz < NS ? (nnz > 0 ? nnz : 1) : NS;
+  if (bz >= nact) return;  // (block-uniform: no share -- before anything is staged)
+  lin_load_common<NT>(X, x, g, tid);
+  for (int e = tid; e < g.np * g.ldw; e += 256) RS[e] = 0.f;
 
   // accumulators in the MFMA C layout: element (i = ti*16 + (lane>>4)*4 + r, j = tj*16 + (lane&15)), ti = wave + 4*u
   constexpr int NU = (NT + 3) / 4;
@@ -680,9 +776,15 @@ __global__ __launch_bounds__(256) void k_lin_grad(const float* __restrict__ x, c
   const float* sc_m = scores + (size_t)m * dd;
   const uint32_t* thr_m = thr + (size_t)m * dd;
 
-  for (int s = 0; s < S; ++s) {
-    const float w = (float)(exp((double)lp[s] - mx) / den);
+  int q = 0;  // ordinal of the next sample with a non-zero weight
+  for (int s0 = 0; s0 < S; s0 += GRAD_WCH) {
+    __syncthreads();
+    if (s0 + tid < S) wch[tid] = (float)(exp((double)lp[s0 + tid] - mx) / den);
+    __syncthreads();
+  for (int s = s0; s < S && s < s0 + GRAD_WCH; ++s) {
+    const float w = wch[s - s0];
     if (w == 0.f) continue;  // block-uniform
+    if ((q++ % NS) != bz) continue;  // (another block's sample)
     if (mode == LIN_MODE_Z_SCORE) {
 #pragma unroll
       for (int u = 0; u < NU; ++u)
@@ -738,6 +840,25 @@ __global__ __launch_bounds__(256) void k_lin_grad(const float* __restrict__ x, c
         }
     }
   }
+  }
+  if (nact > 1) {
+    // partial sums in thread layout ([value][thread]: coalesced, no index arithmetic); the last block adds them in block order
+    float* const base = gs.part + ((size_t)(m * 2 + (int)blockIdx.y) * NS) * gs.stride;
+    float* const mine = base + (size_t)bz * gs.stride + tid;
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) grad_part_store(mine + (size_t)((u * NT + tj) * 4 + r) * 256, acc[u][tj][r]);
+    if (!grad_last_block(gs.ctr + (m * 2 + (int)blockIdx.y), nact, &last_flag)) return;
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[u][tj][r] = grad_part_sum<GRAD_NS, true>(base, gs.stride, (size_t)((u * NT + tj) * 4 + r) * 256 + tid, nact);
+  }
   // epilogue
   const float bold = baseline ? baseline[m] : 0.f;
   const float scale = (mode == LIN_MODE_Z_SCORE && sf_baseline > 0.0) ? (float)exp(-(double)bold) : 1.0f;
@@ -783,7 +904,8 @@ void joint_lin_score_given(const JointWork& jw, const float* theta, const int32_
 
 bool joint_lin_fast_path(int d, int N, bool force_gram) {
   // (the MFMA kernels are instantiated for up to 7 tiles of 16 variables; force_gram: DibsTuning::lin_gram)
-  return !force_gram && d <= 112 && lin_lds_bytes(d, N, (d + 15) / 16, true) <= (size_t)160 * 1024;
+  // (2 KiB below the capacity: the gradient kernel has a little static LDS of its own)
+  return !force_gram && d <= 112 && lin_lds_bytes(d, N, (d + 15) / 16, true) <= (size_t)160 * 1024 - 2048;
 }
 
 int joint_lin_set_gram(JointWork* w, const float* x, const int32_t* mask, int N, int d) {
@@ -841,6 +963,10 @@ int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) {
   w->nng_scratch_floats = 0;
   w->gs_scratch = nullptr;
   w->gs_scratch_floats = 0;
+  w->gpart = nullptr;
+  w->gpart_floats = 0;
+  w->gctr = nullptr;
+  w->gctr_n = 0;
   w->nhf_w1s = w->nhf_w1p = nullptr;
   w->nhf_ew = nullptr;
   w->nhf_pairs = 0;
@@ -866,6 +992,11 @@ void joint_free(JointWork* w) {
   if (w->gs_scratch) hipFree(w->gs_scratch);
   w->gs_scratch = nullptr;
   w->gs_scratch_floats = 0;
+  if (w->gpart) hipFree(w->gpart);
+  if (w->gctr) hipFree(w->gctr);
+  w->gpart = nullptr;
+  w->gctr = nullptr;
+  w->gpart_floats = w->gctr_n = 0;
   if (w->nhf_w1s) hipFree(w->nhf_w1s);
   if (w->nhf_w1p) hipFree(w->nhf_w1p);
   if (w->nhf_ew) hipFree(w->nhf_ew);
@@ -964,9 +1095,11 @@ static void joint_lin_grads(JointWork* w, const JointLaunch& jl, Key2 carry_thet
                       jl.copy_theta ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr, nullptr, carry_theta, LIN_MODE_THETA};
   const LinGradJob jz{jl.logprobs_z, jl.w_lik, (size_t)jl.d * jl.d, nullptr, jl.baseline_out, carry_z,
                       jl.est_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM};
-  hipLaunchKernelGGL(k_lin_grad<NT>, dim3(jl.Mloc, 2), dim3(256), lds2, jl.stream, w->x, w->mask, jl.theta, jl.scores, jl.thr, jt, jz,
+  GradSplit gs;
+  if (!joint_grad_split(w, (size_t)jl.Mloc * 2, (size_t)((NT + 3) / 4) * NT * 4 * 256, &gs)) return;  // (the step's launch check reports the failed hipMalloc)
+  hipLaunchKernelGGL(k_lin_grad<NT>, dim3(jl.Mloc, 2, GRAD_NS), dim3(256), lds2, jl.stream, w->x, w->mask, jl.theta, jl.scores, jl.thr, jt, jz,
                      jl.baseline, jl.m0, jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise, jl.mean_edge,
-                     jl.sig_edge, jl.sf_baseline, w->any_mask);
+                     jl.sig_edge, jl.sf_baseline, w->any_mask, gs);
 }
 
 #define LIN_NT_SWITCH(CALL_)                 \

@@ -148,6 +148,16 @@ __device__ __forceinline__ float nn_build_tw(float* TW, const float* GS, const f
   return prior;
 }
 
+// the same operand from the re-laid-out weights W1T[h][a][j] (k_nn_prior_table): coalesced -- W1[j][a][h] itself is a 4 d H byte stride between
+// neighbouring j, 64 sectors per wave-load; with thousands of sample gradients per launch (late in a run) those strided reads were the
+// gradient kernel's time
+__device__ __forceinline__ void nn_build_tw_t(float* TW, const float* GS, const float* __restrict__ w1t_h, const LinGeom g, int tid) {
+  for (int e = tid; e < g.kp * g.ldw; e += 256) {
+    const int a = e / g.ldw, j = e - a * g.ldw;
+    TW[e] = (a < g.d && j < g.d) ? GS[a * g.d + j] * w1t_h[a * g.d + j] : 0.f;
+  }
+}
+
 // The same two steps for k_nn_logprobs with the per-particle tables (prior table LN, re-laid-out weights W1T): element index e = a d + j
 // advances by the block size with a carry instead of a division, W1T is read coalesced (W1[j][a][h] itself is a 4 d H byte stride between
 // neighbouring j), and only the d x d interior of the zero-padded operand is rewritten per hidden unit.
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(64 * NW) void k_nn_logprobs(const float* __restrict
 //   mode THETA     : grad_theta = sum_s w_s d/dtheta log p(theta, D | G_s)          -> pack row (+ copy of theta)
 //   mode Z_REPARAM : W = sum_s w_s (d/dg) o tau alpha g~(1 - g~), off-diagonal     -> w_lik
 //   mode Z_SCORE   : W = scale * alpha (sum_s w_s G_s - P), off-diagonal           -> w_lik
-// grid = Mloc, block = 256.  Accumulation goes to global memory; every output element is owned by one thread.
+// grid = (Mloc, shares), block = 256.  Accumulation goes to global memory; every output element is owned by one thread.
 // ------------------------------------------------------------------------------------------------
 template <int NT, int ACT = -1>   // ACT >= 0: compile-time activation (relu), as in k_nn_logprobs
 __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, const int32_t* __restrict__ mask,
@@ -378,7 +388,8 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
                                                  float* __restrict__ out, size_t out_stride, float* __restrict__ theta_copy,
                                                  const float* __restrict__ baseline, float* __restrict__ baseline_out, Key2 carry,
                                                  int mode, int m0, int M_global, int d, int N, int S, float alpha, float tau,
-                                                 int layout, int tiny, NNParams np_, double sf_baseline, int any_mask) {
+                                                 int layout, int tiny, NNParams np_, double sf_baseline, int any_mask, GradSplit gs,
+                                                 const float* __restrict__ w1t) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const LinGeom g = lin_geom(d, N, NT);
   constexpr int NU = 2, NUD = (NT + 3) / 4;
@@ -388,54 +399,64 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
   float* RS = TW;                                  // ... and dpre_h [np][ldw] (backward operand), same storage
   float* CS = TW + (size_t)nn_tr_rows(g) * g.ldw;  // per-wave column sums [4][ldw]
   double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)d * d + (size_t)nn_tr_rows(g) * g.ldw + (size_t)4 * g.ldw) + 3) & ~(size_t)3));
-  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // grid = (Mloc, shares); block (x, y) takes share y of particle (x + y) mod Mloc.  Workgroups go to the 8 XCDs round-robin by their linear
+  // id x + Mloc y: with particle = x every share of particle m ran on XCD m mod 8, and the XCD that held the particles with the most weighted
+  // samples set the time (150 of 256 CUs busy, 18 ms instead of 8 at config 5 / step 300); rotated by y, a particle's shares land on all
+  // XCDs, and row y = 0 -- the only shares with work early in a run -- is still dispatched first.
+  const int m = (int)((blockIdx.x + blockIdx.y) % gridDim.x), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t dd = (size_t)d * d;
   const int H = np_.H;
   const NNOff off = nn_offsets(d, H, np_.bias);
   const float* th_m = theta + (size_t)m * P;
-  float* om = out + (size_t)m * out_stride;
+  float* const om_final = out + (size_t)m * out_stride;
+  const Key2 key = lin_mode_key(mode, carry, M_global, m0 + m, layout);
+  const uint64_t nbits = (uint64_t)S * dd;
+  const float* lp = logprobs + (size_t)m * S;
+  // softmax statistics and this block's share of the samples with a non-zero weight (GradSplit, kernels_joint.h)
+  __shared__ float wch[GRAD_WCH];
+  __shared__ int last_flag;
+  double mx, den, sm;
+  int nnz;
+  grad_softmax_stats(lp, S, red, mx, den, sm, nnz);
+  const int NS = gridDim.y, bz = blockIdx.y, nact = nnz < NS ? (nnz > 0 ? nnz : 1) : NS;
+  if (bz >= nact) return;  // (block-uniform: no share -- before anything is staged)
   for (int e = tid; e < g.np * g.ldx; e += 256) {
     const int n = e / g.ldx, c = e - n * g.ldx;
     X[e] = (n < N && c < d) ? x[(size_t)n * d + c] : 0.f;
   }
   for (int e = tid; e < 4 * g.ldw; e += 256) CS[e] = 0.f;
+  // the accumulation row: the output itself while one block does everything, else this block's partial sums
   // outputs start at zero (theta mode: P entries; z modes: d*d)
+  // Several blocks (split): the theta estimator's first-layer gradient -- d*d*H values that every sample updates -- is accumulated in THREAD
+  // layout ([slot][thread]: one coalesced read-modify-write per value; in theta's own layout a wave's 64 values lie 4 d H bytes apart, and
+  // with hundreds of partial rows in flight the 64-byte sectors of those updates came from HBM: 24 ms per launch at config 5, step 300);
+  // the small leaves follow behind it in theta's layout.  The Z modes accumulate d*d values in W's layout (16 consecutive floats per row).
+  const bool split = nact > 1;
   const size_t n_out = mode == LIN_MODE_THETA ? P : dd;
-  for (size_t e = tid; e < n_out; e += 256) om[e] = 0.f;
-  const Key2 key = lin_mode_key(mode, carry, M_global, m0 + m, layout);
-  const uint64_t nbits = (uint64_t)S * dd;
-  const float* lp = logprobs + (size_t)m * S;
-  double mx = -INFINITY;
-  for (int s = tid; s < S; s += 256) mx = (double)lp[s] > mx ? (double)lp[s] : mx;
-  mx = wave_max_d(mx);
-  if (lane == 0) red[wave] = mx;
-  __syncthreads();
-  mx = red[0];
-  for (int w = 1; w < 4; ++w) mx = red[w] > mx ? red[w] : mx;
-  double den = 0.0, sm = 0.0;
-  for (int s = tid; s < S; s += 256) {
-    den += exp((double)lp[s] - mx);
-    sm += (double)lp[s];
+  const size_t w1sz = (size_t)H * NUD * NT * 4 * 256;  // thread-layout area of the first-layer gradient
+  float* const prow = split ? gs.part + ((size_t)m * NS + bz) * gs.stride : nullptr;
+  // `om`: where the values in theta's / W's layout accumulate (split + theta mode: only the small leaves, behind the thread-layout area)
+  float* const om = !split ? om_final : (mode == LIN_MODE_THETA ? prow + w1sz - off.b1 : prow);
+  if (split && mode == LIN_MODE_THETA) {
+    for (size_t e = tid; e < w1sz + (P - off.b1); e += 256) prow[e] = 0.f;
+  } else {
+    for (size_t e = tid; e < n_out; e += 256) om[e] = 0.f;
   }
-  den = wave_sum_d(den);
-  sm = wave_sum_d(sm);
-  __syncthreads();
-  if (lane == 0) {
-    red[wave] = den;
-    red[4 + wave] = sm;
-  }
-  __syncthreads();
-  den = red[0] + red[1] + red[2] + red[3];
-  sm = red[4] + red[5] + red[6] + red[7];
   const float inv_on = 1.0f / np_.obs_noise;
   const float inv_sp2 = 1.0f / (np_.sig_param * np_.sig_param);
   const float* sc_m = scores + (size_t)m * dd;
   const uint32_t* thr_m = thr + (size_t)m * dd;
   const int nrt = g.np >> 4;
 
-  for (int s = 0; s < S; ++s) {
-    const float w = (float)(exp((double)lp[s] - mx) / den);
+  int q = 0;  // ordinal of the next sample with a non-zero weight
+  for (int s0 = 0; s0 < S; s0 += GRAD_WCH) {
+    __syncthreads();
+    if (s0 + tid < S) wch[tid] = (float)(exp((double)lp[s0 + tid] - mx) / den);
+    __syncthreads();
+  for (int s = s0; s < S && s < s0 + GRAD_WCH; ++s) {
+    const float w = wch[s - s0];
     if (w == 0.f) continue;  // block-uniform
+    if ((q++ % NS) != bz) continue;  // (another block's sample)
     __syncthreads();
     nn_build_graph(GS, mode, key, nbits, s, thr_m, sc_m, alpha, tau, layout, tiny, d, tid);
     __syncthreads();
@@ -451,7 +472,8 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
       for (int tj = 0; tj < NT; ++tj) macc[u][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int h = 0; h < H; ++h) {
       __syncthreads();
-      nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid);
+      if (w1t) nn_build_tw_t(TW, GS, w1t + ((size_t)m * H + h) * dd, g, tid);
+      else nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid);
       __syncthreads();
       f32x4 acc[NU][NT];
       nn_gemm_x_tw<NT, NU>(X, TW, g, lane, wave, acc);
@@ -494,7 +516,8 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
     // ---- backward, one hidden unit at a time ----
     for (int h = 0; h < H; ++h) {
       __syncthreads();
-      nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid);
+      if (w1t) nn_build_tw_t(TW, GS, w1t + ((size_t)m * H + h) * dd, g, tid);
+      else nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid);
       __syncthreads();
       f32x4 acc[NU][NT];
       nn_gemm_x_tw<NT, NU>(X, TW, g, lane, wave, acc);
@@ -554,9 +577,11 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
               float xtr = t[tj][r];
               asm volatile("" : "+v"(xtr));
               const float gv = GS[a * d + j];
-              const float w1 = th_m[((size_t)j * d + a) * H + h];
+              const float w1 = w1t ? w1t[((size_t)m * H + h) * dd + (size_t)a * d + j] : th_m[((size_t)j * d + a) * H + h];
               if (mode == LIN_MODE_THETA) {
-                om[((size_t)j * d + a) * H + h] += w * gv * (xtr - w1 * inv_sp2);
+                const float v = w * gv * (xtr - w1 * inv_sp2);
+                if (split) prow[(size_t)(((h * NUD + u) * NT + tj) * 4 + r) * 256 + tid] += v;
+                else om[((size_t)j * d + a) * H + h] += v;
               } else if (a != j) {
                 om[a * d + j] += w * (lin_logn(w1, 0.f, np_.sig_param) + w1 * xtr) * tau * alpha * gv * (1.0f - gv);
               }
@@ -565,12 +590,44 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
       }
     }
   }
+  }
   __syncthreads();
+  if (nact > 1) {
+    // the partial sums were accumulated with plain read-modify-writes: release them, count this block, and the LAST block of the particle
+    // adds the rows in block order into the output
+    __threadfence();
+    if (!grad_last_block(gs.ctr + m, nact, &last_flag)) return;
+    __threadfence();
+    const float* const base = gs.part + (size_t)m * NS * gs.stride;
+    if (mode == LIN_MODE_THETA) {
+      for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int u = 0; u < NUD; ++u) {
+          const int ti = wave + 4 * u;
+          if (ti >= NT) continue;
+#pragma unroll
+          for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int a = ti * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
+              if (a < d && j < d) {
+                const size_t slot = (size_t)(((h * NUD + u) * NT + tj) * 4 + r) * 256 + tid;
+                om_final[((size_t)j * d + a) * H + h] = grad_part_sum<GRAD_NS_NN, false>(base, gs.stride, slot, nact);
+              }
+            }
+        }
+      for (size_t e = off.b1 + tid; e < P; e += 256)  // the small leaves
+        om_final[e] = grad_part_sum<GRAD_NS_NN, false>(base, gs.stride, w1sz + (e - off.b1), nact);
+    } else {
+      for (size_t e = tid; e < n_out; e += 256) om_final[e] = grad_part_sum<GRAD_NS_NN, false>(base, gs.stride, e, nact);
+    }
+    __syncthreads();
+  }
   // epilogue
   const float bold = baseline ? baseline[m] : 0.f;
   if (mode == LIN_MODE_THETA) {
     // graph-independent prior gradient of the remaining leaves: -theta / sig_p^2 (the softmax weights sum to 1)
-    for (size_t e = off.b1 + tid; e < off.P; e += 256) om[e] += -th_m[e] * inv_sp2;
+    for (size_t e = off.b1 + tid; e < off.P; e += 256) om_final[e] += -th_m[e] * inv_sp2;
     if (theta_copy)
       for (size_t e = tid; e < P; e += 256) theta_copy[(size_t)m * out_stride + e] = th_m[e];
   } else if (mode == LIN_MODE_Z_SCORE) {
@@ -578,7 +635,7 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
     for (int e = tid; e < (int)dd; e += 256) {
       const int i = e / d, j = e - i * d;
       const float p = (float)sigmoid_d((double)__fmul_rn(alpha, sc_m[e]));
-      om[e] = i == j ? 0.f : scale * alpha * (om[e] - p);
+      om_final[e] = i == j ? 0.f : scale * alpha * (om_final[e] - p);
     }
   }
   if (mode != LIN_MODE_THETA && baseline_out && tid == 0)
@@ -774,19 +831,27 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
   float* out = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off : jl.w_lik;
   const size_t ostride = mode == LIN_MODE_THETA ? jl.pack_stride : (size_t)jl.d * jl.d;
   float* tcopy = (mode == LIN_MODE_THETA && jl.copy_theta) ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr;
+  GradSplit gs;  // (several blocks per particle once many samples keep a non-zero weight: kernels_joint.h; the row is P floats for theta, d*d for Z)
+  // (partial row of a block: the first-layer gradient in thread layout + the small leaves for theta, d*d for Z; the shares per particle are
+  //  cut back when GRAD_NS_NN rows per particle would exceed 4 GiB -- hidden widths in the dozens)
+  const size_t row_theta = (size_t)np_.H * ((NT + 3) / 4) * NT * 4 * 256 + (P - (size_t)jl.d * jl.d * np_.H);
+  const size_t row = row_theta > (size_t)jl.d * jl.d ? row_theta : (size_t)jl.d * jl.d;
+  int ns_nn = GRAD_NS_NN;
+  while (ns_nn > 1 && (size_t)jl.Mloc * ns_nn * row * 4 > ((size_t)4 << 30)) ns_nn >>= 1;
+  if (!joint_grad_split(w, (size_t)jl.Mloc, row, &gs, ns_nn)) return;  // (the step's launch check reports the failed hipMalloc)
   if (np_.act == 0) {
-    hipLaunchKernelGGL((k_nn_grad<NT, 0>), dim3(jl.Mloc), dim3(256), lds2, jl.stream, w->x, w->mask, jl.theta, P, jl.scores, jl.thr, lp, out,
+    hipLaunchKernelGGL((k_nn_grad<NT, 0>), dim3(jl.Mloc, ns_nn), dim3(256), lds2, jl.stream, w->x, w->mask, jl.theta, P, jl.scores, jl.thr, lp, out,
                      ostride, tcopy, jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode, jl.m0,
-                     jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask);
+                     jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask, gs, w->ln_tab ? w->w1t : nullptr);
   } else {
-    hipLaunchKernelGGL((k_nn_grad<NT, -1>), dim3(jl.Mloc), dim3(256), lds2, jl.stream, w->x, w->mask, jl.theta, P, jl.scores, jl.thr, lp, out,
+    hipLaunchKernelGGL((k_nn_grad<NT, -1>), dim3(jl.Mloc, ns_nn), dim3(256), lds2, jl.stream, w->x, w->mask, jl.theta, P, jl.scores, jl.thr, lp, out,
                      ostride, tcopy, jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode, jl.m0,
-                     jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask);
+                     jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask, gs, w->ln_tab ? w->w1t : nullptr);
   }
 }
 
 bool joint_nn_fast_path(int d, int N, const NNParams& np_) {
-  return np_.n_hidden == 1 && np_.H >= 1 && np_.H <= 64 && N <= 128 && d <= 112 && nn_lds_bytes(d, N, (d + 15) / 16, true) <= (size_t)160 * 1024;
+  return np_.n_hidden == 1 && np_.H >= 1 && np_.H <= 64 && N <= 128 && d <= 112 && nn_lds_bytes(d, N, (d + 15) / 16, true) <= (size_t)160 * 1024 - 2048;  // (2 KiB for the static LDS of k_nn_grad)
 }
 
 // scratch of the general path: grown on first use (activation records of the work items; see kernels_nn_generic.h)

@@ -468,6 +468,46 @@ def _lingauss_step_stages(c_oracle64, d, M, S, Sa, est, prior, interv, steps):
     eng.close()
 
 
+@pytest.mark.parametrize("model,d,M,S,est,noise", [
+    ("lingauss", 20, 3, 64, "reparam", 1e4),    # every sample keeps a weight: 8 samples per block, all 8 blocks of a particle add up
+    ("lingauss", 50, 4, 128, "reparam", 1e4),
+    ("lingauss", 50, 3, 40, "score", 1e4),      # the Z estimator's score form (no matrix products) through the same split
+    ("lingauss", 100, 2, 16, "reparam", 1e4),   # two row tiles per wave
+    ("lingauss", 20, 3, 5, "reparam", 1e4),     # fewer weighted samples than blocks: only 5 partial sums exist
+    ("densenn", 20, 3, 64, "reparam", 1e4),
+    ("densenn", 50, 2, 24, "score", 1e4),
+    ("densenn", 100, 2, 12, "reparam", 1e4),
+])
+def test_joint_gradients_with_many_weighted_samples(c_oracle64, model, d, M, S, est, noise):
+    """Late in a run many samples keep a non-zero softmax weight (dibs.py:376-382, 531-549) and the gradient kernels deal them to GRAD_NS
+    blocks per particle, the last block adding the partial sums (kernels_joint.h: GradSplit).  A large observation noise flattens the
+    log-probabilities so that EVERY sample has a weight from the first step on; same stages, same bounds as the step tests."""
+    data, _, _ = make_data(d, seed=4, joint=True)
+    kw = dict(lin_obs_noise=noise) if model == "lingauss" else dict(nn_obs_noise=noise, nn_hidden=(5,))
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=100, joint=True, likelihood=model, grad_estimator_z=est, n_grad_mc_samples=S,
+                      n_acyclicity_mc_samples=4, score_function_baseline=0.001 if est == "score" else 0.0, **kw)
+    st = c_oracle64.new_state(cfg, prng.PRNGKey(6))
+    eng = _engine(cfg, data.x)
+    eng.init_particles(prng.PRNGKey(6))
+    for t in (400, 401):   # (late: the edge probabilities have saturated, the sampled graphs of a particle are nearly the same graph)
+        _sync_states(eng, st)
+        dbg = c_oracle64.step(cfg, data.x, None, st, t, debug=True)
+        eng.run(t, 1)
+        for name in ("LOGPROBS_THETA", "LOGPROBS_Z"):
+            lp = eng.read(name).reshape(M, S).astype(np.float64)
+            w = np.exp(lp - lp.max(1, keepdims=True))
+            w = (w / w.sum(1, keepdims=True)).astype(np.float32)
+            print(name, "samples with a weight per particle:", (w > 0).sum(1))
+            if name == "LOGPROBS_THETA" and d <= 50:   # (at d = 100 the prior term of the sampled edges still separates the samples: those cases only re-check the one-block path)
+                assert (w > 0).sum(1).max() >= 2, (name, (w > 0).sum(1))   # at least one particle's gradient is shared between blocks
+        assert rel_err(eng.read("LOGPROBS_THETA"), dbg["logprobs_th"]) < 2e-5
+        assert rel_err(eng.read("GRAD_THETA"), dbg["grad_theta"]) < 2e-3, rel_err(eng.read("GRAD_THETA"), dbg["grad_theta"])
+        assert rel_err(eng.read("W_LIK"), dbg["w_lik"]) < 2e-3, rel_err(eng.read("W_LIK"), dbg["w_lik"])
+        g = eng.get_state()
+        assert rel_err(g["theta"], st["theta"]) < 1e-4 and rel_err(g["z"], st["z"]) < 1e-4
+    eng.close()
+
+
 @pytest.mark.parametrize("d,M,S,Sa,est,interv,N,force", [
     (20, 4, 32, 8, "reparam", False, 100, True),    # same sizes as the MFMA path: both device paths against one oracle
     (20, 4, 32, 8, "score", True, 100, True),
