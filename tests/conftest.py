@@ -42,6 +42,23 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
 
+def stage_err(what, a, b, tol):
+    """A stage buffer against the oracle: the max-norm relative error is ASSERTED against `tol`; beside it the element-wise relative error on
+    the entries that carry signal (|b| > 1e-3 max |b|) is printed -- median, 99th percentile and maximum -- so that the log of a run shows
+    what a bound like 2e-3 of the largest entry means entry by entry (`pytest -s`; profiles/round6_stage_errors.txt keeps one run)."""
+    a = np.asarray(a, np.float64).reshape(-1)
+    b = np.asarray(b, np.float64).reshape(-1)
+    scale = max(np.abs(b).max(), 1e-300)
+    e = float(np.abs(a - b).max() / scale)
+    big = np.abs(b) > 1e-3 * scale
+    if big.any():
+        el = np.abs(a - b)[big] / np.abs(b)[big]
+        print(f"  stage {what}: max-norm {e:.2e} (bound {tol:.0e}) | element-wise on {int(big.sum())} signal entries: median {np.median(el):.1e} "
+              f"p99 {np.percentile(el, 99):.1e} max {el.max():.1e}")
+    assert e < tol, (what, e, tol)
+    return e
+
+
 # ---- the ONE criterion for "one SVGD step from the same state" (north_star: Z within 1e-4 relative in float32) -------------------------
 # RMSprop maps phi to a step of ~stepsize / sqrt(0.1) whatever its size while the second-moment estimate is still small, so a coordinate
 # whose phi lies below the float32 noise of the largest one takes a full-size step in a direction decided by rounding -- in the reference's

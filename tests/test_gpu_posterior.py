@@ -7,7 +7,7 @@ part 2), so the statement that can hold -- and is asserted here with FIXED toler
   * wherever the device's particle graphs equal the float64 oracle's (most seeds at the early checkpoints), E-SHD agrees to 1e-3, and
     a fixed minimum number of seeds (TOL; the measured count and the float32 oracle's beside it) is still in that state;
   * at the full step counts (config 2: 1000 steps = BASELINE configs[1]; headline d=50 / 128 particles: 400 steps) the E-SHD of the
-    device, averaged over 8 (data, key) seeds, agrees with the float64 oracle's within 2 standard errors of the paired differences
+    device, averaged over the (data, key) seeds (config 2: 16, headline: 8), agrees with the float64 oracle's within 2 standard errors of the paired differences
     that the oracle's float32 build shows against its float64 build, and every single seed stays within a fixed bound taken from
     the largest such difference (constants in TOL below, measured values beside them).
 
@@ -64,16 +64,24 @@ def _report(name, fx, cps, eshd, graphs):
     return same64
 
 
-# Fixed tolerances, taken from this round's measurements (profiles/round3_posterior_parity.txt lists device, f64 and f32 numbers per seed).
-# Per checkpoint: (seeds of 8 whose particle graphs must ALL equal the f64 oracle's, bound on |mean over seeds of E-SHD_gpu - E-SHD_f64|,
-# bound on the largest single-seed difference).  Yardstick: the oracle's own float32 build against its float64 build --
-#   config 2:  step 250: 7 of 8 seeds identical, E-SHD equal for all 8;  step 500: 4 of 8, mean +0.047, sd 0.21, max 0.375;
-#              step 1000: 0 of 8, mean -0.105, sd 0.79 (2 SE = 0.56), max 1.28
-#   device:    step 250: 7 of 8 (one seed separated early, E-SHD off by 0.5 there);  step 500: 4 of 8, mean +0.012, max 0.5;
-#              step 1000: 0 of 8, mean +0.059, max 0.84
-# One flipped edge in one of 32 equally weighted particles moves E-SHD by 0.031 (128 particles: 0.008).
+# Fixed tolerances per checkpoint: (seeds whose particle graphs must ALL equal the f64 oracle's, bound on |mean over seeds of E-SHD_gpu - E-SHD_f64|,
+# bound on the largest single-seed difference).  Yardstick: the oracle's own float32 build against its float64 build on the same seeds.
+#
+# config 2, round 6: SIXTEEN seeds (tests/golden/make_posterior_golden.py; seeds 0-7 reproduce round 5's fixture bit for bit).  One flipped
+# edge in one of the 32 equally weighted particles moves E-SHD by 0.031.  float32 build - float64 build, per checkpoint:
+#     step 250:  12 of 16 seeds identical graphs (difference exactly 0), the other four -0.03 .. -0.31;  mean -0.035, sd 0.092
+#     step 500:   7 of 16 identical;  mean -0.045, sd 0.302, max 0.81
+#     step 1000:  none identical;     mean +0.076, sd 0.616, max 1.28
+# A seed whose trajectory has separated differs by a draw from the spread of nearby posteriors whatever the arithmetic, so the yardstick of a
+# checkpoint is sd_ref(cp) = max(sd at that checkpoint, sd at step 500) (at step 250 most differences are still exactly zero and the sample sd
+# says nothing about a seed that HAS separated).  Rules, from the float32 oracle's spread alone (nothing is calibrated on the device):
+#     mean over the 16 seeds:  |mean| <= 2 sd_ref / sqrt(16)      = 0.151 / 0.151 / 0.308
+#     any single seed:         |diff| <= 3 sd_ref                 = 0.906 / 0.906 / 1.848
+#     identical seeds:         at least half of the float32 oracle's count (6 / 3 / 0)
+# Device, round 6 (profiles/round6_posterior_parity.txt): mean -0.104 / +0.025 / +0.166 (margins 1.5x / 6x / 1.9x), largest seed 0.50 / 0.75 /
+# 1.59 (1.8x / 1.2x / 1.16x), identical seeds 9 / 6 / 0.  (Round 5's bounds at step 1 000 were 0.56 and 2.0 on 8 seeds.)
 TOL = {
-    "config2": {250: (6, 0.15, 0.75), 500: (3, 0.20, 0.75), 1000: (0, 0.56, 2.0)},
+    "config2": {250: (6, 0.151, 0.906), 500: (3, 0.151, 0.906), 1000: (0, 0.308, 1.848)},
     # headline (d=50, 128 particles; one flipped edge in one particle moves E-SHD by 0.0078).  Yardstick, f32 build of the oracle against f64:
     #   step 200: 5 of 8 seeds with all 128 graphs identical (the others: 2-3 particles differ), mean +0.0013, sd 0.0235 (2 SE = 0.017), max 0.053;
     #   step 300: no seed identical (27-44 % of the particles are), mean +0.0225, sd 0.099 (2 SE = 0.070), max 0.19;
@@ -99,7 +107,7 @@ def _check(name, fx, d, cps, eshd, same64):
 
 
 def test_config2_posterior_1000_steps():
-    """BASELINE configs[1]: MarginalDiBS + BGe, d=20, 32 particles, 1000 steps; 8 seeds; checkpoints 250 / 500 / 1000."""
+    """BASELINE configs[1]: MarginalDiBS + BGe, d=20, 32 particles, 1000 steps; 16 seeds; checkpoints 250 / 500 / 1000."""
     fx, d, cps, eshd, graphs = _device_posterior("config2")
     same64 = _report("config2", fx, cps, eshd, graphs)
     _check("config2", fx, d, cps, eshd, same64)
