@@ -10,8 +10,11 @@ before the timed region.  W untimed steps t = 0..W-1 of the trajectory from PRNG
 between barrier + synchronize fences (max over ranks).  The cost of a step depends on t (sampled parent sets shrink as the particles
 sharpen), so the timed window is restored from a snapshot and measured repeatedly -- at least `--reps` times and until the timed
 regions add up to `--min-seconds` of GPU time: `value` comes from the MEDIAN repetition, `rep_ms_per_step` summarises all of them.
-N > 1 shards the particles over the ranks (strong scaling: total work fixed); per step one RCCL all-gather of the gradient rows between the
-phases and one of the new values beside the next phase A (dibs_amd/distributed.py).
+N > 1 shards the particles over the ranks (strong scaling: total work fixed) and runs the step loop inside the engine
+(dibs_engine_run_sharded): one all-gather of the packed rows per step below 512 particles, from there on the gradient rows between the
+phases and the new values beside the next phase A.  RCCL by default; DIBS_COMM=ipc exchanges through mapped peer memory, so that the
+ranks may share devices (`--gpus 4` on a one-GPU box runs the whole N > 1 path; its value measures processes time-sharing a GPU).
+`steady_state` repeats the timed window from step --steady-t (300) of the same trajectory.
 Rank 0 prints ONE JSON line (DESIGN.md "Measurement" explains every field).
 
 --config selects the workload: `headline` (default) is BASELINE.json's metric config; 2 .. 5 are BASELINE.json configs[1..4] at their
@@ -446,7 +449,7 @@ def main():
         roof.update(launches=dom_n, share_of_step=dom_ms / total_ms,
                     duration="kernel alone on the GPU (the step is serialised while timing); in the timed region the acyclicity kernel runs on "
                              "its second stream beside the likelihood kernels, see kernel_us_per_step_concurrent / frac_concurrent")
-        for tag in ("round5", "round4", "round3", "round2"):   # separate rocprofv3 --pmc passes of this command (scripts/collect_profiles.sh)
+        for tag in ("round6", "round5", "round4", "round3", "round2"):   # separate rocprofv3 --pmc passes of this command (scripts/collect_profiles.sh)
             suffix = "" if args.config == "headline" else f"_cfg{args.config}"
             pmc = os.path.join(ROOT, "profiles", f"{tag}{suffix}_pmc_hbm.json")
             if os.path.exists(pmc):

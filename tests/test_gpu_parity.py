@@ -181,7 +181,7 @@ def test_marginal_bge_edge_cases(c_oracle64, d, M, S, Sa, k, case):
 
 @pytest.mark.parametrize("d,Sa", [(33, 4), (34, 2), (40, 4), (47, 2), (48, 4), (49, 2), (52, 4), (63, 2), (64, 4), (50, 3)])
 def test_acyclicity_kernel_sizes_33_to_64(c_oracle64, d, Sa):
-    """k_acyc_bf (float products on the bf16 matrix pipe with three-way split operands, kernels_acyc_bf16.h) at every tile / exponent
+    """k_acyc_hf (float products on the f16 matrix pipe with two block-scaled pieces per operand, kernels_acyc_f16.h) at every tile / exponent
     boundary of its range: d - 1 = 32 (squarings only), 63 (a "times M" step after every squaring), 47 / 48 / 49 (last row tile and
     last column tile empty, just filled, just started).  Sa = 3 takes the f32-MFMA kernel (chains cannot be paired): same tolerance.
     reference: graph_utils.py:8-28, dibs.py:557-601"""
@@ -201,7 +201,7 @@ def test_acyclicity_kernel_sizes_33_to_64(c_oracle64, d, Sa):
 
 @pytest.mark.parametrize("d,Sa", [(65, 2), (72, 4), (80, 2), (81, 4), (96, 2), (97, 2), (100, 4), (111, 2), (112, 4), (100, 3)])
 def test_acyclicity_kernel_sizes_65_to_112(c_oracle64, d, Sa):
-    """k_acyc_bfw<5 / 6 / 7> (the split-bf16 scheme with 5 .. 7 tiles and waves, kernels_acyc_bf16.h) at the boundaries of its range:
+    """k_acyc_hfw<5 / 6 / 7> (the two-piece f16 scheme with 5 .. 7 tiles and waves, kernels_acyc_f16.h) at the boundaries of its range:
     first / last size of every tile count, odd tile counts (the last k-step reads its second half from the zero page), d = 100 (BASELINE
     config 5).  Sa = 3 takes the f32-MFMA kernel (chains cannot be paired): same tolerance.  reference: graph_utils.py:8-28, dibs.py:557-601"""
     M, S = 2, 2

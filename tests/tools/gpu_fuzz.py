@@ -192,7 +192,9 @@ def main():
                 gg = graphs_from_masks(eng.read("PARENT_MASKS"), kw["n_particles"], kw["n_grad_mc_samples"], kw["n_vars"])
                 nflip = int((gg != dbg["g_samples"]).sum())
                 same_s = (gg == dbg["g_samples"]).all(axis=(2, 3))
-                if nflip > max(2, 1e-5 * gg.size):
+                # (a draw flips when its 23-bit uniform falls between the float32 and the float64 threshold, |p32 - p64| <~ 2^-24: about
+                #  gg.size 2^-24 flips are expected; 2 + 8 x that many are excused -- 3 of 12.8 M draws, not round 5's 1e-5 of them)
+                if nflip > 2 + int(8 * gg.size * 2.0 ** -23):
                     note += f" graphs-differ({nflip} of {gg.size})"
                 elif nflip:
                     e, note = min(e, 0.0), note + f" ({nflip} Bernoulli boundary flips of {gg.size}: Z not compared)"
@@ -204,7 +206,7 @@ def main():
                 # 1e-3 of the largest are Bernoulli boundary flips, as above (seed 902 trial 6 of FUZZ_BIG: one of 5 120 samples, on every
                 # device kernel and on round 4's library alike)
                 off = np.abs(lp_d - lp_o) > 1e-3 * max(np.abs(lp_o).max(), 1e-300)
-                if 0 < off.sum() <= max(2, 1e-5 * M * S * d * d):
+                if 0 < off.sum() <= 2 + int(8 * M * S * d * d * 2.0 ** -23):   # (expected threshold ties, as above -- an absolute handful, not a share of the samples)
                     sel = sel & ~off
                     e, note = min(e, 0.0), note + f" ({int(off.sum())} of {M * S} samples off in log-probability: Bernoulli boundary flips, Z not compared)"
             if sel.any() and np.isfinite(lp_o[sel]).all():
