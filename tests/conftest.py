@@ -45,7 +45,10 @@ def rel_err(a, b):
 def stage_err(what, a, b, tol):
     """A stage buffer against the oracle: the max-norm relative error is ASSERTED against `tol`; beside it the element-wise relative error on
     the entries that carry signal (|b| > 1e-3 max |b|) is printed -- median, 99th percentile and maximum -- so that the log of a run shows
-    what a bound like 2e-3 of the largest entry means entry by entry (`pytest -s`; profiles/round6_stage_errors.txt keeps one run)."""
+    what a bound like 2e-3 of the largest entry means entry by entry (`pytest -s`; profiles/round6_stage_errors.txt keeps one run).
+    Bounds in the tests, from that run (worst case over the 326 stage comparisons of the suite; the runs are bit-reproducible):
+    GRAD_Z / PHI_Z 1e-4 (worst 1.4e-5), GRAD_THETA 5e-4 (6.1e-5), W_LIK / PHI_THETA 2e-3 (5.3e-4 / 7.2e-4: softmax-weighted sums of
+    near-tied log-scores)."""
     a = np.asarray(a, np.float64).reshape(-1)
     b = np.asarray(b, np.float64).reshape(-1)
     scale = max(np.abs(b).max(), 1e-300)

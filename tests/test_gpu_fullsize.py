@@ -155,13 +155,13 @@ def test_config3_fullsize_step(c_oracle64):
         assert (g["key"] == st["key"]).all()
         assert rel_err(eng.read("LOGPROBS_THETA"), dbg["logprobs_th"]) < 2e-5
         assert rel_err(eng.read("LOGPROBS_Z"), dbg["logprobs_z"]) < 2e-5
-        stage_err("GRAD_THETA", eng.read("GRAD_THETA"), dbg["grad_theta"], 2e-3)
+        stage_err("GRAD_THETA", eng.read("GRAD_THETA"), dbg["grad_theta"], 5e-4)
         stage_err("W_LIK", eng.read("W_LIK"), dbg["w_lik"], 2e-3)
         assert rel_err(eng.read("W_ACYC"), dbg["w_acyc"]) < 1e-5
-        stage_err("GRAD_Z", eng.read("GRAD_Z"), dbg["grad_z"], 2e-3)
+        stage_err("GRAD_Z", eng.read("GRAD_Z"), dbg["grad_z"], 1e-4)
         assert rel_err(eng.read("KXX"), dbg["kxx"]) < 1e-5
         stage_err("PHI_THETA", eng.read("PHI_THETA"), dbg["phi_theta"], 2e-3)
-        stage_err("PHI_Z", eng.read("PHI_Z"), dbg["phi_z"], 2e-3)
+        stage_err("PHI_Z", eng.read("PHI_Z"), dbg["phi_z"], 1e-4)
         uz = update_check(cfg, prev["z"], prev["v_z"], eng.read("PHI_Z"), dbg["phi_z"], g["z"], st["z"])
         ut = update_check(cfg, prev["theta"], prev["v_theta"], eng.read("PHI_THETA"), dbg["phi_theta"], g["theta"], st["theta"])
         print(f"config 3 t={t}: z {uz}; theta {ut}")
@@ -306,10 +306,10 @@ def test_config5_fullsize_step(c_oracle64):
     assert (g["key"] == st["key"]).all()
     assert rel_err(eng.read("LOGPROBS_THETA"), dbg["logprobs_th"]) < 2e-5
     assert rel_err(eng.read("LOGPROBS_Z"), dbg["logprobs_z"]) < 2e-5
-    stage_err("GRAD_THETA", eng.read("GRAD_THETA"), dbg["grad_theta"], 2e-3)
+    stage_err("GRAD_THETA", eng.read("GRAD_THETA"), dbg["grad_theta"], 5e-4)
     stage_err("W_LIK", eng.read("W_LIK"), dbg["w_lik"], 2e-3)
     assert rel_err(eng.read("W_ACYC"), dbg["w_acyc"]) < 1e-5
-    stage_err("GRAD_Z", eng.read("GRAD_Z"), dbg["grad_z"], 2e-3)
+    stage_err("GRAD_Z", eng.read("GRAD_Z"), dbg["grad_z"], 1e-4)
     stage_err("PHI_THETA", eng.read("PHI_THETA"), dbg["phi_theta"], 2e-3)
     uz = update_check(cfg, prev["z"], prev["v_z"], eng.read("PHI_Z"), dbg["phi_z"], g["z"], st["z"])
     ut = update_check(cfg, prev["theta"], prev["v_theta"], eng.read("PHI_THETA"), dbg["phi_theta"], g["theta"], st["theta"])

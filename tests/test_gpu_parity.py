@@ -456,10 +456,10 @@ def _lingauss_step_stages(c_oracle64, d, M, S, Sa, est, prior, interv, steps):
         assert (g["key"] == st["key"]).all()
         assert rel_err(eng.read("LOGPROBS_THETA"), dbg["logprobs_th"]) < 2e-5
         assert rel_err(eng.read("LOGPROBS_Z"), dbg["logprobs_z"]) < 2e-5
-        stage_err("GRAD_THETA", eng.read("GRAD_THETA"), dbg["grad_theta"], 2e-3)
+        stage_err("GRAD_THETA", eng.read("GRAD_THETA"), dbg["grad_theta"], 5e-4)
         stage_err("W_LIK", eng.read("W_LIK"), dbg["w_lik"], 2e-3)
         assert rel_err(eng.read("W_ACYC"), dbg["w_acyc"]) < 1e-5
-        stage_err("GRAD_Z", eng.read("GRAD_Z"), dbg["grad_z"], 2e-3)
+        stage_err("GRAD_Z", eng.read("GRAD_Z"), dbg["grad_z"], 1e-4)
         assert rel_err(eng.read("KXX"), dbg["kxx"]) < 1e-5
         stage_err("PHI_THETA", eng.read("PHI_THETA"), dbg["phi_theta"], 2e-3)
         assert rel_err(g["baseline"], st["baseline"]) < 1e-5 or np.abs(st["baseline"]).max() == 0
@@ -501,7 +501,7 @@ def test_joint_gradients_with_many_weighted_samples(c_oracle64, model, d, M, S, 
             if name == "LOGPROBS_THETA" and d <= 50:   # (at d = 100 the prior term of the sampled edges still separates the samples: those cases only re-check the one-block path)
                 assert (w > 0).sum(1).max() >= 2, (name, (w > 0).sum(1))   # at least one particle's gradient is shared between blocks
         assert rel_err(eng.read("LOGPROBS_THETA"), dbg["logprobs_th"]) < 2e-5
-        stage_err("GRAD_THETA", eng.read("GRAD_THETA"), dbg["grad_theta"], 2e-3)
+        stage_err("GRAD_THETA", eng.read("GRAD_THETA"), dbg["grad_theta"], 5e-4)
         stage_err("W_LIK", eng.read("W_LIK"), dbg["w_lik"], 2e-3)
         g = eng.get_state()
         assert rel_err(g["theta"], st["theta"]) < 1e-4 and rel_err(g["z"], st["z"]) < 1e-4
@@ -549,12 +549,12 @@ def test_joint_lingauss_gram_path(c_oracle64, monkeypatch, d, M, S, Sa, est, int
         assert (g["key"] == st["key"]).all()
         assert rel_err(eng.read("LOGPROBS_THETA"), dbg["logprobs_th"]) < 2e-5
         assert rel_err(eng.read("LOGPROBS_Z"), dbg["logprobs_z"]) < 2e-5
-        stage_err("GRAD_THETA", eng.read("GRAD_THETA"), dbg["grad_theta"], 2e-3)
+        stage_err("GRAD_THETA", eng.read("GRAD_THETA"), dbg["grad_theta"], 5e-4)
         stage_err("W_LIK", eng.read("W_LIK"), dbg["w_lik"], 2e-3)
-        stage_err("GRAD_Z", eng.read("GRAD_Z"), dbg["grad_z"], 2e-3)
+        stage_err("GRAD_Z", eng.read("GRAD_Z"), dbg["grad_z"], 1e-4)
         stage_err("PHI_THETA", eng.read("PHI_THETA"), dbg["phi_theta"], 2e-3)
         assert rel_err(g["theta"], st["theta"]) < 1e-4
-        stage_err("PHI_Z", eng.read("PHI_Z"), dbg["phi_z"], 2e-3)
+        stage_err("PHI_Z", eng.read("PHI_Z"), dbg["phi_z"], 1e-4)
         if 0.1 * float(np.abs(dbg["phi_z"]).max()) ** 2 > 1e38:   # (d >= 128: phi^2 beyond float32 in RMSprop, see test_marginal_bge_step_stages)
             assert d >= 128
             continue
@@ -710,9 +710,9 @@ def test_joint_densenn_step_stages(c_oracle64, d, M, S, Sa, H, act, bias, est, i
         assert (g["key"] == st["key"]).all()
         assert rel_err(eng.read("LOGPROBS_THETA"), dbg["logprobs_th"]) < 2e-5
         assert rel_err(eng.read("LOGPROBS_Z"), dbg["logprobs_z"]) < 2e-5
-        stage_err("GRAD_THETA", eng.read("GRAD_THETA"), dbg["grad_theta"], 2e-3)
+        stage_err("GRAD_THETA", eng.read("GRAD_THETA"), dbg["grad_theta"], 5e-4)
         stage_err("W_LIK", eng.read("W_LIK"), dbg["w_lik"], 2e-3)
-        stage_err("GRAD_Z", eng.read("GRAD_Z"), dbg["grad_z"], 2e-3)
+        stage_err("GRAD_Z", eng.read("GRAD_Z"), dbg["grad_z"], 1e-4)
         stage_err("PHI_THETA", eng.read("PHI_THETA"), dbg["phi_theta"], 2e-3)
         assert rel_err(g["theta"], st["theta"]) < 1e-4
         # piecewise-linear activations: a pre-activation within fp32 rounding of 0 flips relu' between the f32 device
@@ -756,12 +756,12 @@ def test_joint_densenn_general_stacks(c_oracle64, d, M, S, Sa, hidden, act, bias
         assert (g["key"] == st["key"]).all()
         assert rel_err(eng.read("LOGPROBS_THETA"), dbg["logprobs_th"]) < 2e-5
         assert rel_err(eng.read("LOGPROBS_Z"), dbg["logprobs_z"]) < 2e-5
-        stage_err("GRAD_THETA", eng.read("GRAD_THETA"), dbg["grad_theta"], 2e-3)
+        stage_err("GRAD_THETA", eng.read("GRAD_THETA"), dbg["grad_theta"], 5e-4)
         stage_err("W_LIK", eng.read("W_LIK"), dbg["w_lik"], 2e-3)
-        stage_err("GRAD_Z", eng.read("GRAD_Z"), dbg["grad_z"], 2e-3)
+        stage_err("GRAD_Z", eng.read("GRAD_Z"), dbg["grad_z"], 1e-4)
         stage_err("PHI_THETA", eng.read("PHI_THETA"), dbg["phi_theta"], 2e-3)
         assert rel_err(g["theta"], st["theta"]) < 1e-4
-        stage_err("PHI_Z", eng.read("PHI_Z"), dbg["phi_z"], 2e-3)
+        stage_err("PHI_Z", eng.read("PHI_Z"), dbg["phi_z"], 1e-4)
         if 0.1 * float(np.abs(dbg["phi_z"]).max()) ** 2 > 1e38:   # (d >= 128: phi^2 beyond float32 in RMSprop, see test_marginal_bge_step_stages)
             assert d >= 128
             continue
