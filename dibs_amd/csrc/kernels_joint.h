@@ -18,6 +18,13 @@ enum { LIN_MODE_THETA = 0, LIN_MODE_Z_SCORE = 1, LIN_MODE_Z_REPARAM = 2, LIN_MOD
 #define GRAD_NS 8   // (16 measured: config 3 at step 1 500 281 us against 271, at step 5 54 against 49)
 #define GRAD_NS_NN 16  // DenseNonlinearGaussian: a sample's gradient takes ~0.7 ms of a block -- finer shares balance the CUs better
 #define GRAD_WCH 256  // weights are evaluated in chunks of this many samples (one double-precision exp per thread and chunk)
+// A sample is differentiated when its softmax weight is at least 2^-30.  The oracle (as round 5's kernels) keeps every weight that is
+// non-zero in float32, down to 1e-45; but a term w_s grad_s with w_s < 2^-30 is 64 times below the float32 resolution of the sum it is added to
+// (the weights sum to 1 and the samples' gradients are of one magnitude) -- the reference's own float32 logsumexp loses it the same way -- and
+// late in a run of the LinearGaussian model such samples are the majority of the "weighted" ones: config 3 at step 1 500 has 12.4 samples per
+// particle with a non-zero weight in the theta estimator (worst particle 54) and 4.2 (24) with a weight of at least 2^-30 -- k_lin_grad
+// 271 -> 154 us; config 5 at step 300 keeps 16.2 of 16.7 (the weights of its saturated graphs really are spread): profiles/round6_late_breakdown.txt.
+#define GRAD_W_MIN 9.313225746154785e-10f
 struct GradSplit {
   float* part;         // [jobs][GRAD_NS][stride] partial sums
   unsigned int* ctr;   // [jobs] arrivals (zero between launches: the last block resets it)
@@ -651,7 +658,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
 // at agent scope, as the kernel-matrix tiles do) and runs the epilogue.  The grouping is a function of the weights only -- not of the shard
 // -- so the result does not depend on the rank count; with one non-zero weight block 0 does everything as before and nothing is exchanged.
 // softmax statistics of a particle's S log-probabilities in double (as the oracle: dibs.py:376-382 through logsumexp): maximum, sum of
-// exponentials, sum of the log-probabilities, and the number of samples whose weight is non-zero in float.  `red`: 16 doubles of LDS.
+// exponentials, sum of the log-probabilities, and the number of samples whose weight is at least GRAD_W_MIN.  `red`: 16 doubles of LDS.
 __device__ __forceinline__ void grad_softmax_stats(const float* __restrict__ lp, int S, double* red, double& mx, double& den, double& sm, int& nnz) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   mx = -INFINITY;
@@ -678,7 +685,7 @@ __device__ __forceinline__ void grad_softmax_stats(const float* __restrict__ lp,
   den = red[0] + red[1] + red[2] + red[3];
   sm = red[4] + red[5] + red[6] + red[7];
   double cnt = 0.0;
-  for (int s = tid; s < S; s += 256) cnt += ((float)(exp((double)lp[s] - mx) / den) != 0.f) ? 1.0 : 0.0;
+  for (int s = tid; s < S; s += 256) cnt += ((float)(exp((double)lp[s] - mx) / den) >= GRAD_W_MIN) ? 1.0 : 0.0;
   cnt = wave_sum_d(cnt);
   if (lane == 0) red[8 + wave] = cnt;
   __syncthreads();
@@ -783,7 +790,7 @@ __global__ __launch_bounds__(256) void k_lin_grad(const float* __restrict__ x, c
     __syncthreads();
   for (int s = s0; s < S && s < s0 + GRAD_WCH; ++s) {
     const float w = wch[s - s0];
-    if (w == 0.f) continue;  // block-uniform
+    if (w < GRAD_W_MIN) continue;  // block-uniform
     if ((q++ % NS) != bz) continue;  // (another block's sample)
     if (mode == LIN_MODE_Z_SCORE) {
 #pragma unroll

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
     __syncthreads();
   for (int s = s0; s < S && s < s0 + GRAD_WCH; ++s) {
     const float w = wch[s - s0];
-    if (w == 0.f) continue;  // block-uniform
+    if (w < GRAD_W_MIN) continue;  // block-uniform
     if ((q++ % NS) != bz) continue;  // (another block's sample)
     __syncthreads();
     nn_build_graph(GS, mode, key, nbits, s, thr_m, sc_m, alpha, tau, layout, tiny, d, tid);

@@ -21,9 +21,11 @@ for cp in sorted(set([5, t0])):
         try:
             lp = eng.read("LOGPROBS_Z").reshape(eng.Mloc, -1).astype(np.float64)
             w = np.exp(lp - lp.max(1, keepdims=True)); w /= w.sum(1, keepdims=True)
-            print("   Z-estimator softmax weights: samples with w > 0 in float32 per particle: mean", float((w.astype(np.float32) > 0).sum(1).mean()), "max", int((w.astype(np.float32) > 0).sum(1).max()))
+            print("   Z-estimator softmax weights: samples with w > 0 in float32 per particle: mean", float((w.astype(np.float32) > 0).sum(1).mean()), "max", int((w.astype(np.float32) > 0).sum(1).max()),
+                  "| with w >= 2^-30: mean", float((w >= 2.0 ** -30).sum(1).mean()), "max", int((w >= 2.0 ** -30).sum(1).max()))
             lp = eng.read("LOGPROBS_THETA").reshape(eng.Mloc, -1).astype(np.float64)
             w = np.exp(lp - lp.max(1, keepdims=True)); w /= w.sum(1, keepdims=True)
-            print("   theta-estimator: mean", float((w.astype(np.float32) > 0).sum(1).mean()), "max", int((w.astype(np.float32) > 0).sum(1).max()))
+            print("   theta-estimator: mean", float((w.astype(np.float32) > 0).sum(1).mean()), "max", int((w.astype(np.float32) > 0).sum(1).max()),
+                  "| with w >= 2^-30: mean", float((w >= 2.0 ** -30).sum(1).mean()), "max", int((w >= 2.0 ** -30).sum(1).max()))
         except Exception as ex:
             print("   (no logprobs)", ex)

@@ -21,3 +21,5 @@ for line in open(sys.argv[1]):
         j = json.loads(line); print(sys.argv[1], round(j["value"], 1), "steady", j.get("steady_state", {}).get("value"), "roof", (j.get("roofline") or {}).get("frac"))
 PY
 done
+rm -rf gpurun_out/prof_* gpurun_out/pmc_*   # (raw rocprofv3 output: the summaries above are what is kept; gpurun merges back at most 64 MiB)
+du -sh gpurun_out
