@@ -658,19 +658,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
 // at agent scope, as the kernel-matrix tiles do) and runs the epilogue.  The grouping is a function of the weights only -- not of the shard
 // -- so the result does not depend on the rank count; with one non-zero weight block 0 does everything as before and nothing is exchanged.
 // softmax statistics of a particle's S log-probabilities in double (as the oracle: dibs.py:376-382 through logsumexp): maximum, sum of
-// exponentials, sum of the log-probabilities, and the number of samples whose weight is at least GRAD_W_MIN.  `red`: 16 doubles of LDS.
+// exponentials, sum of the log-probabilities, and the number of samples whose weight is at least GRAD_W_MIN.  `red`: 3 NW doubles of LDS.
+template <int NW = 4>
 __device__ __forceinline__ void grad_softmax_stats(const float* __restrict__ lp, int S, double* red, double& mx, double& den, double& sm, int& nnz) {
+  constexpr int NTHR = 64 * NW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   mx = -INFINITY;
-  for (int s = tid; s < S; s += 256) mx = (double)lp[s] > mx ? (double)lp[s] : mx;
+  for (int s = tid; s < S; s += NTHR) mx = (double)lp[s] > mx ? (double)lp[s] : mx;
   mx = wave_max_d(mx);
   if (lane == 0) red[wave] = mx;
   __syncthreads();
   mx = red[0];
-  for (int w = 1; w < 4; ++w) mx = red[w] > mx ? red[w] : mx;
+  for (int w = 1; w < NW; ++w) mx = red[w] > mx ? red[w] : mx;
   den = 0.0;
   sm = 0.0;
-  for (int s = tid; s < S; s += 256) {
+  for (int s = tid; s < S; s += NTHR) {
     den += exp((double)lp[s] - mx);
     sm += (double)lp[s];
   }
@@ -679,17 +681,23 @@ __device__ __forceinline__ void grad_softmax_stats(const float* __restrict__ lp,
   __syncthreads();
   if (lane == 0) {
     red[wave] = den;
-    red[4 + wave] = sm;
+    red[NW + wave] = sm;
   }
   __syncthreads();
-  den = red[0] + red[1] + red[2] + red[3];
-  sm = red[4] + red[5] + red[6] + red[7];
+  den = 0.0;
+  sm = 0.0;
+  for (int w = 0; w < NW; ++w) {
+    den += red[w];
+    sm += red[NW + w];
+  }
   double cnt = 0.0;
-  for (int s = tid; s < S; s += 256) cnt += ((float)(exp((double)lp[s] - mx) / den) >= GRAD_W_MIN) ? 1.0 : 0.0;
+  for (int s = tid; s < S; s += NTHR) cnt += ((float)(exp((double)lp[s] - mx) / den) >= GRAD_W_MIN) ? 1.0 : 0.0;
   cnt = wave_sum_d(cnt);
-  if (lane == 0) red[8 + wave] = cnt;
+  if (lane == 0) red[2 * NW + wave] = cnt;
   __syncthreads();
-  nnz = (int)(red[8] + red[9] + red[10] + red[11]);
+  cnt = 0.0;
+  for (int w = 0; w < NW; ++w) cnt += red[2 * NW + w];
+  nnz = (int)cnt;
 }
 // the partial sums of this block are complete (stored with grad_part_store): count this block; true for the LAST of `nact` blocks, which
 // then reads all of them with grad_part_load.  `flag`: one int of LDS.

@@ -57,7 +57,7 @@ __host__ __device__ inline int nn_tr_rows(const LinGeom g) { return g.kp > g.np 
 __host__ __device__ inline size_t nn_lds_bytes(int d, int N, int NT, bool grad) {
   const LinGeom g = lin_geom(d, N, NT);
   size_t f = (size_t)g.np * g.ldx + (size_t)d * d + (size_t)nn_tr_rows(g) * g.ldw;
-  if (grad) f += (size_t)4 * g.ldw;
+  if (grad) f += (size_t)8 * g.ldw;  // per-wave column sums of k_nn_grad (up to 8 waves)
   return ((f * 4 + 15) & ~(size_t)15) + 64 * 8;
 }
 // k_nn_logprobs also keeps the small leaves b1 | W2 | b2 ([d][H] | [d][H] | [d]) behind `red`
@@ -151,11 +151,20 @@ __device__ __forceinline__ float nn_build_tw(float* TW, const float* GS, const f
 // the same operand from the re-laid-out weights W1T[h][a][j] (k_nn_prior_table): coalesced -- W1[j][a][h] itself is a 4 d H byte stride between
 // neighbouring j, 64 sectors per wave-load; with thousands of sample gradients per launch (late in a run) those strided reads were the
 // gradient kernel's time
-__device__ __forceinline__ void nn_build_tw_t(float* TW, const float* GS, const float* __restrict__ w1t_h, const LinGeom g, int tid) {
-  for (int e = tid; e < g.kp * g.ldw; e += 256) {
+__device__ __forceinline__ void nn_build_tw_t(float* TW, const float* GS, const float* __restrict__ w1t_h, const LinGeom g, int tid, int nthr) {
+  for (int e = tid; e < g.kp * g.ldw; e += nthr) {
     const int a = e / g.ldw, j = e - a * g.ldw;
     TW[e] = (a < g.d && j < g.d) ? GS[a * g.d + j] * w1t_h[a * g.d + j] : 0.f;
   }
+}
+
+// per-wave column sums [NW][ldw] added in wave order
+template <int NW>
+__device__ __forceinline__ float nn_cs_sum(const float* CS, int ldw, int j) {
+  float t = CS[j];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) t += CS[w * ldw + j];
+  return t;
 }
 
 // The same two steps for k_nn_logprobs with the per-particle tables (prior table LN, re-laid-out weights W1T): element index e = a d + j
@@ -381,8 +390,10 @@ __global__ __launch_bounds__(64 * NW) void k_nn_logprobs(const float* __restrict
 //   mode Z_SCORE   : W = scale * alpha (sum_s w_s G_s - P), off-diagonal           -> w_lik
 // grid = (Mloc, shares), block = 256.  Accumulation goes to global memory; every output element is owned by one thread.
 // ------------------------------------------------------------------------------------------------
-template <int NT, int ACT = -1>   // ACT >= 0: compile-time activation (relu), as in k_nn_logprobs
-__global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, const int32_t* __restrict__ mask,
+// NW waves per block: 8 when the operands leave room for ONE block per CU only (two waves per SIMD hide the barriers and the LDS / L2 waits
+// of the build -> MFMA -> epilogue cycle of every hidden unit; with 4 the CU ran one wave per SIMD), 4 otherwise.
+template <int NT, int ACT = -1, int NW = 4>   // ACT >= 0: compile-time activation (relu), as in k_nn_logprobs
+__global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x, const int32_t* __restrict__ mask,
                                                  const float* __restrict__ theta, size_t P, const float* __restrict__ scores,
                                                  const uint32_t* __restrict__ thr, const float* __restrict__ logprobs,
                                                  float* __restrict__ out, size_t out_stride, float* __restrict__ theta_copy,
@@ -392,13 +403,13 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
                                                  const float* __restrict__ w1t) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const LinGeom g = lin_geom(d, N, NT);
-  constexpr int NU = 2, NUD = (NT + 3) / 4;
+  constexpr int NU = 8 / NW, NUD = (NT + NW - 1) / NW, NTHR = 64 * NW;  // row tiles per wave (np / 16 <= 8), column-of-x tiles per wave
   float* X = smem;
   float* GS = X + (size_t)g.np * g.ldx;
   float* TW = GS + (size_t)d * d;                  // T_h [kp][ldw] (forward operand) ...
   float* RS = TW;                                  // ... and dpre_h [np][ldw] (backward operand), same storage
-  float* CS = TW + (size_t)nn_tr_rows(g) * g.ldw;  // per-wave column sums [4][ldw]
-  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)d * d + (size_t)nn_tr_rows(g) * g.ldw + (size_t)4 * g.ldw) + 3) & ~(size_t)3));
+  float* CS = TW + (size_t)nn_tr_rows(g) * g.ldw;  // per-wave column sums [NW][ldw]
+  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)d * d + (size_t)nn_tr_rows(g) * g.ldw + (size_t)NW * g.ldw) + 3) & ~(size_t)3));
   // grid = (Mloc, shares); block (x, y) takes share y of particle (x + y) mod Mloc.  Workgroups go to the 8 XCDs round-robin by their linear
   // id x + Mloc y: with particle = x every share of particle m ran on XCD m mod 8, and the XCD that held the particles with the most weighted
   // samples set the time (150 of 256 CUs busy, 18 ms instead of 8 at config 5 / step 300); rotated by y, a particle's shares land on all
@@ -417,14 +428,14 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
   __shared__ int last_flag;
   double mx, den, sm;
   int nnz;
-  grad_softmax_stats(lp, S, red, mx, den, sm, nnz);
+  grad_softmax_stats<NW>(lp, S, red, mx, den, sm, nnz);
   const int NS = gridDim.y, bz = blockIdx.y, nact = nnz < NS ? (nnz > 0 ? nnz : 1) : NS;
   if (bz >= nact) return;  // (block-uniform: no share -- before anything is staged)
-  for (int e = tid; e < g.np * g.ldx; e += 256) {
+  for (int e = tid; e < g.np * g.ldx; e += NTHR) {
     const int n = e / g.ldx, c = e - n * g.ldx;
     X[e] = (n < N && c < d) ? x[(size_t)n * d + c] : 0.f;
   }
-  for (int e = tid; e < 4 * g.ldw; e += 256) CS[e] = 0.f;
+  for (int e = tid; e < NW * g.ldw; e += NTHR) CS[e] = 0.f;
   // the accumulation row: the output itself while one block does everything, else this block's partial sums
   // outputs start at zero (theta mode: P entries; z modes: d*d)
   // Several blocks (split): the theta estimator's first-layer gradient -- d*d*H values that every sample updates -- is accumulated in THREAD
@@ -433,14 +444,14 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
   // the small leaves follow behind it in theta's layout.  The Z modes accumulate d*d values in W's layout (16 consecutive floats per row).
   const bool split = nact > 1;
   const size_t n_out = mode == LIN_MODE_THETA ? P : dd;
-  const size_t w1sz = (size_t)H * NUD * NT * 4 * 256;  // thread-layout area of the first-layer gradient
+  const size_t w1sz = (size_t)H * NUD * NT * 4 * NTHR;  // thread-layout area of the first-layer gradient
   float* const prow = split ? gs.part + ((size_t)m * NS + bz) * gs.stride : nullptr;
   // `om`: where the values in theta's / W's layout accumulate (split + theta mode: only the small leaves, behind the thread-layout area)
   float* const om = !split ? om_final : (mode == LIN_MODE_THETA ? prow + w1sz - off.b1 : prow);
   if (split && mode == LIN_MODE_THETA) {
-    for (size_t e = tid; e < w1sz + (P - off.b1); e += 256) prow[e] = 0.f;
+    for (size_t e = tid; e < w1sz + (P - off.b1); e += NTHR) prow[e] = 0.f;
   } else {
-    for (size_t e = tid; e < n_out; e += 256) om[e] = 0.f;
+    for (size_t e = tid; e < n_out; e += NTHR) om[e] = 0.f;
   }
   const float inv_on = 1.0f / np_.obs_noise;
   const float inv_sp2 = 1.0f / (np_.sig_param * np_.sig_param);
@@ -451,17 +462,17 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
   int q = 0;  // ordinal of the next sample with a non-zero weight
   for (int s0 = 0; s0 < S; s0 += GRAD_WCH) {
     __syncthreads();
-    if (s0 + tid < S) wch[tid] = (float)(exp((double)lp[s0 + tid] - mx) / den);
+    if (tid < GRAD_WCH && s0 + tid < S) wch[tid] = (float)(exp((double)lp[s0 + tid] - mx) / den);
     __syncthreads();
   for (int s = s0; s < S && s < s0 + GRAD_WCH; ++s) {
     const float w = wch[s - s0];
     if (w < GRAD_W_MIN) continue;  // block-uniform
     if ((q++ % NS) != bz) continue;  // (another block's sample)
     __syncthreads();
-    nn_build_graph(GS, mode, key, nbits, s, thr_m, sc_m, alpha, tau, layout, tiny, d, tid);
+    nn_build_graph(GS, mode, key, nbits, s, thr_m, sc_m, alpha, tau, layout, tiny, d, tid, nullptr, NTHR);
     __syncthreads();
     if (mode == LIN_MODE_Z_SCORE) {
-      for (int e = tid; e < (int)dd; e += 256) om[e] += w * GS[e];
+      for (int e = tid; e < (int)dd; e += NTHR) om[e] += w * GS[e];
       continue;
     }
     // ---- forward: mean ----
@@ -472,17 +483,17 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
       for (int tj = 0; tj < NT; ++tj) macc[u][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int h = 0; h < H; ++h) {
       __syncthreads();
-      if (w1t) nn_build_tw_t(TW, GS, w1t + ((size_t)m * H + h) * dd, g, tid);
-      else nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid);
+      if (w1t) nn_build_tw_t(TW, GS, w1t + ((size_t)m * H + h) * dd, g, tid, NTHR);
+      else nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid, NTHR);
       __syncthreads();
       f32x4 acc[NU][NT];
-      nn_gemm_x_tw<NT, NU>(X, TW, g, lane, wave, acc);
+      nn_gemm_x_tw<NT, NU, NW>(X, TW, g, lane, wave, acc);
 #pragma unroll
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj) {
           const int j = tj * 16 + (lane & 15);
-          if (j < d && wave + 4 * u < nrt) {
+          if (j < d && wave + NW * u < nrt) {
             const float b1 = np_.bias ? th_m[off.b1 + (size_t)j * H + h] : 0.f;
             const float w2 = th_m[off.w2 + (size_t)j * H + h];
 #pragma unroll
@@ -498,9 +509,9 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int n = (wave + 4 * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
+          const int n = (wave + NW * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
           float dm = 0.f;
-          if (n < N && j < d && wave + 4 * u < nrt && !(any_mask && mask[(size_t)n * d + j]))
+          if (n < N && j < d && wave + NW * u < nrt && !(any_mask && mask[(size_t)n * d + j]))
             dm = (X[n * g.ldx + j] - macc[u][tj][r] - (np_.bias ? th_m[off.b2 + j] : 0.f)) * inv_on;
           macc[u][tj][r] = dm;
           t += dm;
@@ -511,16 +522,16 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
     }
     __syncthreads();
     if (mode == LIN_MODE_THETA && np_.bias)
-      for (int j = tid; j < d; j += 256)  // d/db2_j = sum_n dmean_nj
-        om[off.b2 + j] += w * (CS[j] + CS[g.ldw + j] + CS[2 * g.ldw + j] + CS[3 * g.ldw + j]);
+      for (int j = tid; j < d; j += NTHR)  // d/db2_j = sum_n dmean_nj
+        om[off.b2 + j] += w * nn_cs_sum<NW>(CS, g.ldw, j);
     // ---- backward, one hidden unit at a time ----
     for (int h = 0; h < H; ++h) {
       __syncthreads();
-      if (w1t) nn_build_tw_t(TW, GS, w1t + ((size_t)m * H + h) * dd, g, tid);
-      else nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid);
+      if (w1t) nn_build_tw_t(TW, GS, w1t + ((size_t)m * H + h) * dd, g, tid, NTHR);
+      else nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid, NTHR);
       __syncthreads();
       f32x4 acc[NU][NT];
-      nn_gemm_x_tw<NT, NU>(X, TW, g, lane, wave, acc);
+      nn_gemm_x_tw<NT, NU, NW>(X, TW, g, lane, wave, acc);
       __syncthreads();  // every wave is done reading T_h: its storage now takes dpre_h
 #pragma unroll
       for (int tj = 0; tj < NT; ++tj) {
@@ -532,8 +543,8 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
         for (int u = 0; u < NU; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int n = (wave + 4 * u) * 16 + (lane >> 4) * 4 + r;
-            if (n < g.np && wave + 4 * u < nrt) {
+            const int n = (wave + NW * u) * 16 + (lane >> 4) * 4 + r;
+            if (n < g.np && wave + NW * u < nrt) {
               const float pre = acc[u][tj][r] + b1;
               const float hv = nn_act(ACT >= 0 ? ACT : np_.act, pre);
               const float dm = macc[u][tj][r];
@@ -547,16 +558,16 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
       }
       __syncthreads();
       if (mode == LIN_MODE_THETA)
-        for (int j = tid; j < d; j += 256) {
+        for (int j = tid; j < d; j += NTHR) {
           float t1 = 0.f;
           for (int n = 0; n < N; ++n) t1 += RS[n * g.ldw + j];
           if (np_.bias) om[off.b1 + (size_t)j * H + h] += w * t1;
-          om[off.w2 + (size_t)j * H + h] += w * (CS[j] + CS[g.ldw + j] + CS[2 * g.ldw + j] + CS[3 * g.ldw + j]);
+          om[off.w2 + (size_t)j * H + h] += w * nn_cs_sum<NW>(CS, g.ldw, j);
         }
       // xtr[a][j] = sum_n x[n][a] dpre[n][j]  (d/dT_h)
 #pragma unroll
       for (int u = 0; u < NUD; ++u) {
-        const int ti = wave + 4 * u;
+        const int ti = wave + NW * u;
         if (ti >= NT) continue;  // (not `break`: keeps the trip count constant so the loop unrolls)
         f32x4 t[NT];
 #pragma unroll
@@ -580,7 +591,7 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
               const float w1 = w1t ? w1t[((size_t)m * H + h) * dd + (size_t)a * d + j] : th_m[((size_t)j * d + a) * H + h];
               if (mode == LIN_MODE_THETA) {
                 const float v = w * gv * (xtr - w1 * inv_sp2);
-                if (split) prow[(size_t)(((h * NUD + u) * NT + tj) * 4 + r) * 256 + tid] += v;
+                if (split) prow[(size_t)(((h * NUD + u) * NT + tj) * 4 + r) * NTHR + tid] += v;
                 else om[((size_t)j * d + a) * H + h] += v;
               } else if (a != j) {
                 om[a * d + j] += w * (lin_logn(w1, 0.f, np_.sig_param) + w1 * xtr) * tau * alpha * gv * (1.0f - gv);
@@ -603,7 +614,7 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
       for (int h = 0; h < H; ++h)
 #pragma unroll
         for (int u = 0; u < NUD; ++u) {
-          const int ti = wave + 4 * u;
+          const int ti = wave + NW * u;
           if (ti >= NT) continue;
 #pragma unroll
           for (int tj = 0; tj < NT; ++tj)
@@ -611,15 +622,15 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
             for (int r = 0; r < 4; ++r) {
               const int a = ti * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
               if (a < d && j < d) {
-                const size_t slot = (size_t)(((h * NUD + u) * NT + tj) * 4 + r) * 256 + tid;
+                const size_t slot = (size_t)(((h * NUD + u) * NT + tj) * 4 + r) * NTHR + tid;
                 om_final[((size_t)j * d + a) * H + h] = grad_part_sum<GRAD_NS_NN, false>(base, gs.stride, slot, nact);
               }
             }
         }
-      for (size_t e = off.b1 + tid; e < P; e += 256)  // the small leaves
+      for (size_t e = off.b1 + tid; e < P; e += NTHR)  // the small leaves
         om_final[e] = grad_part_sum<GRAD_NS_NN, false>(base, gs.stride, w1sz + (e - off.b1), nact);
     } else {
-      for (size_t e = tid; e < n_out; e += 256) om_final[e] = grad_part_sum<GRAD_NS_NN, false>(base, gs.stride, e, nact);
+      for (size_t e = tid; e < n_out; e += NTHR) om_final[e] = grad_part_sum<GRAD_NS_NN, false>(base, gs.stride, e, nact);
     }
     __syncthreads();
   }
@@ -627,12 +638,12 @@ __global__ __launch_bounds__(256) void k_nn_grad(const float* __restrict__ x, co
   const float bold = baseline ? baseline[m] : 0.f;
   if (mode == LIN_MODE_THETA) {
     // graph-independent prior gradient of the remaining leaves: -theta / sig_p^2 (the softmax weights sum to 1)
-    for (size_t e = off.b1 + tid; e < off.P; e += 256) om_final[e] += -th_m[e] * inv_sp2;
+    for (size_t e = off.b1 + tid; e < off.P; e += NTHR) om_final[e] += -th_m[e] * inv_sp2;
     if (theta_copy)
-      for (size_t e = tid; e < P; e += 256) theta_copy[(size_t)m * out_stride + e] = th_m[e];
+      for (size_t e = tid; e < P; e += NTHR) theta_copy[(size_t)m * out_stride + e] = th_m[e];
   } else if (mode == LIN_MODE_Z_SCORE) {
     const float scale = sf_baseline > 0.0 ? (float)exp(-(double)bold) : 1.0f;
-    for (int e = tid; e < (int)dd; e += 256) {
+    for (int e = tid; e < (int)dd; e += NTHR) {
       const int i = e / d, j = e - i * d;
       const float p = (float)sigmoid_d((double)__fmul_rn(alpha, sc_m[e]));
       om_final[e] = i == j ? 0.f : scale * alpha * (om_final[e] - p);
@@ -798,10 +809,6 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
   // four rounds of blocks (config 5: spb 2 / 4 / 8 -> 51.2 / 53.0 / 53.1 steps/s)
   const int spb = (jl.S / 4) * jl.Mloc >= 1024 ? 4 : 2;
   const size_t lds1 = nn_lds_bytes_logprobs(jl.d, jl.N, NT, np_.H), lds2 = nn_lds_bytes(jl.d, jl.N, NT, true);
-  if (lds2 > 48 * 1024) {
-    hipFuncSetAttribute((const void*)k_nn_grad<NT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    hipFuncSetAttribute((const void*)k_nn_grad<NT, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-  }
   float* lp = mode == LIN_MODE_THETA ? jl.logprobs_th : jl.logprobs_z;
   const size_t w1t_need = (size_t)jl.Mloc * np_.H * jl.d * jl.d;
   if (w->w1t_floats < w1t_need) {  // (first launch; optional: without it the kernel reads W1 in place)
@@ -834,20 +841,27 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
   GradSplit gs;  // (several blocks per particle once many samples keep a non-zero weight: kernels_joint.h; the row is P floats for theta, d*d for Z)
   // (partial row of a block: the first-layer gradient in thread layout + the small leaves for theta, d*d for Z; the shares per particle are
   //  cut back when GRAD_NS_NN rows per particle would exceed 4 GiB -- hidden widths in the dozens)
-  const size_t row_theta = (size_t)np_.H * ((NT + 3) / 4) * NT * 4 * 256 + (P - (size_t)jl.d * jl.d * np_.H);
+  const bool wide = lds2 > 80 * 1024;  // one block per CU: 8 waves (see k_nn_grad)
+  const int nthr = wide ? 512 : 256, nud = wide ? (NT + 7) / 8 : (NT + 3) / 4;
+  const size_t row_theta = (size_t)np_.H * nud * NT * 4 * nthr + (P - (size_t)jl.d * jl.d * np_.H);
   const size_t row = row_theta > (size_t)jl.d * jl.d ? row_theta : (size_t)jl.d * jl.d;
   int ns_nn = GRAD_NS_NN;
   while (ns_nn > 1 && (size_t)jl.Mloc * ns_nn * row * 4 > ((size_t)4 << 30)) ns_nn >>= 1;
   if (!joint_grad_split(w, (size_t)jl.Mloc, row, &gs, ns_nn)) return;  // (the step's launch check reports the failed hipMalloc)
-  if (np_.act == 0) {
-    hipLaunchKernelGGL((k_nn_grad<NT, 0>), dim3(jl.Mloc, ns_nn), dim3(256), lds2, jl.stream, w->x, w->mask, jl.theta, P, jl.scores, jl.thr, lp, out,
-                     ostride, tcopy, jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode, jl.m0,
-                     jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask, gs, w->ln_tab ? w->w1t : nullptr);
-  } else {
-    hipLaunchKernelGGL((k_nn_grad<NT, -1>), dim3(jl.Mloc, ns_nn), dim3(256), lds2, jl.stream, w->x, w->mask, jl.theta, P, jl.scores, jl.thr, lp, out,
-                     ostride, tcopy, jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode, jl.m0,
-                     jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask, gs, w->ln_tab ? w->w1t : nullptr);
+#define NN_GRAD_LAUNCH(ACT_, NW_)                                                                                                              \
+  {                                                                                                                                            \
+    if (lds2 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_grad<NT, ACT_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);   \
+    hipLaunchKernelGGL((k_nn_grad<NT, ACT_, NW_>), dim3(jl.Mloc, ns_nn), dim3(64 * NW_), lds2, jl.stream, w->x, w->mask, jl.theta, P, jl.scores,  \
+                       jl.thr, lp, out, ostride, tcopy, jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode,    \
+                       jl.m0, jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask, gs,                \
+                       w->ln_tab ? w->w1t : nullptr);                                                                                         \
   }
+  if (wide) {
+    if (np_.act == 0) NN_GRAD_LAUNCH(0, 8) else NN_GRAD_LAUNCH(-1, 8)
+  } else {
+    if (np_.act == 0) NN_GRAD_LAUNCH(0, 4) else NN_GRAD_LAUNCH(-1, 4)
+  }
+#undef NN_GRAD_LAUNCH
 }
 
 bool joint_nn_fast_path(int d, int N, const NNParams& np_) {
