@@ -1157,15 +1157,17 @@ void joint_lin_all_grads(JointWork* w, const JointLaunch& jl, Key2 carry_theta, 
     const bool glob = ling_ops_global(jl.d, true);
     const int ng = glob ? (w->n_gram == 1 ? -1 : w->n_gram) : ling_ngram_arg(jl.d, w->n_gram, true);
     const size_t lds = glob ? 256 : ling_lds(jl.d, ng, true);
-    float* gs = glob ? joint_gs_scratch(w, (size_t)2 * jl.Mloc * 2 * jl.d * jl.d) : nullptr;
+    float* gs = glob ? joint_gs_scratch(w, (size_t)GRAD_NS * 2 * jl.Mloc * 2 * jl.d * jl.d) : nullptr;
     if (glob && !gs) return;
+    GradSplit gsp;
+    if (!joint_grad_split(w, (size_t)jl.Mloc * 2, (size_t)jl.d * jl.d, &gsp)) return;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_ling_grad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const LinGradJob jt{jl.logprobs_th, jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off, jl.pack_stride,
                         jl.copy_theta ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr, nullptr, carry_theta, LIN_MODE_THETA};
     const LinGradJob jz{jl.logprobs_z, jl.w_lik, (size_t)jl.d * jl.d, nullptr, jl.baseline_out, carry_z,
                         jl.est_z == 0 ? LIN_MODE_Z_SCORE : LIN_MODE_Z_REPARAM};
-    hipLaunchKernelGGL(k_ling_grad, dim3(jl.Mloc, 2), dim3(256), lds, jl.stream, w->gram, ng, jl.theta, jl.scores, jl.thr, jt, jz, jl.baseline,
-                       jl.m0, jl.M, jl.d, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise, jl.mean_edge, jl.sig_edge, jl.sf_baseline, gs);
+    hipLaunchKernelGGL(k_ling_grad, dim3(jl.Mloc, 2, GRAD_NS), dim3(256), lds, jl.stream, w->gram, ng, jl.theta, jl.scores, jl.thr, jt, jz, jl.baseline,
+                       jl.m0, jl.M, jl.d, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, jl.obs_noise, jl.mean_edge, jl.sig_edge, jl.sf_baseline, gs, gsp);
     return;
   }
 #define LIN_CALL(NT_) joint_lin_grads<NT_>(w, jl, carry_theta, carry_z)

@@ -81,61 +81,56 @@ __global__ __launch_bounds__(256) void k_ling_logprobs(const double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// softmax-weighted gradients, same contract (LinGradJob, blockIdx.y selects the job) as k_lin_grad.  grid = (Mloc, 2), block = 256
-// Accumulation goes to the output row in global memory; every element is owned by one thread.
+// softmax-weighted gradients, same contract (LinGradJob, blockIdx.y selects the job) as k_lin_grad, same sharing of a particle's weighted
+// samples between blocks (GradSplit, kernels_joint.h).  grid = (Mloc, 2, shares), block = 256; block (x, y, z) takes share z of particle
+// (x + z) mod Mloc.  Accumulation goes to a row in global memory -- the output itself while one block does everything, else the block's
+// partial row -- and every element is owned by one thread.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ling_grad(const double* __restrict__ gram, int n_gram, const float* __restrict__ theta,
                                                    const float* __restrict__ scores, const uint32_t* __restrict__ thr, LinGradJob job0,
                                                    LinGradJob job1, const float* __restrict__ baseline, int m0, int M_global, int d, int S,
                                                    float alpha, float tau, int layout, int tiny, float obs_noise, float mu, float sig,
-                                                   double sf_baseline, float* __restrict__ ops_glob) {
+                                                   double sf_baseline, float* __restrict__ ops_glob, GradSplit gs) {
   const LinGradJob job = blockIdx.y ? job1 : job0;
   const int mode = job.mode;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* Cs = reinterpret_cast<double*>(smem_raw);
   const size_t dd = (size_t)d * d;
   // (ops_glob != null, n_vars > 141: masked weights and graph of this block in global scratch [gridDim.y][gridDim.x][2][d*d], see k_ling_logprobs)
-  float* WG = ops_glob ? ops_glob + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * dd : reinterpret_cast<float*>(smem_raw + (n_gram == 1 ? dd * 8 : 0));
+  float* WG = ops_glob ? ops_glob + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 2 * dd
+                       : reinterpret_cast<float*>(smem_raw + (n_gram == 1 ? dd * 8 : 0));
   float* GS = WG + dd;
   double* red = ops_glob ? reinterpret_cast<double*>(smem_raw)
                          : reinterpret_cast<double*>(smem_raw + (n_gram == 1 ? dd * 8 : 0) + ((2 * dd * 4 + 15) & ~(size_t)15));
-  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = (int)((blockIdx.x + blockIdx.z) % gridDim.x), tid = threadIdx.x;
   const float* TH = theta + (size_t)m * dd;
-  float* om = job.out + (size_t)m * job.out_stride;
-  if (n_gram == 1)
-    for (int e = tid; e < (int)dd; e += 256) Cs[e] = gram[e];
-  for (int e = tid; e < (int)dd; e += 256) om[e] = 0.f;
+  float* const om_final = job.out + (size_t)m * job.out_stride;
   const Key2 key = lin_mode_key(mode, job.carry, M_global, m0 + m, layout);
   const uint64_t nbits = (uint64_t)S * dd;
   const float* lp = job.logprobs + (size_t)m * S;
-  double mx = -INFINITY;
-  for (int s = tid; s < S; s += 256) mx = (double)lp[s] > mx ? (double)lp[s] : mx;
-  mx = wave_max_d(mx);
-  if (lane == 0) red[wave] = mx;
-  __syncthreads();
-  mx = red[0];
-  for (int w = 1; w < 4; ++w) mx = red[w] > mx ? red[w] : mx;
-  double den = 0.0, sm = 0.0;
-  for (int s = tid; s < S; s += 256) {
-    den += exp((double)lp[s] - mx);
-    sm += (double)lp[s];
-  }
-  den = wave_sum_d(den);
-  sm = wave_sum_d(sm);
-  __syncthreads();
-  if (lane == 0) {
-    red[wave] = den;
-    red[4 + wave] = sm;
-  }
-  __syncthreads();
-  den = red[0] + red[1] + red[2] + red[3];
-  sm = red[4] + red[5] + red[6] + red[7];
+  __shared__ float wch[GRAD_WCH];
+  __shared__ int last_flag;
+  double mx, den, sm;
+  int nnz;
+  grad_softmax_stats(lp, S, red, mx, den, sm, nnz);
+  const int bz = blockIdx.z, NS = gridDim.z, nact = nnz < NS ? (nnz > 0 ? nnz : 1) : NS;
+  if (bz >= nact) return;  // (block-uniform: no share)
+  float* const om = nact > 1 ? gs.part + ((size_t)(m * 2 + (int)blockIdx.y) * NS + bz) * gs.stride : om_final;
+  if (n_gram == 1)
+    for (int e = tid; e < (int)dd; e += 256) Cs[e] = gram[e];
+  for (int e = tid; e < (int)dd; e += 256) om[e] = 0.f;
   const double inv_on = 1.0 / (double)obs_noise;
   const float* sc_m = scores + (size_t)m * dd;
   const uint32_t* thr_m = thr + (size_t)m * dd;
-  for (int s = 0; s < S; ++s) {
-    const float w = (float)(exp((double)lp[s] - mx) / den);
-    if (w == 0.f) continue;  // block-uniform
+  int q = 0;  // ordinal of the next weighted sample
+  for (int s0 = 0; s0 < S; s0 += GRAD_WCH) {
+    __syncthreads();
+    if (s0 + tid < S) wch[tid] = (float)(exp((double)lp[s0 + tid] - mx) / den);
+    __syncthreads();
+  for (int s = s0; s < S && s < s0 + GRAD_WCH; ++s) {
+    const float w = wch[s - s0];
+    if (w < GRAD_W_MIN) continue;  // block-uniform
+    if ((q++ % NS) != bz) continue;  // (another block's sample)
     __syncthreads();
     for (int e = tid; e < (int)dd; e += 256) {
       const int a = e / d, j = e - a * d;
@@ -166,14 +161,23 @@ __global__ __launch_bounds__(256) void k_ling_grad(const double* __restrict__ gr
       }
     });
   }
+  }
   __syncthreads();
+  if (nact > 1) {  // (plain read-modify-writes above: release, count this block; the last one adds the rows in block order)
+    __threadfence();
+    if (!grad_last_block(gs.ctr + (m * 2 + (int)blockIdx.y), nact, &last_flag)) return;
+    __threadfence();
+    const float* const base = gs.part + (size_t)(m * 2 + (int)blockIdx.y) * NS * gs.stride;
+    for (int e = tid; e < (int)dd; e += 256) om_final[e] = grad_part_sum<GRAD_NS, false>(base, gs.stride, (size_t)e, nact);
+    __syncthreads();
+  }
   const float bold = baseline ? baseline[m] : 0.f;
   if (mode == LIN_MODE_Z_SCORE) {
     const float scale = sf_baseline > 0.0 ? (float)exp(-(double)bold) : 1.0f;
     for (int e = tid; e < (int)dd; e += 256) {
       const int i = e / d, j = e - i * d;
       const float p = (float)sigmoid_d((double)__fmul_rn(alpha, sc_m[e]));
-      om[e] = i == j ? 0.f : scale * alpha * (om[e] - p);
+      om_final[e] = i == j ? 0.f : scale * alpha * (om_final[e] - p);
     }
   }
   if (job.theta_copy)
