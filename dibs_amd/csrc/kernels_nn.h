@@ -887,15 +887,23 @@ static int joint_nng_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
   const NNNet net = nn_net(jl.d, np_);
   size_t lds = (((size_t)jl.d * jl.d + 3) & ~(size_t)3) * 4 + 128;
   const int nb = nng_blocks((long)jl.S * jl.Mloc);
-  const size_t need1 = (size_t)nb * 256 * net.hsum, need2 = (size_t)jl.Mloc * 2 * net.hsum * jl.d * jl.N;
+  // shares per particle of the gradient kernel (GradSplit): as many as keep its per-block activation records within 2 GiB and its partial
+  // rows within 2 GiB
+  int ns_g = GRAD_NS;
+  const size_t rec = (size_t)2 * net.hsum * jl.d * jl.N, row = (size_t)net.P > (size_t)jl.d * jl.d ? (size_t)net.P : (size_t)jl.d * jl.d;
+  while (ns_g > 1 && ((size_t)jl.Mloc * ns_g * rec * 4 > ((size_t)2 << 30) || (size_t)jl.Mloc * ns_g * row * 4 > ((size_t)2 << 30))) ns_g >>= 1;
+  const size_t need1 = (size_t)nb * 256 * net.hsum, need2 = (size_t)jl.Mloc * ns_g * rec;
   float* scr = nng_scratch(w, need1 > need2 ? need1 : need2);
   if (!scr) return 1;
   float* gs = nullptr;  // (n_vars > 198: the sampled graph of a block does not fit LDS -- global scratch)
   if (lds > (size_t)160 * 1024 - 1024) {
-    gs = joint_gs_scratch(w, (size_t)(nb > jl.Mloc ? nb : jl.Mloc) * jl.d * jl.d);
+    const size_t nblk = (size_t)jl.Mloc * ns_g;
+    gs = joint_gs_scratch(w, ((size_t)nb > nblk ? (size_t)nb : nblk) * jl.d * jl.d);
     if (!gs) return 1;
     lds = 256;
   }
+  GradSplit gsp;
+  if (!joint_grad_split(w, (size_t)jl.Mloc, row, &gsp, ns_g)) return 1;
   float* lp = mode == LIN_MODE_THETA ? jl.logprobs_th : jl.logprobs_z;
   if (lds > 48 * 1024) {
     hipFuncSetAttribute((const void*)k_nng_logprobs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -906,9 +914,9 @@ static int joint_nng_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
   float* out = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off : jl.w_lik;
   const size_t ostride = mode == LIN_MODE_THETA ? jl.pack_stride : (size_t)jl.d * jl.d;
   float* tcopy = (mode == LIN_MODE_THETA && jl.copy_theta) ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr;
-  hipLaunchKernelGGL(k_nng_grad, dim3(jl.Mloc), dim3(256), lds, jl.stream, w->x, w->mask, jl.theta, jl.scores, jl.thr, lp, out, ostride, tcopy,
+  hipLaunchKernelGGL(k_nng_grad, dim3(jl.Mloc, ns_g), dim3(256), lds, jl.stream, w->x, w->mask, jl.theta, jl.scores, jl.thr, lp, out, ostride, tcopy,
                      jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode, jl.m0, jl.M, jl.d, jl.N, jl.S,
-                     jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask, scr, gs);
+                     jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask, scr, gs, gsp);
   return 0;
 }
 

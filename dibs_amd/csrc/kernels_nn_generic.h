@@ -146,8 +146,9 @@ __global__ __launch_bounds__(256) void k_nng_logprobs(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// softmax-weighted gradients, same contract as k_nn_grad (kernels_nn.h).  grid = Mloc, block = 256
-// dynamic LDS = d * d * 4 + 128;  scratch: Mloc * 2 * hsum * d * N floats (activations | pre-activation gradients)
+// softmax-weighted gradients, same contract as k_nn_grad (kernels_nn.h) and the same sharing of a particle's weighted samples between blocks
+// (GradSplit, kernels_joint.h).  grid = (Mloc, shares), block = 256; block (x, y) takes share y of particle (x + y) mod Mloc
+// dynamic LDS = d * d * 4 + 128;  scratch: Mloc * shares * 2 * hsum * d * N floats (activations | pre-activation gradients, per block)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_nng_grad(const float* __restrict__ x, const int32_t* __restrict__ mask,
                                                   const float* __restrict__ theta, const float* __restrict__ scores,
@@ -156,51 +157,44 @@ __global__ __launch_bounds__(256) void k_nng_grad(const float* __restrict__ x, c
                                                   const float* __restrict__ baseline, float* __restrict__ baseline_out, Key2 carry, int mode,
                                                   int m0, int M_global, int d, int N, int S, float alpha, float tau, int layout, int tiny,
                                                   NNParams np_, double sf_baseline, int any_mask, float* __restrict__ scratch,
-                                                  float* __restrict__ gs_glob) {
+                                                  float* __restrict__ gs_glob, GradSplit gs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* GS = gs_glob ? gs_glob + (size_t)blockIdx.x * d * d : smem;  // (see k_nng_logprobs)
+  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  float* GS = gs_glob ? gs_glob + blk * d * d : smem;  // (see k_nng_logprobs)
   double* red = reinterpret_cast<double*>(gs_glob ? smem : smem + (((size_t)d * d + 3) & ~(size_t)3));
   const NNNet net = nn_net(d, np_);
-  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = (int)((blockIdx.x + blockIdx.y) % gridDim.x), tid = threadIdx.x;
   const size_t dd = (size_t)d * d, NI = (size_t)d * N;
   const float* th_m = theta + (size_t)m * net.P;
-  float* om = out + (size_t)m * out_stride;
-  float* ACT = scratch + (size_t)m * 2 * net.hsum * NI;  // [hsum][NI] layer outputs
+  float* const om_final = out + (size_t)m * out_stride;
+  float* ACT = scratch + blk * 2 * net.hsum * NI;        // [hsum][NI] layer outputs (this block's)
   float* DPR = ACT + (size_t)net.hsum * NI;              // [hsum][NI] d log p / d pre-activation
   const size_t n_out = mode == LIN_MODE_THETA ? (size_t)net.P : dd;
-  for (size_t e = tid; e < n_out; e += 256) om[e] = 0.f;
   const Key2 key = lin_mode_key(mode, carry, M_global, m0 + m, layout);
   const uint64_t nbits = (uint64_t)S * dd;
   const float* lp = logprobs + (size_t)m * S;
-  double mx = -INFINITY;
-  for (int s = tid; s < S; s += 256) mx = (double)lp[s] > mx ? (double)lp[s] : mx;
-  mx = wave_max_d(mx);
-  if (lane == 0) red[wave] = mx;
-  __syncthreads();
-  mx = red[0];
-  for (int w = 1; w < 4; ++w) mx = red[w] > mx ? red[w] : mx;
-  double den = 0.0, sm = 0.0;
-  for (int s = tid; s < S; s += 256) {
-    den += exp((double)lp[s] - mx);
-    sm += (double)lp[s];
-  }
-  den = wave_sum_d(den);
-  sm = wave_sum_d(sm);
-  __syncthreads();
-  if (lane == 0) {
-    red[wave] = den;
-    red[4 + wave] = sm;
-  }
-  __syncthreads();
-  den = red[0] + red[1] + red[2] + red[3];
-  sm = red[4] + red[5] + red[6] + red[7];
+  __shared__ float wch[GRAD_WCH];
+  __shared__ int last_flag;
+  double mx, den, sm;
+  int nnz;
+  grad_softmax_stats(lp, S, red, mx, den, sm, nnz);
+  const int bz = blockIdx.y, NS = gridDim.y, nact = nnz < NS ? (nnz > 0 ? nnz : 1) : NS;
+  if (bz >= nact) return;  // (block-uniform: no share)
+  float* const om = nact > 1 ? gs.part + ((size_t)m * NS + bz) * gs.stride : om_final;
+  for (size_t e = tid; e < n_out; e += 256) om[e] = 0.f;
   const float inv_on = 1.0f / np_.obs_noise, inv_sp2 = 1.0f / (np_.sig_param * np_.sig_param);
   const float* sc_m = scores + (size_t)m * dd;
   const uint32_t* thr_m = thr + (size_t)m * dd;
 
-  for (int s = 0; s < S; ++s) {
-    const float w = (float)(exp((double)lp[s] - mx) / den);
-    if (w == 0.f) continue;  // block-uniform
+  int q = 0;  // ordinal of the next weighted sample
+  for (int s0 = 0; s0 < S; s0 += GRAD_WCH) {
+    __syncthreads();
+    if (s0 + tid < S) wch[tid] = (float)(exp((double)lp[s0 + tid] - mx) / den);
+    __syncthreads();
+  for (int s = s0; s < S && s < s0 + GRAD_WCH; ++s) {
+    const float w = wch[s - s0];
+    if (w < GRAD_W_MIN) continue;  // block-uniform
+    if ((q++ % NS) != bz) continue;  // (another block's sample)
     __syncthreads();
     for (int e = tid; e < (int)dd; e += 256) {
       const int a = e / d, j = e - a * d;
@@ -281,11 +275,20 @@ __global__ __launch_bounds__(256) void k_nng_grad(const float* __restrict__ x, c
       }
     }
   }
+  }
   __syncthreads();
+  if (nact > 1) {  // (plain read-modify-writes above: release, count this block; the last one adds the rows in block order)
+    __threadfence();
+    if (!grad_last_block(gs.ctr + m, nact, &last_flag)) return;
+    __threadfence();
+    const float* const base = gs.part + (size_t)m * NS * gs.stride;
+    for (size_t e = tid; e < n_out; e += 256) om_final[e] = grad_part_sum<GRAD_NS, false>(base, gs.stride, e, nact);
+    __syncthreads();
+  }
   const float bold = baseline ? baseline[m] : 0.f;
   if (mode == LIN_MODE_THETA) {
     // graph-independent prior gradient of the leaves behind the first-layer weights: -theta / sig_p^2 (the weights sum to 1)
-    for (long e = net.boff[0] + tid; e < net.P; e += 256) om[e] += -th_m[e] * inv_sp2;  // (boff[0] = end of the first-layer weights)
+    for (long e = net.boff[0] + tid; e < net.P; e += 256) om_final[e] += -th_m[e] * inv_sp2;  // (boff[0] = end of the first-layer weights)
     if (theta_copy)
       for (long e = tid; e < net.P; e += 256) theta_copy[(size_t)m * out_stride + e] = th_m[e];
   } else if (mode == LIN_MODE_Z_SCORE) {
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256) void k_nng_grad(const float* __restrict__ x, c
     for (int e = tid; e < (int)dd; e += 256) {
       const int i = e / d, j = e - i * d;
       const float p = (float)sigmoid_d((double)__fmul_rn(alpha, sc_m[e]));
-      om[e] = i == j ? 0.f : scale * alpha * (om[e] - p);
+      om_final[e] = i == j ? 0.f : scale * alpha * (om_final[e] - p);
     }
   }
   if (mode != LIN_MODE_THETA && baseline_out && tid == 0)

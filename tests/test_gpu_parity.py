@@ -479,6 +479,8 @@ def _lingauss_step_stages(c_oracle64, d, M, S, Sa, est, prior, interv, steps):
     ("densenn", 100, 2, 12, "reparam", 1e4),
     ("lingauss-gram", 20, 3, 64, "reparam", 1e4),   # the Gram-matrix path (k_ling_grad) shares the samples the same way
     ("lingauss-gram", 50, 2, 40, "score", 1e4),
+    ("densenn-deep", 12, 3, 40, "reparam", 1e4),    # two hidden layers: the general-stack kernels (k_nng_grad)
+    ("densenn-deep", 20, 2, 24, "score", 1e4),
 ])
 def test_joint_gradients_with_many_weighted_samples(c_oracle64, monkeypatch, model, d, M, S, est, noise):
     """Late in a run many samples keep a non-zero softmax weight (dibs.py:376-382, 531-549) and the gradient kernels deal them to GRAD_NS
@@ -489,7 +491,10 @@ def test_joint_gradients_with_many_weighted_samples(c_oracle64, monkeypatch, mod
     if gram:
         monkeypatch.setenv("DIBS_LIN_GRAM", "1")   # (latched when the engine is created: tuning.h)
         model = "lingauss"
-    kw = dict(lin_obs_noise=noise) if model == "lingauss" else dict(nn_obs_noise=noise, nn_hidden=(5,))
+    deep = model == "densenn-deep"
+    if deep:
+        model = "densenn"
+    kw = dict(lin_obs_noise=noise) if model == "lingauss" else dict(nn_obs_noise=noise, nn_hidden=(4, 3) if deep else (5,))
     cfg = make_config(n_vars=d, n_particles=M, n_observations=100, joint=True, likelihood=model, grad_estimator_z=est, n_grad_mc_samples=S,
                       n_acyclicity_mc_samples=4, score_function_baseline=0.001 if est == "score" else 0.0, **kw)
     st = c_oracle64.new_state(cfg, prng.PRNGKey(6))
