@@ -80,6 +80,8 @@ struct dibs_engine {
   BgeStats bge;
   bool kmat_fused;  // this step's latent kernel matrix was computed inside the k_bge_sample launch
   float* soft_ds;  // [Mloc, S, d, d]  BGe reparam estimator: per-sample score-space gradients
+  float* soft_tri = nullptr;  // ... beyond 128 variables: the waves' packed triangles (factor | inverse columns) in global scratch
+  int soft_blocks = 0;        //     of this many persistent blocks (kernels_bge_soft.h, GLOB)
   bool has_data;
   // work
   float* w_tot;     // [Mloc][d][d] total score-space gradient when a particle's W, U, V do not fit in one block's LDS (kernels_tail.h)
@@ -375,7 +377,14 @@ static int engine_alloc(dibs_engine* e, const dibs_config& c, void* stream) {
     e->bq.cap = (uint32_t)(Ml * e->S * e->d);
     HIP_OK(dalloc(&e->bq.list, (size_t)BGE_NQ * e->bq.cap * bge_entry_u4(e->W)));  // (one list per size tier, each sized for every problem)
     HIP_OK(dalloc(&e->bq.counts, (size_t)16));
-    if (c.grad_estimator_z == DIBS_EST_REPARAM) HIP_OK(dalloc(&e->soft_ds, Ml * e->S * dd));
+    if (c.grad_estimator_z == DIBS_EST_REPARAM) {
+      HIP_OK(dalloc(&e->soft_ds, Ml * e->S * dd));
+      if (e->d > 128) {
+        const size_t prob = Ml * e->S;
+        e->soft_blocks = (int)(prob < 1024 ? prob : 1024);
+        HIP_OK(dalloc(&e->soft_tri, (size_t)e->soft_blocks * 4 * 2 * bge_soft_tri(e->d)));
+      }
+    }
   }
   if (c.joint) {
     if (joint_alloc(&e->jw, e->Mloc, e->d, e->N, e->S) != 0) return fail("joint work buffers: hipMalloc failed");
@@ -412,8 +421,9 @@ extern "C" int dibs_engine_create(const dibs_config* cfg, void* stream, dibs_eng
   if (c.joint && c.likelihood == DIBS_LIK_BGE)
     return fail("JointDiBS + BGe is not constructible (BGe has no parameters; linearGaussian.py:53-54)");
   if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_REPARAM) {
-    // soft-graph BGe (kernels_bge_soft.h): one or two matrix rows per lane, packed factor + inverse columns per wave in LDS
-    if (c.n_vars > 128 || bge_soft_waves(c.n_vars, false) < 1)
+    // soft-graph BGe (kernels_bge_soft.h): one or two matrix rows per lane, packed factor + inverse columns per wave in LDS; beyond 128
+    // variables four rows per lane and the triangles in global scratch
+    if (c.n_vars <= 128 && bge_soft_waves(c.n_vars, false) < 1)
       return fail("BGe + reparam estimator: n_vars too large for the device kernel");
   }
   if (c.likelihood == DIBS_LIK_BGE && c.grad_estimator_z == DIBS_EST_SCORE &&
@@ -470,7 +480,7 @@ extern "C" int dibs_engine_destroy(dibs_engine* e) {
   if (e->stream2) hipStreamSynchronize(e->stream2);
   void* ptrs[] = {e->z, e->vz, e->theta, e->vtheta, e->baseline, e->baseline2, e->scores, e->probs, e->eas, e->thr, e->w_lik, e->acyc_part, e->w_acyc,
                   e->logprobs_z, e->logprobs_th, e->pack, e->kz, e->kt, e->phi_z, e->phi_th, e->counters, e->masks,
-                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot, e->join_flag, e->fork_flag, e->carry_bak, e->ksum, e->kpart, e->kmat_ctr};
+                  e->node_scores, e->x, e->mask, e->bq.list, e->bq.counts, e->soft_ds, e->acyc_big, e->w_tot, e->join_flag, e->fork_flag, e->carry_bak, e->soft_tri, e->ksum, e->kpart, e->kmat_ctr};
   for (void* p : ptrs)
     if (p) hipFree(p);
   joint_free(&e->jw);
@@ -999,7 +1009,7 @@ static int step_local(dibs_engine* e, int t, const RowTarget& rt, const StepKeys
     const BgeSoftParams sp{e->bge.R, e->bge.Nj, e->bge.alpha_lambd, e->bge.alpha_mu, e->bge.log_t, e->bge.n_mats};
     KTimer tm(e, DIBS_K_BGE_NODES);
     bge_soft_launch(sp, e->scores, carry_lik, e->m0, Mg, e->Mloc, e->d, e->S, alpha, (float)c.tau, L, c.logistic_minval_tiny,
-                    e->soft_ds, e->logprobs_z, e->w_lik, e->stream);
+                    e->soft_ds, e->logprobs_z, e->w_lik, e->stream, e->soft_tri, e->soft_blocks);
   } else if (c.likelihood == DIBS_LIK_BGE) {
     const BgeParams bp = e->bge.params();
     {  // (queue counters: zero at creation, reset by k_particle_grad at the end of every step)

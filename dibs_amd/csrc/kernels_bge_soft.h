@@ -62,30 +62,51 @@ __host__ __device__ inline size_t bge_soft_lds_bytes(int d, bool r_in_lds) {
   return bge_soft_shared_bytes(d, r_in_lds) + (size_t)bge_soft_waves(d, r_in_lds) * bge_soft_wave_bytes(d);
 }
 
-// grid = (S, Mloc), block = 256.  RPL: matrix rows per lane (1: d <= 64, 2: d <= 128)
-template <bool R_LDS, int RPL>
+// the fence between a wave's writes of the factor / inverse columns and the other lanes' reads: LDS, or (GLOB) global memory of this CU
+template <bool GLOB>
+__device__ __forceinline__ void bge_soft_fence() {
+  if (GLOB) __threadfence_block();  // (the stores have reached the L2: write-through)
+  wave_lds_fence();
+}
+// an entry of the packed triangles.  GLOB: read past the vector L1 -- a line may have been cached before a neighbouring entry (the next
+// column, or the previous problem's factor) was written, and a store does not refresh it
+template <bool GLOB>
+__device__ __forceinline__ float bge_soft_ld(const float* p) {
+  return GLOB ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+// GLOB (129 <= d <= 256, round 6): the two packed triangles of a wave (2 x 32 896 floats at d = 256) live in global scratch instead of LDS,
+// four rows per lane, persistent blocks that walk the (sample, particle) pairs -- the same arithmetic, untuned: it exists so that
+// grad_estimator_z = "reparam" has the n_vars limit of everything else.
+__host__ __device__ inline size_t bge_soft_glob_lds_bytes() { return 256 + 4 * (size_t)4 * 256 * 4; }  // red | p, y, w, dinv [256] per wave
+// grid = (S, Mloc) (GLOB: (blocks, 1)), block = 256.  RPL: matrix rows per lane (1: d <= 64, 2: d <= 128, 4: d <= 256)
+template <bool R_LDS, int RPL, bool GLOB = false>
 __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scores, BgeSoftParams bp, Key2 carry, int m0, int M_global,
                                                   int d, int S, float alpha, float tau, int layout, int tiny,
-                                                  float* __restrict__ ds_out, float* __restrict__ logprobs) {
+                                                  float* __restrict__ ds_out, float* __restrict__ logprobs, float* __restrict__ tri_glob,
+                                                  int n_prob) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int s = blockIdx.x, m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int dd = d * d, ntri = bge_soft_tri(d);
+  constexpr int VL = GLOB ? 256 : 128;  // length of the per-wave vectors
   float* Rs = reinterpret_cast<float*>(smem_raw);             // R (one matrix for all nodes)
-  double* red = reinterpret_cast<double*>(smem_raw + bge_soft_shared_bytes(d, R_LDS) - 256);  // [4] partial log-probs (+ pad)
-  const int nw = bge_soft_waves(d, R_LDS);
-  unsigned char* wbase = smem_raw + bge_soft_shared_bytes(d, R_LDS) + (size_t)wave * bge_soft_wave_bytes(d);
-  float* Lc = reinterpret_cast<float*>(wbase);  // L, column-major packed: (r, q), r >= q, at q d - q (q - 1) / 2 + r - q
-  float* Ut = Lc + ntri;                        // columns of L^-1, row-major packed: (k, c), c <= k, at k (k + 1) / 2 + c
-  float* pv = Ut + ntri;
-  float* yv = pv + 128;
-  float* wv = yv + 128;
-  float* dinv = wv + 128;
-
+  double* red = reinterpret_cast<double*>(GLOB ? smem_raw : smem_raw + bge_soft_shared_bytes(d, R_LDS) - 256);  // [4] partial log-probs (+ pad)
+  const int nw = GLOB ? 4 : bge_soft_waves(d, R_LDS);
+  unsigned char* wbase = GLOB ? smem_raw + 256 + (size_t)wave * 4 * VL * 4
+                              : smem_raw + bge_soft_shared_bytes(d, R_LDS) + (size_t)wave * bge_soft_wave_bytes(d);
+  // L, column-major packed: (r, q), r >= q, at q d - q (q - 1) / 2 + r - q;  columns of L^-1, row-major packed: (k, c), c <= k, at k (k + 1) / 2 + c
+  float* Lc = GLOB ? tri_glob + ((size_t)blockIdx.x * 4 + wave) * 2 * ntri : reinterpret_cast<float*>(wbase);
+  float* Ut = Lc + ntri;
+  float* pv = GLOB ? reinterpret_cast<float*>(wbase) : Ut + ntri;
+  float* yv = pv + VL;
+  float* wv = yv + VL;
+  float* dinv = wv + VL;
+  if (R_LDS)
+    for (int e = tid; e < dd; e += 256) Rs[e] = bp.R[e];
+  for (int prob = GLOB ? (int)blockIdx.x : 0; prob < (GLOB ? n_prob : 1); prob += GLOB ? (int)gridDim.x : 1) {
+  const int s = GLOB ? prob % S : (int)blockIdx.x, m = GLOB ? prob / S : (int)blockIdx.y;
   const float* sc_m = scores + (size_t)m * dd;
   const Key2 key = lin_mode_key(LIN_MODE_Z_REPARAM, carry, M_global, m0 + m, layout);  // dibs.py:430-431
   const uint64_t nbits = (uint64_t)S * dd;
-  if (R_LDS)
-    for (int e = tid; e < dd; e += 256) Rs[e] = bp.R[e];
   if (tid < 4) red[tid] = 0.0;
   __syncthreads();
 
@@ -108,7 +129,7 @@ __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scor
         lsum += (double)p[h];
       }
       const double l = wave_sum_d(lsum);
-      wave_lds_fence();
+      bge_soft_fence<GLOB>();
       // ---- Cholesky of M_pa, column by column (lane = row) -------------------------------------------------
       float dm1[RPL];  // L_rr^2 - 1 of this lane's rows
       double ldp = 0.0;
@@ -126,13 +147,15 @@ __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scor
             int ir = r, ik = kk;                                            // (r, q) and (kk, q) of column q = 0
 #pragma unroll 8
             for (int q = 0; q < kk; ++q) {  // (unrolled: the LDS reads of several terms in flight)
-              acc[h] = fmaf(-Lc[ir], Lc[ik], acc[h]);
+              acc[h] = fmaf(-bge_soft_ld<GLOB>(Lc + ir), bge_soft_ld<GLOB>(Lc + ik), acc[h]);
               ir += d - q - 1;
               ik += d - q - 1;
             }
           }
         }
-        const float accp = RPL == 1 ? acc[0] : (kk < 64 ? acc[0] : acc[RPL - 1]);
+        float accp = acc[0];
+#pragma unroll
+        for (int h = 1; h < RPL; ++h) accp = (kk >> 6) == h ? acc[h] : accp;  // (wave-uniform select of the pivot row's block)
         const float pivm1 = __shfl(accp, kk & 63, 64);
         const float piv = 1.0f + pivm1;
         const float inv = rsqrtf(piv);
@@ -149,7 +172,7 @@ __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scor
             Lc[ck + r] = acc[h] * inv;
           }
         }
-        wave_lds_fence();
+        bge_soft_fence<GLOB>();
       }
       const double ld_pa = wave_sum_d(ldp);
       // ---- forward substitutions: lane c solves L u = e_c (column c of L^-1), the lane that owns row j solves L w = b instead ----
@@ -160,7 +183,7 @@ __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scor
         b_own[h] = act[h] ? p[h] * R[j * d + r] : 0.f;
         wv[r] = b_own[h];  // (rhs, overwritten by the solution row by row)
       }
-      wave_lds_fence();
+      bge_soft_fence<GLOB>();
       for (int k = 0; k < d; ++k) {
         const int tk = k * (k + 1) / 2;
         float vs[RPL];
@@ -170,13 +193,13 @@ __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scor
         for (int h = 0; h < RPL; ++h) vs[h] = (lane + 64 * h == k) ? 1.f : 0.f;
 #pragma unroll 8
         for (int q = 0; q < k; ++q) {
-          const float lkq = Lc[ik];
+          const float lkq = bge_soft_ld<GLOB>(Lc + ik);
           ik += d - q - 1;
           vw = fmaf(-lkq, wv[q], vw);
 #pragma unroll
           for (int h = 0; h < RPL; ++h) {
             const int c = lane + 64 * h;
-            if (c <= q) vs[h] = fmaf(-lkq, Ut[q * (q + 1) / 2 + c], vs[h]);
+            if (c <= q) vs[h] = fmaf(-lkq, bge_soft_ld<GLOB>(Ut + q * (q + 1) / 2 + c), vs[h]);
           }
         }
         const float di = dinv[k];
@@ -186,7 +209,7 @@ __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scor
           if (c <= k) Ut[tk + c] = vs[h] * di;
         }
         if (lane == 0) wv[k] = vw * di;
-        wave_lds_fence();
+        bge_soft_fence<GLOB>();
       }
       // ---- (M_pa^-1)_cc and y_c = (L^-T w)_c from this lane's column of L^-1 ------------------------------------
       float offd[RPL], y[RPL];
@@ -197,7 +220,7 @@ __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scor
         y[h] = 0.f;
         if (act[h]) {
           for (int k = c; k < d; ++k) {
-            const float u = Ut[k * (k + 1) / 2 + c];
+            const float u = bge_soft_ld<GLOB>(Ut + k * (k + 1) / 2 + c);
             if (k > c) offd[h] = fmaf(u, u, offd[h]);
             y[h] = fmaf(u, wv[k], y[h]);
           }
@@ -210,7 +233,7 @@ __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scor
       for (int h = 0; h < RPL; ++h) btyp += (double)b_own[h] * (double)y[h];
       const double bty = wave_sum_d(btyp);
       const double sch = (double)R[j * d + j] - bty;
-      wave_lds_fence();
+      bge_soft_fence<GLOB>();
       const double Nn = bp.Nj[j], al = bp.alpha_lambd;
       double lj = 0.0, gprime = 0.0, ls = 0.0, c2 = 0.0;
       if (Nn > 0.0) {  // linearGaussian.py:118: a node without observations scores 0
@@ -236,12 +259,14 @@ __global__ __launch_bounds__(256) void k_bge_soft(const float* __restrict__ scor
         const double dl = Nn > 0.0 ? gprime - 0.5 * ls - (double)h_r - (2.0 * c2 / sch) * (double)y[h] * (double)t_r : 0.0;
         out[r * d + j] = (r == j) ? 0.f : (float)dl * tau * alpha * g[h] * (1.0f - g[h]);
       }
-      wave_lds_fence();
+      bge_soft_fence<GLOB>();
     }
     if (lane == 0) red[wave] = lp_wave;
   }
   __syncthreads();
   if (tid == 0) logprobs[(size_t)m * S + s] = (float)(red[0] + red[1] + red[2] + red[3]);
+  __syncthreads();  // (GLOB: red is reset for the block's next problem)
+  }
 }
 
 #ifdef DIBS_TU_BGE_SOFT
@@ -285,14 +310,21 @@ __global__ __launch_bounds__(256) void k_soft_combine(const float* __restrict__ 
 
 // both launches of the estimator: per-sample soft-graph scores + gradients, then the softmax-weighted combination
 void bge_soft_launch(const BgeSoftParams& sp, const float* scores, Key2 carry, int m0, int M, int Mloc, int d, int S, float alpha,
-                     float tau, int layout, int tiny, float* soft_ds, float* logprobs, float* w_lik, hipStream_t stream) {
+                     float tau, int layout, int tiny, float* soft_ds, float* logprobs, float* w_lik, hipStream_t stream, float* tri_glob,
+                     int glob_blocks) {
+  if (d > 128) {  // packed triangles in global scratch (tri_glob: glob_blocks * 4 waves * 2 * tri(d) floats), persistent blocks
+    hipLaunchKernelGGL((k_bge_soft<false, 4, true>), dim3(glob_blocks), dim3(256), bge_soft_glob_lds_bytes(), stream, scores, sp, carry, m0, M, d, S,
+                       alpha, tau, layout, tiny, soft_ds, logprobs, tri_glob, S * Mloc);
+    hipLaunchKernelGGL(k_soft_combine, dim3(Mloc, (d * d + 255) / 256), dim3(256), (size_t)S * 4 + 16, stream, soft_ds, logprobs, w_lik, d, S);
+    return;
+  }
   const bool rl = sp.n_mats == 1 && bge_soft_waves(d, true) >= (bge_soft_waves(d, false) < 4 ? bge_soft_waves(d, false) : 4);
   const size_t lds = bge_soft_lds_bytes(d, rl);
 #define SOFT_LAUNCH(RL_, RPL_)                                                                                                          \
   {                                                                                                                                     \
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_bge_soft<RL_, RPL_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL((k_bge_soft<RL_, RPL_>), dim3(S, Mloc), dim3(256), lds, stream, scores, sp, carry, m0, M, d, S, alpha, tau, layout, \
-                       tiny, soft_ds, logprobs);                                                                                        \
+                       tiny, soft_ds, logprobs, (float*)nullptr, 1);                                                                    \
   }
   if (d <= 64) {
     // blocked factorisation on the matrix pipe (kernels_bge_soft_mf.h)
@@ -320,5 +352,6 @@ void bge_soft_launch(const BgeSoftParams& sp, const float* scores, Key2 carry, i
 }
 #else
 void bge_soft_launch(const BgeSoftParams& sp, const float* scores, Key2 carry, int m0, int M, int Mloc, int d, int S, float alpha,
-                     float tau, int layout, int tiny, float* soft_ds, float* logprobs, float* w_lik, hipStream_t stream);
+                     float tau, int layout, int tiny, float* soft_ds, float* logprobs, float* w_lik, hipStream_t stream, float* tri_glob,
+                     int glob_blocks);
 #endif  // DIBS_TU_BGE_SOFT

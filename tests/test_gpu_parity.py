@@ -1038,7 +1038,8 @@ def test_sharded_engines_match_single_rank(joint, d, M):
                                              (50, 4, 16, 4, False), (64, 4, 16, 4, True),   # headline size / the last one-row-per-lane size
                                              # block boundaries of k_bge_soft_mf (16 x 16 blocks, node j ordered last): full last block, one real row in it
                                              (16, 2, 4, 2, False), (17, 2, 4, 2, True), (33, 1, 4, 2, False), (48, 1, 2, 2, True), (49, 1, 2, 2, False), (63, 1, 2, 2, False),
-                                             (65, 1, 2, 2, False), (100, 1, 2, 2, True)])   # two matrix rows per lane
+                                             (65, 1, 2, 2, False), (100, 1, 2, 2, True),    # two matrix rows per lane
+                                             (130, 1, 2, 2, False), (160, 2, 2, 2, True)])  # > 128 (round 6): four rows per lane, triangles in global scratch
 def test_marginal_bge_reparam_estimator(d, M, S, Sa, interv):
     """MarginalDiBS(grad_estimator_z='reparam'): BGe on Gumbel-soft graphs (dibs.py:395-459 with linearGaussian.py:63-170 on a
     real-valued parent vector).  Checked against the torch-autograd oracle (the C port has no soft BGe), which differentiates
@@ -1081,7 +1082,9 @@ def test_marginal_bge_reparam_estimator(d, M, S, Sa, interv):
         # a coordinate whose phi lies below the float32 noise of the largest one may take that step with the other sign)
         u = update_check(cfg, st.z.numpy(), st.v_z.numpy(), phi_dev, phi_o, g["z"], st2.z.numpy())
         print(f"soft BGe d={d} t={t}: {u}")
-        assert_update_parity(u, 0.9, f"soft BGe d={d} t={t}")
+        if d <= 128:   # (beyond ~128 variables phi^2 of the dense early soft graphs leaves float32: RMSprop's second moment is inf and the step 0, for
+            #  the reference's float32 arithmetic as for the device -- INTEGRATION.md, limits table; the stages above are the comparison there)
+            assert_update_parity(u, 0.9, f"soft BGe d={d} t={t}")
         st = st2
     eng.close()
 
