@@ -65,6 +65,9 @@ CASES = [
     (4, dict(d=20, M=16, S=32, Sa=8, joint=True, chunks=[[0, 2], [2, 2], [4, 2]], overlapped=[0, 1, 1])),
     # >= 256 particles: the SVGD transform as a GEMM (k_phi_gemm), 68 particles per rank
     (4, dict(d=6, M=272, S=16, Sa=4, chunks=[[0, 2], [2, 2]], overlapped=[0, 1])),
+    # eight ranks (the driver's largest layout), two particles each
+    (8, dict(d=20, M=16, S=32, Sa=8, chunks=[[0, 3], [3, 3]], overlapped=[0, 1])),
+    (8, dict(d=12, M=16, S=16, Sa=4, joint=True, chunks=[[0, 2], [2, 2]], overlapped=[1, 0])),
 ]
 
 
@@ -84,13 +87,15 @@ def test_sharded_loop_over_mapped_memory_is_bit_identical(R, case):
         assert (outs[r]["key"] == ref[-1]["key"]).all(), "the loop-carry key advances identically on every rank"
 
 
-def test_headline_size_four_ranks_one_gpu():
-    """the headline workload (d = 50, 128 particles, S = 128, Sa = 32) as four ranks of 32 particles on one GPU, 6 steps in two chunks"""
+@pytest.mark.parametrize("R", [4, 8])
+def test_headline_size_ranks_on_one_gpu(R):
+    """the headline workload (d = 50, 128 particles, S = 128, Sa = 32) as 4 ranks of 32 and as 8 ranks of 16 particles (the layout of
+    `bench.py --gpus 8`) on one GPU, 6 steps in two chunks, packed then overlapped"""
     case = dict(d=50, M=128, S=128, Sa=32, chunks=[[0, 3], [3, 3]], overlapped=[0, 1], seed=1, data_seed=0)
     ref = _reference(case)
-    outs = _run_ranks(case, 4)
+    outs = _run_ranks(case, R)
     for i, st in enumerate(ref):
-        for r in range(4):
+        for r in range(R):
             assert np.array_equal(outs[r][f"z_{i}"], st["z"])
 
 
