@@ -65,13 +65,17 @@ CASES = [
     (4, dict(d=20, M=16, S=32, Sa=8, joint=True, chunks=[[0, 2], [2, 2], [4, 2]], overlapped=[0, 1, 1])),
     # >= 256 particles: the SVGD transform as a GEMM (k_phi_gemm), 68 particles per rank
     (4, dict(d=6, M=272, S=16, Sa=4, chunks=[[0, 2], [2, 2]], overlapped=[0, 1])),
+    # late step indices: the edge probabilities are saturated, every sample of a particle keeps a softmax weight and the gradient kernels share
+    # them between blocks (GradSplit) -- the shares must not depend on the shard
+    (2, dict(d=20, M=16, S=32, Sa=8, joint=True, chunks=[[400, 2], [402, 2]], overlapped=[0, 1])),
+    (4, dict(d=12, M=8, S=24, Sa=4, joint=True, model="densenn", chunks=[[300, 2], [302, 1]], overlapped=[1, 0])),
     # eight ranks (the driver's largest layout), two particles each
     (8, dict(d=20, M=16, S=32, Sa=8, chunks=[[0, 3], [3, 3]], overlapped=[0, 1])),
     (8, dict(d=12, M=16, S=16, Sa=4, joint=True, chunks=[[0, 2], [2, 2]], overlapped=[1, 0])),
 ]
 
 
-@pytest.mark.parametrize("R,case", CASES, ids=[f"R{r}-d{c['d']}-M{c['M']}-{'joint' if c.get('joint') else 'marg'}-{''.join(map(str, c['overlapped']))}"
+@pytest.mark.parametrize("R,case", CASES, ids=[f"R{r}-d{c['d']}-M{c['M']}-{'joint' if c.get('joint') else 'marg'}-t{c['chunks'][0][0]}-{''.join(map(str, c['overlapped']))}"
                                                for r, c in CASES])
 def test_sharded_loop_over_mapped_memory_is_bit_identical(R, case):
     ref = _reference(case)
