@@ -57,7 +57,7 @@ __host__ __device__ inline int nn_tr_rows(const LinGeom g) { return g.kp > g.np 
 __host__ __device__ inline size_t nn_lds_bytes(int d, int N, int NT, bool grad) {
   const LinGeom g = lin_geom(d, N, NT);
   size_t f = (size_t)g.np * g.ldx + (size_t)d * d + (size_t)nn_tr_rows(g) * g.ldw;
-  if (grad) f += (size_t)8 * g.ldw;  // per-wave column sums of k_nn_grad (up to 8 waves)
+  if (grad) f += (size_t)16 * g.ldw;  // two sets of per-wave column sums of k_nn_grad (up to 8 waves)
   return ((f * 4 + 15) & ~(size_t)15) + 64 * 8;
 }
 // k_nn_logprobs also keeps the small leaves b1 | W2 | b2 ([d][H] | [d][H] | [d]) behind `red`
@@ -392,6 +392,84 @@ __global__ __launch_bounds__(64 * NW) void k_nn_logprobs(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 // NW waves per block: 8 when the operands leave room for ONE block per CU only (two waves per SIMD hide the barriers and the LDS / L2 waits
 // of the build -> MFMA -> epilogue cycle of every hidden unit; with 4 the CU ran one wave per SIMD), 4 otherwise.
+// ---- k_nn_grad's pieces ----
+// accumulate into a partial row / the output without waiting for the old value: global_atomic_add_f32 without return.  One thread owns the
+// element (or the adds are separated by block barriers), and same-address operations of a wave execute in issue order, so the sum is the
+// sequential one; what it removes is the round trip of a read-modify-write (28 per thread and hidden unit, each past the L2 once hundreds of
+// partial rows are in flight: 78 of 320 us per sample gradient at config 5 / step 300, profiles/round6_nn_grad_phases.txt)
+__device__ __forceinline__ void nn_acc(float* p, float v) { (void)unsafeAtomicAdd(p, v); }
+// sample graph s into GS for the gradient kernel; FAST as in nn_build_graph_tab (paired legacy layout, 32-bit counters, hoisted key schedule)
+template <bool FAST>
+__device__ __forceinline__ void nn_grad_build_graph(float* GS, int mode, Key2 key, const TfKeys& tk, uint64_t nbits, int s, int S,
+                                                    const uint32_t* thr_m, const float* sc_m, float alpha, float tau, int layout, int tiny, int d,
+                                                    int tid, int nthr) {
+  if constexpr (!FAST) {
+    nn_build_graph(GS, mode, key, nbits, s, thr_m, sc_m, alpha, tau, layout, tiny, d, tid, nullptr, nthr);
+  } else {
+    const int dd = d * d, hS = S >> 1;
+    const bool hi = s >= hS;
+    const uint32_t cbase = (uint32_t)(hi ? s - hS : s) * (uint32_t)dd, half = (uint32_t)(nbits >> 1);
+    const float ulo = tiny ? 1.17549435e-38f : 1.1920929e-07f;
+    const float inv_d = 1.0f / (float)d;
+    for (int e = tid; e < dd; e += nthr) {
+      const int a = (int)(((float)e + 0.5f) * inv_d), j = e - a * d;  // e / d, exact for e < 2^20
+      float gv = 0.f;
+      if (a != j) {
+        uint32_t y0, y1;
+        threefry2x32_uk(tk, cbase + (uint32_t)e, cbase + (uint32_t)e + half, y0, y1);
+        const uint32_t y = hi ? y1 : y0;
+        if (mode == LIN_MODE_Z_REPARAM) {
+          const float as = alpha * sc_m[e];
+          if (tau == 1.0f) {
+            const float u = rng_uniform(y, ulo, 1.0f);
+            gv = u * __builtin_amdgcn_rcpf(fmaf(1.0f - u, expf(-as), u));
+          } else {
+            gv = 1.0f / (1.0f + expf(-tau * (rng_logistic(y, tiny) + as)));
+          }
+        } else {
+          gv = (y >> 9) < thr_m[e] ? 1.0f : 0.0f;
+        }
+      }
+      GS[e] = gv;
+    }
+  }
+}
+// T_h = GS o W1T_h into the operand region: the d x d interior with all of a thread's table loads in flight at once (EPT per round), and the
+// padding rows d .. kp-1 (the region also holds dpre_h, whose rows overwrite them; its padding COLUMNS only ever receive exact zeros)
+template <int EPT>
+__device__ __forceinline__ void nn_grad_build_tw(float* TW, const float* GS, const float* __restrict__ w1t_h, const LinGeom g, int tid, int nthr) {
+  const int d = g.d, dd = d * d, pad = g.ldw - d;
+  const float inv_d = 1.0f / (float)d;
+  for (int e0 = tid; e0 < dd; e0 += EPT * nthr) {
+    float wv[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int e = e0 + q * nthr;
+      wv[q] = w1t_h[e < dd ? e : dd - 1];
+    }
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+      const int e = e0 + q * nthr;
+      const int a = (int)(((float)e + 0.5f) * inv_d);
+      if (e < dd) TW[e + a * pad] = GS[e] * wv[q];
+    }
+  }
+  for (int e = d * g.ldw + tid; e < g.kp * g.ldw; e += nthr) TW[e] = 0.f;
+}
+
+#ifdef DIBS_NN_STAMPS
+static __device__ unsigned long long g_nn_stamps[64];
+#define NN_ST(k)                                                        \
+  do {                                                                  \
+    if (tid == 0) {                                                     \
+      const unsigned long long t_ = wall_clock64();                     \
+      atomicAdd(&g_nn_stamps[(mode & 3) * 16 + (k)], t_ - st_prev);     \
+      st_prev = t_;                                                     \
+    }                                                                   \
+  } while (0)
+#else
+#define NN_ST(k)
+#endif
 template <int NT, int ACT = -1, int NW = 4>   // ACT >= 0: compile-time activation (relu), as in k_nn_logprobs
 __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x, const int32_t* __restrict__ mask,
                                                  const float* __restrict__ theta, size_t P, const float* __restrict__ scores,
@@ -409,7 +487,7 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
   float* TW = GS + (size_t)d * d;                  // T_h [kp][ldw] (forward operand) ...
   float* RS = TW;                                  // ... and dpre_h [np][ldw] (backward operand), same storage
   float* CS = TW + (size_t)nn_tr_rows(g) * g.ldw;  // per-wave column sums [NW][ldw]
-  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)d * d + (size_t)nn_tr_rows(g) * g.ldw + (size_t)NW * g.ldw) + 3) & ~(size_t)3));
+  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)d * d + (size_t)nn_tr_rows(g) * g.ldw + (size_t)2 * NW * g.ldw) + 3) & ~(size_t)3));
   // grid = (Mloc, shares); block (x, y) takes share y of particle (x + y) mod Mloc.  Workgroups go to the 8 XCDs round-robin by their linear
   // id x + Mloc y: with particle = x every share of particle m ran on XCD m mod 8, and the XCD that held the particles with the most weighted
   // samples set the time (150 of 256 CUs busy, 18 ms instead of 8 at config 5 / step 300); rotated by y, a particle's shares land on all
@@ -428,6 +506,9 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
   __shared__ int last_flag;
   double mx, den, sm;
   int nnz;
+#ifdef DIBS_NN_STAMPS
+  unsigned long long st_prev = wall_clock64();
+#endif
   grad_softmax_stats<NW>(lp, S, red, mx, den, sm, nnz);
   const int NS = gridDim.y, bz = blockIdx.y, nact = nnz < NS ? (nnz > 0 ? nnz : 1) : NS;
   if (bz >= nact) return;  // (block-uniform: no share -- before anything is staged)
@@ -435,7 +516,9 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
     const int n = e / g.ldx, c = e - n * g.ldx;
     X[e] = (n < N && c < d) ? x[(size_t)n * d + c] : 0.f;
   }
-  for (int e = tid; e < NW * g.ldw; e += NTHR) CS[e] = 0.f;
+  for (int e = tid; e < 2 * NW * g.ldw; e += NTHR) CS[e] = 0.f;  // [0]: sum_n dmean / dm h, [1]: sum_n dpre (per wave)
+  float* const CS1 = CS + NW * g.ldw;
+  for (int e = tid; e < nn_tr_rows(g) * g.ldw; e += NTHR) TW[e] = 0.f;  // (operand padding: see nn_grad_build_tw)
   // the accumulation row: the output itself while one block does everything, else this block's partial sums
   // outputs start at zero (theta mode: P entries; z modes: d*d)
   // Several blocks (split): the theta estimator's first-layer gradient -- d*d*H values that every sample updates -- is accumulated in THREAD
@@ -458,6 +541,24 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
   const float* sc_m = scores + (size_t)m * dd;
   const uint32_t* thr_m = thr + (size_t)m * dd;
   const int nrt = g.np >> 4;
+  const bool fastg = layout == 0 && (S & 1) == 0 && (uint64_t)S * dd < 0xFFFFFFFFull;  // (block-uniform)
+  const TfKeys tk = tf_keys(key);
+  // which of the lane's output elements are observations that count (not padding, not intervened on): one bit each
+  uint32_t okb[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    okb[u] = 0u;
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = (wave + NW * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
+        const bool v = n < N && j < d && wave + NW * u < nrt && !(any_mask && mask[(size_t)n * d + j]);
+        okb[u] |= (uint32_t)v << (tj * 4 + r);
+      }
+  }
+  static_assert(NT * 4 <= 32, "validity bits of a row tile");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zeroed rows are in place before another wave adds to them (barriers below)
 
   int q = 0;  // ordinal of the next sample with a non-zero weight
   for (int s0 = 0; s0 < S; s0 += GRAD_WCH) {
@@ -469,8 +570,14 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
     if (w < GRAD_W_MIN) continue;  // block-uniform
     if ((q++ % NS) != bz) continue;  // (another block's sample)
     __syncthreads();
-    nn_build_graph(GS, mode, key, nbits, s, thr_m, sc_m, alpha, tau, layout, tiny, d, tid, nullptr, NTHR);
+    NN_ST(0);
+    if (fastg) nn_grad_build_graph<true>(GS, mode, key, tk, nbits, s, S, thr_m, sc_m, alpha, tau, layout, tiny, d, tid, NTHR);
+    else nn_grad_build_graph<false>(GS, mode, key, tk, nbits, s, S, thr_m, sc_m, alpha, tau, layout, tiny, d, tid, NTHR);
     __syncthreads();
+    NN_ST(1);
+#ifdef DIBS_NN_STAMPS
+    if (tid == 0) atomicAdd(&g_nn_stamps[(mode & 3) * 16 + 12], 1ull);
+#endif
     if (mode == LIN_MODE_Z_SCORE) {
       for (int e = tid; e < (int)dd; e += NTHR) om[e] += w * GS[e];
       continue;
@@ -483,11 +590,13 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
       for (int tj = 0; tj < NT; ++tj) macc[u][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int h = 0; h < H; ++h) {
       __syncthreads();
-      if (w1t) nn_build_tw_t(TW, GS, w1t + ((size_t)m * H + h) * dd, g, tid, NTHR);
+      if (w1t) nn_grad_build_tw<8>(TW, GS, w1t + ((size_t)m * H + h) * dd, g, tid, NTHR);
       else nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid, NTHR);
       __syncthreads();
+      NN_ST(2);
       f32x4 acc[NU][NT];
       nn_gemm_x_tw<NT, NU, NW>(X, TW, g, lane, wave, acc);
+      NN_ST(3);
 #pragma unroll
       for (int u = 0; u < NU; ++u)
 #pragma unroll
@@ -501,18 +610,19 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
           }
         }
     }
+    NN_ST(4);
     // dmean = (1 - mask) (x - mean) / obs_noise  (kept in registers, C layout; zero on padding rows / columns)
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj) {
       float t = 0.f;
+      const float b2 = (np_.bias && tj * 16 + (lane & 15) < d) ? th_m[off.b2 + tj * 16 + (lane & 15)] : 0.f;
 #pragma unroll
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int n = (wave + NW * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
           float dm = 0.f;
-          if (n < N && j < d && wave + NW * u < nrt && !(any_mask && mask[(size_t)n * d + j]))
-            dm = (X[n * g.ldx + j] - macc[u][tj][r] - (np_.bias ? th_m[off.b2 + j] : 0.f)) * inv_on;
+          if ((okb[u] >> (tj * 4 + r)) & 1u) dm = (X[n * g.ldx + j] - macc[u][tj][r] - b2) * inv_on;
           macc[u][tj][r] = dm;
           t += dm;
         }
@@ -523,22 +633,25 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
     __syncthreads();
     if (mode == LIN_MODE_THETA && np_.bias)
       for (int j = tid; j < d; j += NTHR)  // d/db2_j = sum_n dmean_nj
-        om[off.b2 + j] += w * nn_cs_sum<NW>(CS, g.ldw, j);
+        nn_acc(om + off.b2 + j, w * nn_cs_sum<NW>(CS, g.ldw, j));
     // ---- backward, one hidden unit at a time ----
     for (int h = 0; h < H; ++h) {
       __syncthreads();
-      if (w1t) nn_build_tw_t(TW, GS, w1t + ((size_t)m * H + h) * dd, g, tid, NTHR);
+      NN_ST(5);
+      if (w1t) nn_grad_build_tw<8>(TW, GS, w1t + ((size_t)m * H + h) * dd, g, tid, NTHR);
       else nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid, NTHR);
       __syncthreads();
+      NN_ST(6);
       f32x4 acc[NU][NT];
       nn_gemm_x_tw<NT, NU, NW>(X, TW, g, lane, wave, acc);
       __syncthreads();  // every wave is done reading T_h: its storage now takes dpre_h
+      NN_ST(7);
 #pragma unroll
       for (int tj = 0; tj < NT; ++tj) {
         const int j = tj * 16 + (lane & 15);
         const float b1 = (np_.bias && j < d) ? th_m[off.b1 + (size_t)j * H + h] : 0.f;
         const float w2 = j < d ? th_m[off.w2 + (size_t)j * H + h] : 0.f;
-        float t2 = 0.f;
+        float t2 = 0.f, t1 = 0.f;
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
@@ -548,22 +661,29 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
               const float pre = acc[u][tj][r] + b1;
               const float hv = nn_act(ACT >= 0 ? ACT : np_.act, pre);
               const float dm = macc[u][tj][r];
-              RS[n * g.ldw + j] = dm * w2 * nn_dact(ACT >= 0 ? ACT : np_.act, pre, hv);  // dpre
+              const float dp = dm * w2 * nn_dact(ACT >= 0 ? ACT : np_.act, pre, hv);  // dpre
+              RS[n * g.ldw + j] = dp;
+              t1 += dp;                                                   // for d/db1
               t2 += dm * hv;                                              // for d/dW2
             }
           }
         t2 += __shfl_xor(t2, 16);
         t2 += __shfl_xor(t2, 32);
-        if (lane < 16) CS[wave * g.ldw + j] = t2;
+        t1 += __shfl_xor(t1, 16);
+        t1 += __shfl_xor(t1, 32);
+        if (lane < 16) {
+          CS[wave * g.ldw + j] = t2;
+          CS1[wave * g.ldw + j] = t1;
+        }
       }
       __syncthreads();
+      NN_ST(8);
       if (mode == LIN_MODE_THETA)
-        for (int j = tid; j < d; j += NTHR) {
-          float t1 = 0.f;
-          for (int n = 0; n < N; ++n) t1 += RS[n * g.ldw + j];
-          if (np_.bias) om[off.b1 + (size_t)j * H + h] += w * t1;
-          om[off.w2 + (size_t)j * H + h] += w * nn_cs_sum<NW>(CS, g.ldw, j);
+        for (int j = tid; j < d; j += NTHR) {  // (column sums of dpre / dm h by wave, added in wave order)
+          if (np_.bias) nn_acc(om + off.b1 + (size_t)j * H + h, w * nn_cs_sum<NW>(CS1, g.ldw, j));
+          nn_acc(om + off.w2 + (size_t)j * H + h, w * nn_cs_sum<NW>(CS, g.ldw, j));
         }
+      NN_ST(9);
       // xtr[a][j] = sum_n x[n][a] dpre[n][j]  (d/dT_h)
 #pragma unroll
       for (int u = 0; u < NUD; ++u) {
@@ -579,6 +699,7 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
 #pragma unroll
           for (int tj = 0; tj < NT; ++tj) t[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, RS[bq + k0 * g.ldw + tj * 16], t[tj], 0, 0, 0);
         }
+        NN_ST(10);
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
@@ -588,23 +709,27 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
               float xtr = t[tj][r];
               asm volatile("" : "+v"(xtr));
               const float gv = GS[a * d + j];
+              if (gv == 0.f) continue;  // no term (hard graphs late in a run: a few per cent of the entries are edges)
               const float w1 = w1t ? w1t[((size_t)m * H + h) * dd + (size_t)a * d + j] : th_m[((size_t)j * d + a) * H + h];
               if (mode == LIN_MODE_THETA) {
                 const float v = w * gv * (xtr - w1 * inv_sp2);
-                if (split) prow[(size_t)(((h * NUD + u) * NT + tj) * 4 + r) * NTHR + tid] += v;
-                else om[((size_t)j * d + a) * H + h] += v;
+                if (split) nn_acc(prow + (size_t)(((h * NUD + u) * NT + tj) * 4 + r) * NTHR + tid, v);
+                else nn_acc(om + ((size_t)j * d + a) * H + h, v);
               } else if (a != j) {
-                om[a * d + j] += w * (lin_logn(w1, 0.f, np_.sig_param) + w1 * xtr) * tau * alpha * gv * (1.0f - gv);
+                nn_acc(om + a * d + j, w * (lin_logn(w1, 0.f, np_.sig_param) + w1 * xtr) * tau * alpha * gv * (1.0f - gv));
               }
             }
           }
       }
+      NN_ST(11);
     }
   }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's adds have been performed
   __syncthreads();
+  NN_ST(0);
   if (nact > 1) {
-    // the partial sums were accumulated with plain read-modify-writes: release them, count this block, and the LAST block of the particle
+    // release the partial sums, count this block, and the LAST block of the particle
     // adds the rows in block order into the output
     __threadfence();
     if (!grad_last_block(gs.ctr + m, nact, &last_flag)) return;
@@ -633,6 +758,7 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
       for (size_t e = tid; e < n_out; e += NTHR) om_final[e] = grad_part_sum<GRAD_NS_NN, false>(base, gs.stride, e, nact);
     }
     __syncthreads();
+    NN_ST(13);
   }
   // epilogue
   const float bold = baseline ? baseline[m] : 0.f;
@@ -864,6 +990,16 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
 #undef NN_GRAD_LAUNCH
 }
 
+#ifdef DIBS_NN_STAMPS
+extern "C" void dibs_debug_nn_stamps(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_stamps), sizeof(unsigned long long) * 64);
+  if (reset) {
+    unsigned long long z[64] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stamps), z, sizeof(z));
+  }
+}
+#endif
 bool joint_nn_fast_path(int d, int N, const NNParams& np_) {
   return np_.n_hidden == 1 && np_.H >= 1 && np_.H <= 64 && N <= 128 && d <= 112 && nn_lds_bytes(d, N, (d + 15) / 16, true) <= (size_t)160 * 1024 - 2048;  // (2 KiB for the static LDS of k_nn_grad)
 }
