@@ -708,6 +708,7 @@ __device__ __forceinline__ float grad_part_load(const float* p) { return __hip_a
 // of a particle took milliseconds)
 template <int NSMAX, bool ATOMIC>
 __device__ __forceinline__ float grad_part_sum(const float* base, size_t stride, size_t idx, int nact) {
+  if (nact == 1) return ATOMIC ? grad_part_load(base + idx) : base[idx];  // (block-uniform; 0.f + v == v)
   float v[NSMAX];
 #pragma unroll
   for (int b = 0; b < NSMAX; ++b) {

@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "kernels_joint.h"
 
 #ifndef DIBS_MAX_HIDDEN_LAYERS
@@ -57,7 +58,7 @@ __host__ __device__ inline int nn_tr_rows(const LinGeom g) { return g.kp > g.np 
 __host__ __device__ inline size_t nn_lds_bytes(int d, int N, int NT, bool grad) {
   const LinGeom g = lin_geom(d, N, NT);
   size_t f = (size_t)g.np * g.ldx + (size_t)d * d + (size_t)nn_tr_rows(g) * g.ldw;
-  if (grad) f += (size_t)16 * g.ldw;  // two sets of per-wave column sums of k_nn_grad (up to 8 waves)
+  (void)grad;
   return ((f * 4 + 15) & ~(size_t)15) + 64 * 8;
 }
 // k_nn_logprobs also keeps the small leaves b1 | W2 | b2 ([d][H] | [d][H] | [d]) behind `red`
@@ -384,15 +385,40 @@ __global__ __launch_bounds__(64 * NW) void k_nn_logprobs(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// softmax-weighted gradients (samples whose weight underflows to 0 in float are skipped, as in the oracle):
+// softmax-weighted gradients (samples whose weight is below GRAD_W_MIN are skipped; the oracle skips those that underflow to 0):
 //   mode THETA     : grad_theta = sum_s w_s d/dtheta log p(theta, D | G_s)          -> pack row (+ copy of theta)
 //   mode Z_REPARAM : W = sum_s w_s (d/dg) o tau alpha g~(1 - g~), off-diagonal     -> w_lik
 //   mode Z_SCORE   : W = scale * alpha (sum_s w_s G_s - P), off-diagonal           -> w_lik
-// grid = (Mloc, shares), block = 256.  Accumulation goes to global memory; every output element is owned by one thread.
+// grid = (Mloc, shares), block = 64 NW.
+//
+// One sample gradient, ONE COLUMN TILE (16 nodes j) AT A TIME -- the nodes' networks are independent (mean_nj depends on column j of every
+// T_h only), so for a column tile the whole chain runs with the activations of all hidden units in registers:
+//   slices T_h[:, tile] of up to NN_HC hidden units -> LDS;  pre_h = x T_h (f32 MFMA) -> h_h = act(pre_h + b1) kept in registers;
+//   dmean;  dpre_h = dmean w2 act'(.) -> LDS slices (same storage);  xtr_h = x^T dpre_h (f32 MFMA);  gradient terms.
+// Round 5's kernel walked hidden units outermost over ALL columns: h_h could not stay anywhere (d = 100: 140 registers per thread, LDS full),
+// so the backward pass rebuilt T_h and repeated the forward GEMM -- 15 GEMMs and 10 operand builds per sample where 10 and 5 are needed, at
+// 256 VGPRs with spills.  (More hidden units than NN_HC: processed in groups, and only then the forward product is repeated.)
+// The first-layer gradient -- d*d*H values that every sample updates -- accumulates in a partial row in THREAD layout ([slot][thread]) with
+// no-return atomic adds, for the entries that are edges only; the block that finishes a particle last (or its only block) adds the partial
+// rows in block order and writes theta's layout through LDS (theta's own layout puts a wave's 64 values 4 d H bytes apart).
 // ------------------------------------------------------------------------------------------------
-// NW waves per block: 8 when the operands leave room for ONE block per CU only (two waves per SIMD hide the barriers and the LDS / L2 waits
-// of the build -> MFMA -> epilogue cycle of every hidden unit; with 4 the CU ran one wave per SIMD), 4 otherwise.
-// ---- k_nn_grad's pieces ----
+#define NN_HC 8
+#define NN_SLR 128  // rows of a slice (kp <= 112, np <= 128): a compile-time stride keeps the hidden units' LDS offsets in the instructions
+// LDS floats: X[np][ldx] | GS[d*d] | SL[hcs][NN_SLR][16] | CS[8][16] | CS2[hcs][2][8][16] | red     (hcs = hidden units per group)
+__host__ __device__ inline size_t nn_grad_lds_floats(int d, int N, int NT, int hcs) {
+  const LinGeom g = lin_geom(d, N, NT);
+  return (size_t)g.np * g.ldx + (size_t)d * d + (size_t)hcs * NN_SLR * 16 + (size_t)8 * 16 + (size_t)hcs * 2 * 8 * 16;
+}
+__host__ __device__ inline size_t nn_grad_lds_bytes(int d, int N, int NT, int hcs) {
+  return ((nn_grad_lds_floats(d, N, NT, hcs) * 4 + 15) & ~(size_t)15) + 64 * 8;
+}
+// hidden units per group: as many as registers (NN_HC) and LDS hold (2 KiB stay free for the kernel's static LDS); 0: does not fit at all
+inline int nn_grad_hcs(int d, int N, int NT, int H) {
+  int hcs = H < NN_HC ? H : NN_HC;
+  while (hcs > 0 && nn_grad_lds_bytes(d, N, NT, hcs) > (size_t)160 * 1024 - 2048) --hcs;
+  return hcs;
+}
+
 // accumulate into a partial row / the output without waiting for the old value: global_atomic_add_f32 without return.  One thread owns the
 // element (or the adds are separated by block barriers), and same-address operations of a wave execute in issue order, so the sum is the
 // sequential one; what it removes is the round trip of a read-modify-write (28 per thread and hidden unit, each past the L2 once hundreds of
@@ -434,43 +460,133 @@ __device__ __forceinline__ void nn_grad_build_graph(float* GS, int mode, Key2 ke
     }
   }
 }
-// T_h = GS o W1T_h into the operand region: the d x d interior with all of a thread's table loads in flight at once (EPT per round), and the
-// padding rows d .. kp-1 (the region also holds dpre_h, whose rows overwrite them; its padding COLUMNS only ever receive exact zeros)
+// operand slices of column tile tj for hidden units h0 .. h0+hn-1: SL[hc][a][jl] = GS[a][j] W1[j][a][h0+hc], j = 16 tj + jl; zero for a >= d,
+// j >= d.  All of a thread's weight loads of a round (EPT) are in flight together.  w1t_m: the particle's re-laid-out weights W1T[h][a][j]
+// (k_nn_prior_table; coalesced) or null (theta's own layout).
 template <int EPT>
-__device__ __forceinline__ void nn_grad_build_tw(float* TW, const float* GS, const float* __restrict__ w1t_h, const LinGeom g, int tid, int nthr) {
-  const int d = g.d, dd = d * d, pad = g.ldw - d;
-  const float inv_d = 1.0f / (float)d;
-  for (int e0 = tid; e0 < dd; e0 += EPT * nthr) {
+__device__ __forceinline__ void nn_grad_build_slices(float* SL, const float* GS, const float* __restrict__ w1t_m, const float* __restrict__ th_m,
+                                                     int H, int h0, int hn, int tj, const LinGeom g, int tid, int nthr) {
+  const int d = g.d, kp = g.kp, tot = hn * kp * 16;
+  const float inv_kp = 1.0f / (float)kp;
+  for (int i0 = tid; i0 < tot; i0 += EPT * nthr) {
     float wv[EPT];
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
-      const int e = e0 + q * nthr;
-      wv[q] = w1t_h[e < dd ? e : dd - 1];
+      const int i = i0 + q * nthr, row = i >> 4, j = tj * 16 + (i & 15);
+      const int hc = (int)(((float)row + 0.5f) * inv_kp), a = row - hc * kp;
+      const bool ok = i < tot && a < d && j < d;
+      wv[q] = !ok ? 0.f : (w1t_m ? w1t_m[((size_t)(h0 + hc) * d + a) * d + j] : th_m[((size_t)j * d + a) * H + h0 + hc]);
     }
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
-      const int e = e0 + q * nthr;
-      const int a = (int)(((float)e + 0.5f) * inv_d);
-      if (e < dd) TW[e + a * pad] = GS[e] * wv[q];
+      const int i = i0 + q * nthr, row = i >> 4, j = tj * 16 + (i & 15);
+      const int hc = (int)(((float)row + 0.5f) * inv_kp), a = row - hc * kp;
+      if (i < tot) SL[(hc * NN_SLR + a) * 16 + (i & 15)] = (a < d && j < d) ? GS[a * d + j] * wv[q] : 0.f;
     }
   }
-  for (int e = d * g.ldw + tid; e < g.kp * g.ldw; e += nthr) TW[e] = 0.f;
 }
+// pre_hc = x[row tiles of this wave] * SL[hc] for hc < HN (A fragment loaded once per k-step for all hidden units; two k-steps per trip so the
+// second step's LDS reads are in flight during the first step's MFMAs)
+template <int HN, int NU, int NW>
+__device__ __forceinline__ void nn_grad_gemm_fwd(const float* X, const float* SL, const LinGeom g, int lane, int wave, f32x4 (&acc)[NN_HC][NU]) {
+  const int nrt = g.np >> 4;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+#pragma unroll
+    for (int hc = 0; hc < HN; ++hc) acc[hc][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ti = wave + NW * u;
+    if (ti >= nrt) continue;
+    const float* ap = X + (ti * 16 + (lane & 15)) * g.ldx + (lane >> 4);
+    const float* bq = SL + (lane >> 4) * 16 + (lane & 15);
+    int k0 = 0;
+    for (; k0 + 4 < g.kp; k0 += 8) {
+      const float a0 = ap[0], a1 = ap[4];
+      float b0[HN], b1[HN];
+#pragma unroll
+      for (int hc = 0; hc < HN; ++hc) {
+        b0[hc] = bq[hc * NN_SLR * 16];
+        b1[hc] = bq[hc * NN_SLR * 16 + 64];
+      }
+#pragma unroll
+      for (int hc = 0; hc < HN; ++hc) acc[hc][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[hc], acc[hc][u], 0, 0, 0);
+#pragma unroll
+      for (int hc = 0; hc < HN; ++hc) acc[hc][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[hc], acc[hc][u], 0, 0, 0);
+      ap += 8;
+      bq += 128;
+    }
+    if (k0 < g.kp) {
+      const float a0 = ap[0];
+#pragma unroll
+      for (int hc = 0; hc < HN; ++hc) acc[hc][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bq[hc * NN_SLR * 16], acc[hc][u], 0, 0, 0);
+    }
+#pragma unroll
+    for (int hc = 0; hc < HN; ++hc)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[hc][u][r];
+        asm volatile("" : "+v"(v));  // keep MFMA results out of AGPR-sourced stores (see lds_matmul)
+        acc[hc][u][r] = v;
+      }
+  }
+}
+// xtr_hc[a][jl] = sum_n x[n][a] dpre_hc[n][jl] for the a-tile ti, hc < HN  (np is a multiple of 16: two k-steps per trip)
+template <int HN>
+__device__ __forceinline__ void nn_grad_gemm_xtr(const float* X, const float* SL, const LinGeom g, int lane, int ti, f32x4 (&t)[NN_HC]) {
+#pragma unroll
+  for (int hc = 0; hc < HN; ++hc) t[hc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* ap = X + (lane >> 4) * g.ldx + ti * 16 + (lane & 15);
+  const float* bq = SL + (lane >> 4) * 16 + (lane & 15);
+  const int st = 4 * g.ldx;
+  for (int k0 = 0; k0 < g.np; k0 += 8) {
+    const float a0 = ap[0], a1 = ap[st];
+    float b0[HN], b1[HN];
+#pragma unroll
+    for (int hc = 0; hc < HN; ++hc) {
+      b0[hc] = bq[hc * NN_SLR * 16];
+      b1[hc] = bq[hc * NN_SLR * 16 + 64];
+    }
+#pragma unroll
+    for (int hc = 0; hc < HN; ++hc) t[hc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[hc], t[hc], 0, 0, 0);
+#pragma unroll
+    for (int hc = 0; hc < HN; ++hc) t[hc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[hc], t[hc], 0, 0, 0);
+    ap += 2 * st;
+    bq += 128;
+  }
+#pragma unroll
+  for (int hc = 0; hc < HN; ++hc)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = t[hc][r];
+      asm volatile("" : "+v"(v));
+      t[hc][r] = v;
+    }
+}
+#define NN_HN_SWITCH(hn_, CALL)      \
+  switch (hn_) {                     \
+    case 1: { constexpr int HN = 1; CALL; } break; \
+    case 2: { constexpr int HN = 2; CALL; } break; \
+    case 3: { constexpr int HN = 3; CALL; } break; \
+    case 4: { constexpr int HN = 4; CALL; } break; \
+    case 5: { constexpr int HN = 5; CALL; } break; \
+    case 6: { constexpr int HN = 6; CALL; } break; \
+    case 7: { constexpr int HN = 7; CALL; } break; \
+    default: { constexpr int HN = 8; CALL; } break; \
+  }
 
 #ifdef DIBS_NN_STAMPS
-static __device__ unsigned long long g_nn_stamps[64];
+static __device__ unsigned long long g_nn_stamps[128];
 #define NN_ST(k)                                                        \
   do {                                                                  \
     if (tid == 0) {                                                     \
       const unsigned long long t_ = wall_clock64();                     \
-      atomicAdd(&g_nn_stamps[(mode & 3) * 16 + (k)], t_ - st_prev);     \
+      atomicAdd(&g_nn_stamps[(mode & 3) * 32 + (k)], t_ - st_prev);     \
       st_prev = t_;                                                     \
     }                                                                   \
   } while (0)
 #else
 #define NN_ST(k)
 #endif
-template <int NT, int ACT = -1, int NW = 4>   // ACT >= 0: compile-time activation (relu), as in k_nn_logprobs
+template <int ACT = -1, int NW = 4>   // ACT >= 0: compile-time activation (relu), as in k_nn_logprobs; NW waves (8 when one block fills a CU's LDS)
 __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x, const int32_t* __restrict__ mask,
                                                  const float* __restrict__ theta, size_t P, const float* __restrict__ scores,
                                                  const uint32_t* __restrict__ thr, const float* __restrict__ logprobs,
@@ -478,23 +594,24 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
                                                  const float* __restrict__ baseline, float* __restrict__ baseline_out, Key2 carry,
                                                  int mode, int m0, int M_global, int d, int N, int S, float alpha, float tau,
                                                  int layout, int tiny, NNParams np_, double sf_baseline, int any_mask, GradSplit gs,
-                                                 const float* __restrict__ w1t) {
+                                                 const float* __restrict__ w1t, const float* __restrict__ ln_tab, int NT, int hcs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const LinGeom g = lin_geom(d, N, NT);
-  constexpr int NU = 8 / NW, NUD = (NT + NW - 1) / NW, NTHR = 64 * NW;  // row tiles per wave (np / 16 <= 8), column-of-x tiles per wave
+  constexpr int NU = 8 / NW, NUDM = (7 + NW - 1) / NW, NTHR = 64 * NW, HC = NN_HC;  // row tiles per wave (np / 16 <= 8), a-tiles per wave (NT <= 7)
+  const int H = np_.H;  // hcs <= HC: hidden units per group (launcher: nn_grad_hcs)
   float* X = smem;
   float* GS = X + (size_t)g.np * g.ldx;
-  float* TW = GS + (size_t)d * d;                  // T_h [kp][ldw] (forward operand) ...
-  float* RS = TW;                                  // ... and dpre_h [np][ldw] (backward operand), same storage
-  float* CS = TW + (size_t)nn_tr_rows(g) * g.ldw;  // per-wave column sums [NW][ldw]
-  double* red = reinterpret_cast<double*>(smem + ((((size_t)g.np * g.ldx + (size_t)d * d + (size_t)nn_tr_rows(g) * g.ldw + (size_t)2 * NW * g.ldw) + 3) & ~(size_t)3));
+  float* SL = GS + (size_t)d * d;         // T slices [hc][a < kp][16] and, after a barrier, dpre slices [hc][n < np][16]; NN_SLR rows apart
+  float* CS = SL + (size_t)hcs * NN_SLR * 16;  // per-wave column sums of dmean [NW][16]
+  float* CS2 = CS + 8 * 16;                 // per-wave column sums of dm h / dpre [hc][2][NW][16]
+  const size_t lds_floats = nn_grad_lds_floats(d, N, NT, hcs);
+  double* red = reinterpret_cast<double*>(smem + ((lds_floats + 3) & ~(size_t)3));
   // grid = (Mloc, shares); block (x, y) takes share y of particle (x + y) mod Mloc.  Workgroups go to the 8 XCDs round-robin by their linear
   // id x + Mloc y: with particle = x every share of particle m ran on XCD m mod 8, and the XCD that held the particles with the most weighted
   // samples set the time (150 of 256 CUs busy, 18 ms instead of 8 at config 5 / step 300); rotated by y, a particle's shares land on all
   // XCDs, and row y = 0 -- the only shares with work early in a run -- is still dispatched first.
   const int m = (int)((blockIdx.x + blockIdx.y) % gridDim.x), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t dd = (size_t)d * d;
-  const int H = np_.H;
   const NNOff off = nn_offsets(d, H, np_.bias);
   const float* th_m = theta + (size_t)m * P;
   float* const om_final = out + (size_t)m * out_stride;
@@ -503,6 +620,8 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
   const float* lp = logprobs + (size_t)m * S;
   // softmax statistics and this block's share of the samples with a non-zero weight (GradSplit, kernels_joint.h)
   __shared__ float wch[GRAD_WCH];
+  __shared__ unsigned short lst[GRAD_WCH];
+  __shared__ int lst_n[2];
   __shared__ int last_flag;
   double mx, den, sm;
   int nnz;
@@ -512,63 +631,92 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
   grad_softmax_stats<NW>(lp, S, red, mx, den, sm, nnz);
   const int NS = gridDim.y, bz = blockIdx.y, nact = nnz < NS ? (nnz > 0 ? nnz : 1) : NS;
   if (bz >= nact) return;  // (block-uniform: no share -- before anything is staged)
+  NN_ST(14);
   for (int e = tid; e < g.np * g.ldx; e += NTHR) {
     const int n = e / g.ldx, c = e - n * g.ldx;
     X[e] = (n < N && c < d) ? x[(size_t)n * d + c] : 0.f;
   }
-  for (int e = tid; e < 2 * NW * g.ldw; e += NTHR) CS[e] = 0.f;  // [0]: sum_n dmean / dm h, [1]: sum_n dpre (per wave)
-  float* const CS1 = CS + NW * g.ldw;
-  for (int e = tid; e < nn_tr_rows(g) * g.ldw; e += NTHR) TW[e] = 0.f;  // (operand padding: see nn_grad_build_tw)
-  // the accumulation row: the output itself while one block does everything, else this block's partial sums
-  // outputs start at zero (theta mode: P entries; z modes: d*d)
-  // Several blocks (split): the theta estimator's first-layer gradient -- d*d*H values that every sample updates -- is accumulated in THREAD
-  // layout ([slot][thread]: one coalesced read-modify-write per value; in theta's own layout a wave's 64 values lie 4 d H bytes apart, and
-  // with hundreds of partial rows in flight the 64-byte sectors of those updates came from HBM: 24 ms per launch at config 5, step 300);
-  // the small leaves follow behind it in theta's layout.  The Z modes accumulate d*d values in W's layout (16 consecutive floats per row).
+  NN_ST(15);
+  // Where things accumulate.  theta mode: the first-layer gradient always in this block's partial row (thread layout, w1sz floats); the small
+  // leaves b1 | W2 | b2 behind it when several blocks share the particle, else in the output itself.  Z modes: d*d values in W's layout, in
+  // the partial row (shared) or the output.
   const bool split = nact > 1;
   const size_t n_out = mode == LIN_MODE_THETA ? P : dd;
-  const size_t w1sz = (size_t)H * NUD * NT * 4 * NTHR;  // thread-layout area of the first-layer gradient
-  float* const prow = split ? gs.part + ((size_t)m * NS + bz) * gs.stride : nullptr;
-  // `om`: where the values in theta's / W's layout accumulate (split + theta mode: only the small leaves, behind the thread-layout area)
-  float* const om = !split ? om_final : (mode == LIN_MODE_THETA ? prow + w1sz - off.b1 : prow);
-  if (split && mode == LIN_MODE_THETA) {
-    for (size_t e = tid; e < w1sz + (P - off.b1); e += NTHR) prow[e] = 0.f;
+  const size_t w1sz = (size_t)NT * NUDM * H * 4 * NTHR;  // slots ((tj NUDM + u) H + h) 4 + r, see the x^T dpre epilogue
+  float* const prow = gs.part + ((size_t)m * NS + bz) * gs.stride;
+  float* const om = mode == LIN_MODE_THETA ? (split ? prow + w1sz - off.b1 : om_final) : (split ? prow : om_final);
+  if (mode == LIN_MODE_THETA) {
+    for (size_t e = tid; e < w1sz; e += NTHR) prow[e] = 0.f;
+    for (size_t e = off.b1 + tid; e < P; e += NTHR) om[e] = 0.f;
   } else {
-    for (size_t e = tid; e < n_out; e += NTHR) om[e] = 0.f;
+    for (size_t e = tid; e < dd; e += NTHR) om[e] = 0.f;
   }
+  NN_ST(6);
   const float inv_on = 1.0f / np_.obs_noise;
   const float inv_sp2 = 1.0f / (np_.sig_param * np_.sig_param);
   const float* sc_m = scores + (size_t)m * dd;
   const uint32_t* thr_m = thr + (size_t)m * dd;
+  const float* w1t_m = w1t ? w1t + (size_t)m * H * dd : nullptr;
   const int nrt = g.np >> 4;
   const bool fastg = layout == 0 && (S & 1) == 0 && (uint64_t)S * dd < 0xFFFFFFFFull;  // (block-uniform)
   const TfKeys tk = tf_keys(key);
-  // which of the lane's output elements are observations that count (not padding, not intervened on): one bit each
+  // which of the lane's output elements are observations that count (not padding, not intervened on): bit tj*4 + r of okb[u]
   uint32_t okb[NU];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     okb[u] = 0u;
 #pragma unroll
-    for (int tj = 0; tj < NT; ++tj)
+    for (int tj = 0; tj < 7; ++tj)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = (wave + NW * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
-        const bool v = n < N && j < d && wave + NW * u < nrt && !(any_mask && mask[(size_t)n * d + j]);
+        const bool v = tj < NT && n < N && j < d && wave + NW * u < nrt && !(any_mask && mask[(size_t)n * d + j]);
         okb[u] |= (uint32_t)v << (tj * 4 + r);
       }
   }
-  static_assert(NT * 4 <= 32, "validity bits of a row tile");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zeroed rows are in place before another wave adds to them (barriers below)
+  const int jl = lane & 15;
+  NN_ST(5);
 
-  int q = 0;  // ordinal of the next sample with a non-zero weight
+  // This block's samples of a chunk are listed first (wave 0, ballots) and the heavy loop runs over the list: a scan over all S samples
+  // with the per-sample state live across it paid the loop's register spills on every skipped sample (1.8 us each: 230 us per block at
+  // config 5, more than the gradient of a sample -- profiles/round6_nn_grad_phases.txt).
+  int q = 0;  // weighted samples before this chunk (block-uniform)
   for (int s0 = 0; s0 < S; s0 += GRAD_WCH) {
     __syncthreads();
     if (tid < GRAD_WCH && s0 + tid < S) wch[tid] = (float)(exp((double)lp[s0 + tid] - mx) / den);
     __syncthreads();
-  for (int s = s0; s < S && s < s0 + GRAD_WCH; ++s) {
-    const float w = wch[s - s0];
-    if (w < GRAD_W_MIN) continue;  // block-uniform
-    if ((q++ % NS) != bz) continue;  // (another block's sample)
+    NN_ST(18);
+    if (wave == 0) {
+      int cnt = 0, qq = q;
+      for (int i0 = 0; i0 < GRAD_WCH; i0 += 64) {
+        const int i = i0 + lane;
+        const float wv = s0 + i < S ? wch[i] : 0.f;
+        const bool has = wv >= GRAD_W_MIN;
+        const unsigned long long hb = __ballot(has), lt = (1ull << lane) - 1ull;
+        const int ord = qq + __popcll(hb & lt);
+        const bool mine = has && (ord % NS) == bz;
+        const unsigned long long mb = __ballot(mine);
+        if (mine) {  // (in place: position <= i, and the wave has read its 64 entries before it writes)
+          const int p = cnt + __popcll(mb & lt);
+          wch[p] = wv;
+          lst[p] = (unsigned short)i;
+        }
+        cnt += __popcll(mb);
+        qq += __popcll(hb);
+      }
+      if (lane == 0) {
+        lst_n[0] = cnt;
+        lst_n[1] = qq;
+      }
+    }
+    __syncthreads();
+    const int nmine = lst_n[0];
+    q = lst_n[1];
+    NN_ST(19);
+  for (int k = 0; k < nmine; ++k) {
+    const int s = s0 + lst[k];
+    const float w = wch[k];
     __syncthreads();
     NN_ST(0);
     if (fastg) nn_grad_build_graph<true>(GS, mode, key, tk, nbits, s, S, thr_m, sc_m, alpha, tau, layout, tiny, d, tid, NTHR);
@@ -576,190 +724,280 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
     __syncthreads();
     NN_ST(1);
 #ifdef DIBS_NN_STAMPS
-    if (tid == 0) atomicAdd(&g_nn_stamps[(mode & 3) * 16 + 12], 1ull);
+    if (tid == 0) atomicAdd(&g_nn_stamps[(mode & 3) * 32 + 12], 1ull);
 #endif
     if (mode == LIN_MODE_Z_SCORE) {
       for (int e = tid; e < (int)dd; e += NTHR) om[e] += w * GS[e];
       continue;
     }
-    // ---- forward: mean ----
-    f32x4 macc[NU][NT];
+    for (int tj = 0; tj < NT; ++tj) {
+      const int j = tj * 16 + jl;
+      const bool jok = j < d;
+      f32x4 hv[HC][NU];  // act(pre_h + b1) of the lane's elements, all hidden units of a group
+      f32x4 macc[NU];
 #pragma unroll
-    for (int u = 0; u < NU; ++u)
+      for (int u = 0; u < NU; ++u) macc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      float w2v[HC];  // second-layer weights of the lane's node for the current group (requested ahead of the products)
+      const float b2 = (np_.bias && jok) ? th_m[off.b2 + j] : 0.f;
+      f32x4 zs[NUDM];  // Z estimator: sum_h W1 xtr_h of the lane's elements
 #pragma unroll
-      for (int tj = 0; tj < NT; ++tj) macc[u][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int h = 0; h < H; ++h) {
-      __syncthreads();
-      if (w1t) nn_grad_build_tw<8>(TW, GS, w1t + ((size_t)m * H + h) * dd, g, tid, NTHR);
-      else nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid, NTHR);
-      __syncthreads();
-      NN_ST(2);
-      f32x4 acc[NU][NT];
-      nn_gemm_x_tw<NT, NU, NW>(X, TW, g, lane, wave, acc);
-      NN_ST(3);
+      for (int u = 0; u < NUDM; ++u) zs[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // The bodies are instantiated per group size HN (generic lambdas; NN_HN_SWITCH picks one): every hidden-unit loop is unrolled over
+      // exactly the units that exist, so no register is held for an absent one.
+      // ---- forward for the group h0 .. h0+HN-1: slices, products, activations (into hv), mean ----
+      auto fwd = [&](auto hnc, const int h0) {
+        constexpr int HN = decltype(hnc)::value;
+        __syncthreads();  // the slices' last readers (previous tile's x^T dpre, previous group) are done
+        nn_grad_build_slices<8>(SL, GS, w1t_m, th_m, H, h0, HN, tj, g, tid, NTHR);
+        float b1v[HN];
 #pragma unroll
-      for (int u = 0; u < NU; ++u)
+        for (int hc = 0; hc < HN; ++hc) {
+          b1v[hc] = (np_.bias && jok) ? th_m[off.b1 + (size_t)j * H + h0 + hc] : 0.f;
+          w2v[hc] = jok ? th_m[off.w2 + (size_t)j * H + h0 + hc] : 0.f;
+        }
+        __syncthreads();
+        NN_ST(2);
+        nn_grad_gemm_fwd<HN, NU, NW>(X, SL, g, lane, wave, hv);
 #pragma unroll
-        for (int tj = 0; tj < NT; ++tj) {
-          const int j = tj * 16 + (lane & 15);
-          if (j < d && wave + NW * u < nrt) {
-            const float b1 = np_.bias ? th_m[off.b1 + (size_t)j * H + h] : 0.f;
-            const float w2 = th_m[off.w2 + (size_t)j * H + h];
+        for (int hc = 0; hc < HN; ++hc)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) macc[u][tj][r] += w2 * nn_act(ACT >= 0 ? ACT : np_.act, acc[u][tj][r] + b1);
+          for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float a_ = nn_act(ACT >= 0 ? ACT : np_.act, hv[hc][u][r] + b1v[hc]);
+              hv[hc][u][r] = a_;
+              macc[u][r] = fmaf(w2v[hc], a_, macc[u][r]);
+            }
+        NN_ST(3);
+      };
+      // ---- backward for the group: dpre slices, column sums, small leaves, x^T dpre, gradient terms ----
+      auto bwd = [&](auto hnc, const int h0, const bool again) {
+        constexpr int HN = decltype(hnc)::value;
+        if (again) {  // (more hidden units than a group holds: this group's activations again)
+          __syncthreads();
+          nn_grad_build_slices<8>(SL, GS, w1t_m, th_m, H, h0, HN, tj, g, tid, NTHR);
+          float b1v[HN];
+#pragma unroll
+          for (int hc = 0; hc < HN; ++hc) {
+            b1v[hc] = (np_.bias && jok) ? th_m[off.b1 + (size_t)j * H + h0 + hc] : 0.f;
+            w2v[hc] = jok ? th_m[off.w2 + (size_t)j * H + h0 + hc] : 0.f;
+          }
+          __syncthreads();
+          nn_grad_gemm_fwd<HN, NU, NW>(X, SL, g, lane, wave, hv);
+#pragma unroll
+          for (int hc = 0; hc < HN; ++hc)
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) hv[hc][u][r] = nn_act(ACT >= 0 ? ACT : np_.act, hv[hc][u][r] + b1v[hc]);
+        }
+        __syncthreads();  // every wave is done reading the T slices: their storage now takes dpre
+        NN_ST(5);
+#pragma unroll
+        for (int hc = 0; hc < HN; ++hc) {
+          float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int n = (wave + NW * u) * 16 + (lane >> 4) * 4 + r;
+              if (wave + NW * u < nrt) {
+                const float a_ = hv[hc][u][r], dm = macc[u][r];
+                // act' from the activation value alone (relu / leaky relu: sign(h) = sign(pre); tanh: 1 - h^2; sigmoid: h (1 - h))
+                const float dp = dm * w2v[hc] * nn_dact(ACT >= 0 ? ACT : np_.act, a_, a_);
+                SL[(hc * NN_SLR + n) * 16 + jl] = dp;
+                t1 += dp;        // for d/db1
+                t2 += dm * a_;   // for d/dW2
+              }
+            }
+          t1 += __shfl_xor(t1, 16);
+          t1 += __shfl_xor(t1, 32);
+          t2 += __shfl_xor(t2, 16);
+          t2 += __shfl_xor(t2, 32);
+          if (lane < 16) {
+            CS2[((hc * 2 + 0) * 8 + wave) * 16 + lane] = t2;
+            CS2[((hc * 2 + 1) * 8 + wave) * 16 + lane] = t1;
           }
         }
-    }
-    NN_ST(4);
-    // dmean = (1 - mask) (x - mean) / obs_noise  (kept in registers, C layout; zero on padding rows / columns)
-#pragma unroll
-    for (int tj = 0; tj < NT; ++tj) {
-      float t = 0.f;
-      const float b2 = (np_.bias && tj * 16 + (lane & 15) < d) ? th_m[off.b2 + tj * 16 + (lane & 15)] : 0.f;
-#pragma unroll
-      for (int u = 0; u < NU; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = (wave + NW * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
-          float dm = 0.f;
-          if ((okb[u] >> (tj * 4 + r)) & 1u) dm = (X[n * g.ldx + j] - macc[u][tj][r] - b2) * inv_on;
-          macc[u][tj][r] = dm;
-          t += dm;
+        __syncthreads();
+        NN_ST(7);
+        if (mode == LIN_MODE_THETA) {  // small leaves: column sums by wave, added in wave order
+          for (int i = tid; i < HN * 16; i += NTHR) {
+            const int hc = i >> 4, j2 = tj * 16 + (i & 15);
+            if (j2 < d) {
+              float s2 = 0.f, s1 = 0.f;
+              for (int wv_ = 0; wv_ < NW; ++wv_) {
+                s2 += CS2[((hc * 2 + 0) * 8 + wv_) * 16 + (i & 15)];
+                s1 += CS2[((hc * 2 + 1) * 8 + wv_) * 16 + (i & 15)];
+              }
+              nn_acc(om + off.w2 + (size_t)j2 * H + h0 + hc, w * s2);
+              if (np_.bias) nn_acc(om + off.b1 + (size_t)j2 * H + h0 + hc, w * s1);
+            }
+          }
+          if (h0 == 0 && np_.bias && tid >= NTHR - 16) {  // d/db2_j = sum_n dmean_nj
+            const int c = tid - (NTHR - 16), j2 = tj * 16 + c;
+            if (j2 < d) {
+              float sb = 0.f;
+              for (int wv_ = 0; wv_ < NW; ++wv_) sb += CS[wv_ * 16 + c];
+              nn_acc(om + off.b2 + j2, w * sb);
+            }
+          }
         }
-      t += __shfl_xor(t, 16);
-      t += __shfl_xor(t, 32);
-      if (lane < 16) CS[wave * g.ldw + tj * 16 + lane] = t;
-    }
-    __syncthreads();
-    if (mode == LIN_MODE_THETA && np_.bias)
-      for (int j = tid; j < d; j += NTHR)  // d/db2_j = sum_n dmean_nj
-        nn_acc(om + off.b2 + j, w * nn_cs_sum<NW>(CS, g.ldw, j));
-    // ---- backward, one hidden unit at a time ----
-    for (int h = 0; h < H; ++h) {
-      __syncthreads();
-      NN_ST(5);
-      if (w1t) nn_grad_build_tw<8>(TW, GS, w1t + ((size_t)m * H + h) * dd, g, tid, NTHR);
-      else nn_build_tw<false>(TW, GS, th_m, h, H, np_.sig_param, g, tid, NTHR);
-      __syncthreads();
-      NN_ST(6);
-      f32x4 acc[NU][NT];
-      nn_gemm_x_tw<NT, NU, NW>(X, TW, g, lane, wave, acc);
-      __syncthreads();  // every wave is done reading T_h: its storage now takes dpre_h
-      NN_ST(7);
+        NN_ST(8);
+        // xtr_h[a][j] = sum_n x[n][a] dpre_h[n][j]  (d/dT_h), a-tiles ti = wave + NW u
 #pragma unroll
-      for (int tj = 0; tj < NT; ++tj) {
-        const int j = tj * 16 + (lane & 15);
-        const float b1 = (np_.bias && j < d) ? th_m[off.b1 + (size_t)j * H + h] : 0.f;
-        const float w2 = j < d ? th_m[off.w2 + (size_t)j * H + h] : 0.f;
-        float t2 = 0.f, t1 = 0.f;
+        for (int u = 0; u < NUDM; ++u) {
+          const int ti = wave + NW * u;
+          if (ti >= NT) continue;
+          // the first-layer weights of the lane's elements: requested before the product, used after it (one trip past the L2 per tile
+          // instead of one per element).  32-bit element indices off the particle's base pointer.
+          float gvr[4];
+          f32x4 w1v[HN];
+          const int a0 = ti * 16 + (lane >> 4) * 4;
+          const uint32_t wi = (uint32_t)h0 * (uint32_t)dd + (uint32_t)a0 * (uint32_t)d + (uint32_t)j;                       // W1T[h0][a0][j]
+          const uint32_t ti_ = ((uint32_t)j * (uint32_t)d + (uint32_t)a0) * (uint32_t)H + (uint32_t)h0;                     // W1[j][a0][h0]
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            gvr[r] = (a0 + r < d && jok) ? GS[(a0 + r) * d + j] : 0.f;
+#pragma unroll
+            for (int hc = 0; hc < HN; ++hc)
+              w1v[hc][r] = gvr[r] == 0.f ? 0.f : (w1t_m ? w1t_m[wi + (uint32_t)hc * (uint32_t)dd + (uint32_t)(r * d)] : th_m[ti_ + (uint32_t)(r * H + hc)]);
+          }
+          f32x4 t[HC];
+          nn_grad_gemm_xtr<HN>(X, SL, g, lane, ti, t);
+          NN_ST(9);
+          // partial-row slot of element (tj, u, h, r): ((tj NUDM + u) H + h) 4 + r  (thread layout: slot * NTHR + tid)
+          const uint32_t s0_ = ((uint32_t)(tj * NUDM + u) * (uint32_t)H + (uint32_t)h0) * 4u * NTHR + (uint32_t)tid;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (gvr[r] == 0.f) continue;  // no term (hard graphs late in a run: a few per cent of the entries are edges)
+#pragma unroll
+            for (int hc = 0; hc < HN; ++hc) {
+              if (mode == LIN_MODE_THETA) nn_acc(prow + (s0_ + (uint32_t)((hc * 4 + r) * NTHR)), w * gvr[r] * (t[hc][r] - w1v[hc][r] * inv_sp2));
+              else zs[u][r] = fmaf(w1v[hc][r], t[hc][r], zs[u][r]);
+            }
+          }
+          NN_ST(10);
+        }
+      };
+      for (int h0 = 0; h0 < H; h0 += hcs) {
+        const int hn = H - h0 < hcs ? H - h0 : hcs;
+        NN_HN_SWITCH(hn, (fwd(std::integral_constant<int, HN>{}, h0)));
+      }
+      // ---- dmean = (1 - mask) (x - mean) / obs_noise (registers, C layout; zero on padding rows / columns) ----
+      {
+        float t = 0.f;
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int n = (wave + NW * u) * 16 + (lane >> 4) * 4 + r;
-            if (n < g.np && wave + NW * u < nrt) {
-              const float pre = acc[u][tj][r] + b1;
-              const float hv = nn_act(ACT >= 0 ? ACT : np_.act, pre);
-              const float dm = macc[u][tj][r];
-              const float dp = dm * w2 * nn_dact(ACT >= 0 ? ACT : np_.act, pre, hv);  // dpre
-              RS[n * g.ldw + j] = dp;
-              t1 += dp;                                                   // for d/db1
-              t2 += dm * hv;                                              // for d/dW2
-            }
+            float dm = 0.f;
+            if ((okb[u] >> (tj * 4 + r)) & 1u) dm = (X[n * g.ldx + j] - macc[u][r] - b2) * inv_on;
+            macc[u][r] = dm;
+            t += dm;
           }
-        t2 += __shfl_xor(t2, 16);
-        t2 += __shfl_xor(t2, 32);
-        t1 += __shfl_xor(t1, 16);
-        t1 += __shfl_xor(t1, 32);
-        if (lane < 16) {
-          CS[wave * g.ldw + j] = t2;
-          CS1[wave * g.ldw + j] = t1;
-        }
+        t += __shfl_xor(t, 16);
+        t += __shfl_xor(t, 32);
+        if (lane < 16) CS[wave * 16 + lane] = t;
       }
-      __syncthreads();
-      NN_ST(8);
-      if (mode == LIN_MODE_THETA)
-        for (int j = tid; j < d; j += NTHR) {  // (column sums of dpre / dm h by wave, added in wave order)
-          if (np_.bias) nn_acc(om + off.b1 + (size_t)j * H + h, w * nn_cs_sum<NW>(CS1, g.ldw, j));
-          nn_acc(om + off.w2 + (size_t)j * H + h, w * nn_cs_sum<NW>(CS, g.ldw, j));
-        }
-      NN_ST(9);
-      // xtr[a][j] = sum_n x[n][a] dpre[n][j]  (d/dT_h)
+      NN_ST(4);
+      for (int h0 = 0; h0 < H; h0 += hcs) {
+        const int hn = H - h0 < hcs ? H - h0 : hcs;
+        NN_HN_SWITCH(hn, (bwd(std::integral_constant<int, HN>{}, h0, H > hcs)));
+      }
+      if (mode == LIN_MODE_Z_REPARAM) {
 #pragma unroll
-      for (int u = 0; u < NUD; ++u) {
-        const int ti = wave + NW * u;
-        if (ti >= NT) continue;  // (not `break`: keeps the trip count constant so the loop unrolls)
-        f32x4 t[NT];
-#pragma unroll
-        for (int tj = 0; tj < NT; ++tj) t[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int ap = (lane >> 4) * g.ldx + ti * 16 + (lane & 15);
-        const int bq = (lane >> 4) * g.ldw + (lane & 15);
-        for (int k0 = 0; k0 < g.np; k0 += 4) {
-          const float a = X[ap + k0 * g.ldx];
-#pragma unroll
-          for (int tj = 0; tj < NT; ++tj) t[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, RS[bq + k0 * g.ldw + tj * 16], t[tj], 0, 0, 0);
-        }
-        NN_ST(10);
-#pragma unroll
-        for (int tj = 0; tj < NT; ++tj)
+        for (int u = 0; u < NUDM; ++u) {
+          const int ti = wave + NW * u;
+          if (ti >= NT) continue;
+          float lnv[4];  // sum_h logN(W1[j][a][h]; 0, sig_p): the particle's prior table, if there is one
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int a = ti * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
-            if (a < d && j < d) {
-              float xtr = t[tj][r];
-              asm volatile("" : "+v"(xtr));
-              const float gv = GS[a * d + j];
-              if (gv == 0.f) continue;  // no term (hard graphs late in a run: a few per cent of the entries are edges)
-              const float w1 = w1t ? w1t[((size_t)m * H + h) * dd + (size_t)a * d + j] : th_m[((size_t)j * d + a) * H + h];
-              if (mode == LIN_MODE_THETA) {
-                const float v = w * gv * (xtr - w1 * inv_sp2);
-                if (split) nn_acc(prow + (size_t)(((h * NUD + u) * NT + tj) * 4 + r) * NTHR + tid, v);
-                else nn_acc(om + ((size_t)j * d + a) * H + h, v);
-              } else if (a != j) {
-                nn_acc(om + a * d + j, w * (lin_logn(w1, 0.f, np_.sig_param) + w1 * xtr) * tau * alpha * gv * (1.0f - gv));
-              }
-            }
+            const int a = ti * 16 + (lane >> 4) * 4 + r;
+            const bool ok = a < d && jok && a != j;
+            lnv[r] = 0.f;
+            if (ok && ln_tab) lnv[r] = ln_tab[(size_t)m * dd + (size_t)a * d + j];
+            if (ok && !ln_tab)
+              for (int h = 0; h < H; ++h) lnv[r] += lin_logn(th_m[((size_t)j * d + a) * H + h], 0.f, np_.sig_param);
           }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int a = ti * 16 + (lane >> 4) * 4 + r;
+            if (a >= d || !jok || a == j) continue;
+            const float gv = GS[a * d + j];
+            nn_acc(om + a * d + j, w * (lnv[r] + zs[u][r]) * tau * alpha * gv * (1.0f - gv));
+          }
+        }
+        NN_ST(11);
       }
-      NN_ST(11);
     }
   }
   }
+  NN_ST(20);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's adds have been performed
+  NN_ST(16);
   __syncthreads();
-  NN_ST(0);
-  if (nact > 1) {
-    // release the partial sums, count this block, and the LAST block of the particle
-    // adds the rows in block order into the output
+  NN_ST(17);
+  if (split) {
+    // release the partial sums, count this block, and the LAST block of the particle adds the rows in block order into the output
     __threadfence();
     if (!grad_last_block(gs.ctr + m, nact, &last_flag)) return;
     __threadfence();
-    const float* const base = gs.part + (size_t)m * NS * gs.stride;
-    if (mode == LIN_MODE_THETA) {
+  }
+  const float* const base = gs.part + (size_t)m * NS * gs.stride;
+  if (mode == LIN_MODE_THETA) {
+    // first-layer gradient: thread layout -> theta's layout [j][a][h], as many column tiles at a time as LDS holds (X, GS, the slices are dead)
+    const int tpc = (int)(lds_floats / ((size_t)16 * d * H));
+    if (tpc >= 1) {
+      for (int tj0 = 0; tj0 < NT; tj0 += tpc) {
+        const int tj1 = tj0 + tpc < NT ? tj0 + tpc : NT;
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int u = 0; u < NUDM; ++u) {
+            const int ti = wave + NW * u;
+            if (ti >= NT) continue;
+            for (int tj = tj0; tj < tj1; ++tj)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int a = ti * 16 + (lane >> 4) * 4 + r, j = tj * 16 + jl;
+                if (a < d && j < d) {
+                  const size_t slot = (size_t)(((tj * NUDM + u) * H + h) * 4 + r) * NTHR + tid;
+                  smem[((size_t)(j - 16 * tj0) * d + a) * H + h] = grad_part_sum<GRAD_NS_NN, false>(base, gs.stride, slot, nact);
+                }
+              }
+          }
+        __syncthreads();
+        const int nj = (d - 16 * tj0) < 16 * (tj1 - tj0) ? (d - 16 * tj0) : 16 * (tj1 - tj0);
+        const size_t cnt = (size_t)nj * d * H, o0 = (size_t)16 * tj0 * d * H;
+        for (size_t e = tid; e < cnt; e += NTHR) om_final[o0 + e] = smem[e];
+        __syncthreads();
+      }
+    } else {
       for (int h = 0; h < H; ++h)
 #pragma unroll
-        for (int u = 0; u < NUD; ++u) {
+        for (int u = 0; u < NUDM; ++u) {
           const int ti = wave + NW * u;
           if (ti >= NT) continue;
-#pragma unroll
           for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int a = ti * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
+              const int a = ti * 16 + (lane >> 4) * 4 + r, j = tj * 16 + jl;
               if (a < d && j < d) {
-                const size_t slot = (size_t)(((h * NUD + u) * NT + tj) * 4 + r) * NTHR + tid;
+                const size_t slot = (size_t)(((tj * NUDM + u) * H + h) * 4 + r) * NTHR + tid;
                 om_final[((size_t)j * d + a) * H + h] = grad_part_sum<GRAD_NS_NN, false>(base, gs.stride, slot, nact);
               }
             }
         }
+    }
+    if (split)
       for (size_t e = off.b1 + tid; e < P; e += NTHR)  // the small leaves
         om_final[e] = grad_part_sum<GRAD_NS_NN, false>(base, gs.stride, w1sz + (e - off.b1), nact);
-    } else {
-      for (size_t e = tid; e < n_out; e += NTHR) om_final[e] = grad_part_sum<GRAD_NS_NN, false>(base, gs.stride, e, nact);
-    }
-    __syncthreads();
-    NN_ST(13);
+  } else if (split) {
+    for (size_t e = tid; e < n_out; e += NTHR) om_final[e] = grad_part_sum<GRAD_NS_NN, false>(base, gs.stride, e, nact);
   }
+  __syncthreads();
+  NN_ST(13);
   // epilogue
   const float bold = baseline ? baseline[m] : 0.f;
   if (mode == LIN_MODE_THETA) {
@@ -778,6 +1016,7 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
   if (mode != LIN_MODE_THETA && baseline_out && tid == 0)
     baseline_out[m] = (mode == LIN_MODE_Z_SCORE) ? (float)(sf_baseline * (sm / S) + (1.0 - sf_baseline) * (double)bold) : bold;
 }
+
 
 // theta init with the stax key discipline (nonlinearGaussian.py:155-186; stax.serial / Dense of jax.example_libraries):
 // subkey(m, j) = row m*d+j of split(key, M*d); per stax layer: rng, layer_rng = split(rng) (the activation layer consumes
@@ -934,7 +1173,7 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
   // samples per block: the block's prologue (x and the small leaves into LDS, validity bits) is shared by them; 4 while that leaves at least
   // four rounds of blocks (config 5: spb 2 / 4 / 8 -> 51.2 / 53.0 / 53.1 steps/s)
   const int spb = (jl.S / 4) * jl.Mloc >= 1024 ? 4 : 2;
-  const size_t lds1 = nn_lds_bytes_logprobs(jl.d, jl.N, NT, np_.H), lds2 = nn_lds_bytes(jl.d, jl.N, NT, true);
+  const size_t lds1 = nn_lds_bytes_logprobs(jl.d, jl.N, NT, np_.H);
   float* lp = mode == LIN_MODE_THETA ? jl.logprobs_th : jl.logprobs_z;
   const size_t w1t_need = (size_t)jl.Mloc * np_.H * jl.d * jl.d;
   if (w->w1t_floats < w1t_need) {  // (first launch; optional: without it the kernel reads W1 in place)
@@ -964,23 +1203,25 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
   float* out = mode == LIN_MODE_THETA ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.gtheta_off : jl.w_lik;
   const size_t ostride = mode == LIN_MODE_THETA ? jl.pack_stride : (size_t)jl.d * jl.d;
   float* tcopy = (mode == LIN_MODE_THETA && jl.copy_theta) ? jl.pack + (size_t)jl.m0 * jl.pack_stride + jl.theta_off : nullptr;
-  GradSplit gs;  // (several blocks per particle once many samples keep a non-zero weight: kernels_joint.h; the row is P floats for theta, d*d for Z)
+  GradSplit gs;  // (several blocks per particle once many samples keep a non-zero weight: kernels_joint.h)
   // (partial row of a block: the first-layer gradient in thread layout + the small leaves for theta, d*d for Z; the shares per particle are
   //  cut back when GRAD_NS_NN rows per particle would exceed 4 GiB -- hidden widths in the dozens)
+  const int hcs = nn_grad_hcs(jl.d, jl.N, NT, np_.H);  // (> 0: joint_nn_fast_path)
+  const size_t lds2 = nn_grad_lds_bytes(jl.d, jl.N, NT, hcs);
   const bool wide = lds2 > 80 * 1024;  // one block per CU: 8 waves (see k_nn_grad)
-  const int nthr = wide ? 512 : 256, nud = wide ? (NT + 7) / 8 : (NT + 3) / 4;
-  const size_t row_theta = (size_t)np_.H * nud * NT * 4 * nthr + (P - (size_t)jl.d * jl.d * np_.H);
+  const int nthr = wide ? 512 : 256, nudm = wide ? 1 : 2;  // (k_nn_grad: NTHR, NUDM)
+  const size_t row_theta = (size_t)NT * nudm * np_.H * 4 * nthr + (P - (size_t)jl.d * jl.d * np_.H);
   const size_t row = row_theta > (size_t)jl.d * jl.d ? row_theta : (size_t)jl.d * jl.d;
   int ns_nn = GRAD_NS_NN;
   while (ns_nn > 1 && (size_t)jl.Mloc * ns_nn * row * 4 > ((size_t)4 << 30)) ns_nn >>= 1;
   if (!joint_grad_split(w, (size_t)jl.Mloc, row, &gs, ns_nn)) return;  // (the step's launch check reports the failed hipMalloc)
 #define NN_GRAD_LAUNCH(ACT_, NW_)                                                                                                              \
   {                                                                                                                                            \
-    if (lds2 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_grad<NT, ACT_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);   \
-    hipLaunchKernelGGL((k_nn_grad<NT, ACT_, NW_>), dim3(jl.Mloc, ns_nn), dim3(64 * NW_), lds2, jl.stream, w->x, w->mask, jl.theta, P, jl.scores,  \
+    if (lds2 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_grad<ACT_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);       \
+    hipLaunchKernelGGL((k_nn_grad<ACT_, NW_>), dim3(jl.Mloc, ns_nn), dim3(64 * NW_), lds2, jl.stream, w->x, w->mask, jl.theta, P, jl.scores,      \
                        jl.thr, lp, out, ostride, tcopy, jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode,    \
                        jl.m0, jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask, gs,                \
-                       w->ln_tab ? w->w1t : nullptr);                                                                                         \
+                       w->ln_tab ? w->w1t : nullptr, w->ln_tab, NT, hcs);                                                                     \
   }
   if (wide) {
     if (np_.act == 0) NN_GRAD_LAUNCH(0, 8) else NN_GRAD_LAUNCH(-1, 8)
@@ -993,15 +1234,16 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
 #ifdef DIBS_NN_STAMPS
 extern "C" void dibs_debug_nn_stamps(unsigned long long* out, int reset) {
   hipDeviceSynchronize();
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_stamps), sizeof(unsigned long long) * 64);
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_stamps), sizeof(unsigned long long) * 128);
   if (reset) {
-    unsigned long long z[64] = {0};
+    unsigned long long z[128] = {0};
     hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stamps), z, sizeof(z));
   }
 }
 #endif
 bool joint_nn_fast_path(int d, int N, const NNParams& np_) {
-  return np_.n_hidden == 1 && np_.H >= 1 && np_.H <= 64 && N <= 128 && d <= 112 && nn_lds_bytes(d, N, (d + 15) / 16, true) <= (size_t)160 * 1024 - 2048;  // (2 KiB for the static LDS of k_nn_grad)
+  return np_.n_hidden == 1 && np_.H >= 1 && np_.H <= 64 && N <= 128 && d <= 112 && nn_grad_hcs(d, N, (d + 15) / 16, np_.H) > 0 &&
+         nn_lds_bytes_logprobs(d, N, (d + 15) / 16, np_.H) <= (size_t)160 * 1024 - 512;
 }
 
 // scratch of the general path: grown on first use (activation records of the work items; see kernels_nn_generic.h)

@@ -11,15 +11,15 @@ cfg, x, mask = bench.make_workload(name, bench.CONFIGS[name]["M"])
 eng = Engine(cfg); eng.set_data(x, mask); eng.init_particles(random.PRNGKey(1))
 eng.run(0, t0)
 lib = C.CDLL(_lib.LIB_PATH)
-buf = (C.c_ulonglong * 64)()
+buf = (C.c_ulonglong * 128)()
 lib.dibs_debug_nn_stamps(buf, 1)
 n = 5
 eng.run(t0, n)
 lib.dibs_debug_nn_stamps(buf, 0)
-names = ["loop ctl / tail", "graph build", "fwd build T_h", "fwd gemm", "fwd epilogue", "dmean + b2 | bwd wait", "bwd build T_h", "bwd gemm",
-         "dpre store + col sums", "b1 / W2 leaves", "xtr gemm", "xtr epilogue (RMW)", "(samples)", "combine"]
+names = ["barrier in front of a sample", "graph build", "slices build (+ barrier)", "fwd gemm + activations", "dmean", "validity bits | wait: slices free", "zero rows", "dpre store + col sums",
+         "small leaves", "xtr gemm", "xtr epilogue (adds)", "Z epilogue", "(samples)", "combine", "softmax stats", "x -> LDS", "wait: own adds performed", "barrier after the samples", "weights of a chunk", "scan to the next own sample", "scan after the last sample"]
 for mode, mn in ((0, "theta"), (1, "z (reparam)"), (2, "z (score)")):
-    row = [buf[mode * 16 + k] for k in range(16)]
+    row = [buf[mode * 32 + k] for k in range(32)]
     ns = row[12]
     if not ns:
         continue
