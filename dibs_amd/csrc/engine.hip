@@ -708,6 +708,19 @@ extern "C" int dibs_engine_get_state(dibs_engine* e, float* z, float* v_z, float
 // kernels that may need more than the default 64 KiB of dynamic LDS (see launch.h).  One attribute call per (device, kernel) and size
 // increase, not one per launch; the table is shared by every engine of the process, so it is keyed by device and guarded by a mutex
 // (ctypes releases the GIL: two engines may be stepped from two host threads).
+int dibs_cu_count() {
+  static std::mutex mu;
+  static std::map<int, int> cus;
+  int dev = 0;
+  hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  int& n = cus[dev];
+  if (n == 0) {
+    hipDeviceProp_t prop;
+    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
 void dibs_allow_lds(const void* kernel, size_t bytes) {
   static std::mutex mu;
   static std::map<std::pair<int, const void*>, size_t> granted;

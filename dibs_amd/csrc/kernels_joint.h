@@ -31,6 +31,14 @@ struct GradSplit {
   size_t stride;
 };
 
+// work list of a persistent gradient kernel (k_grad_plan below): per job the softmax statistics of its samples, and the (job, share) items
+// that have at least one weighted sample
+struct GradPlan {
+  double* stats;        // [jobs][4]: maximum, sum of exponentials, sum of the log-probabilities, number of weighted samples
+  unsigned int* items;  // [<= jobs * shares]: job * 64 + share
+  unsigned int* ctr;    // [0]: number of items, [1]: next item to take
+};
+
 struct JointWork {
   float* x;        // [N, d] device copy
   int32_t* mask;   // [N, d]
@@ -63,6 +71,8 @@ struct JointWork {
   size_t gpart_floats;
   unsigned int* gctr;
   size_t gctr_n;
+  GradPlan gplan;     // persistent gradient kernels: statistics + item list, grown on first use
+  size_t gplan_jobs, gplan_items;
 };
 static inline float* joint_gs_scratch(JointWork* w, size_t floats) {
   if (w->gs_scratch_floats < floats) {
@@ -94,6 +104,23 @@ static inline bool joint_grad_split(JointWork* w, size_t jobs, size_t stride, Gr
     w->gctr_n = jobs;
   }
   *out = GradSplit{w->gpart, w->gctr, stride};
+  return true;
+}
+
+static inline bool joint_grad_plan(JointWork* w, size_t jobs, int ns, GradPlan* out) {
+  if (w->gplan_jobs < jobs || w->gplan_items < jobs * (size_t)ns) {
+    if (w->gplan.stats) hipFree(w->gplan.stats);
+    if (w->gplan.items) hipFree(w->gplan.items);
+    if (w->gplan.ctr) hipFree(w->gplan.ctr);
+    w->gplan = GradPlan{nullptr, nullptr, nullptr};
+    w->gplan_jobs = w->gplan_items = 0;
+    if (hipMalloc((void**)&w->gplan.stats, jobs * 4 * sizeof(double)) != hipSuccess) return false;
+    if (hipMalloc((void**)&w->gplan.items, jobs * (size_t)ns * 4) != hipSuccess) return false;
+    if (hipMalloc((void**)&w->gplan.ctr, 8) != hipSuccess) return false;
+    w->gplan_jobs = jobs;
+    w->gplan_items = jobs * (size_t)ns;
+  }
+  *out = w->gplan;
   return true;
 }
 
@@ -699,6 +726,28 @@ __device__ __forceinline__ void grad_softmax_stats(const float* __restrict__ lp,
   for (int w = 0; w < NW; ++w) cnt += red[2 * NW + w];
   nnz = (int)cnt;
 }
+// plan of a persistent gradient kernel: one wave per job computes the statistics and appends the job's shares that have work to the item
+// list (in arrival order -- nothing depends on the order: an item's partial row and its place in the sum are fixed by (job, share)).
+// grid = jobs, block = 64; ctr zeroed by the launcher.
+#ifdef DIBS_TU_NN
+__global__ void k_grad_plan(const float* __restrict__ logprobs, int S, int ns, GradPlan gp) {
+  __shared__ double red[4];
+  const int m = blockIdx.x;
+  double mx, den, sm;
+  int nnz;
+  grad_softmax_stats<1>(logprobs + (size_t)m * S, S, red, mx, den, sm, nnz);
+  if (threadIdx.x == 0) {
+    gp.stats[(size_t)m * 4 + 0] = mx;
+    gp.stats[(size_t)m * 4 + 1] = den;
+    gp.stats[(size_t)m * 4 + 2] = sm;
+    gp.stats[(size_t)m * 4 + 3] = (double)nnz;
+    const int nact = nnz < ns ? (nnz > 0 ? nnz : 1) : ns;
+    const unsigned int base = atomicAdd(gp.ctr, (unsigned int)nact);
+    for (int y = 0; y < nact; ++y) gp.items[base + y] = (unsigned int)m * 64u + (unsigned int)y;
+  }
+}
+#endif
+
 // the partial sums of this block are complete (stored with grad_part_store): count this block; true for the LAST of `nact` blocks, which
 // then reads all of them with grad_part_load.  `flag`: one int of LDS.
 __device__ __forceinline__ void grad_part_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -983,6 +1032,8 @@ int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) {
   w->gpart_floats = 0;
   w->gctr = nullptr;
   w->gctr_n = 0;
+  w->gplan = GradPlan{nullptr, nullptr, nullptr};
+  w->gplan_jobs = w->gplan_items = 0;
   w->nhf_w1s = w->nhf_w1p = nullptr;
   w->nhf_ew = nullptr;
   w->nhf_pairs = 0;
@@ -1013,6 +1064,11 @@ void joint_free(JointWork* w) {
   w->gpart = nullptr;
   w->gctr = nullptr;
   w->gpart_floats = w->gctr_n = 0;
+  if (w->gplan.stats) hipFree(w->gplan.stats);
+  if (w->gplan.items) hipFree(w->gplan.items);
+  if (w->gplan.ctr) hipFree(w->gplan.ctr);
+  w->gplan = GradPlan{nullptr, nullptr, nullptr};
+  w->gplan_jobs = w->gplan_items = 0;
   if (w->nhf_w1s) hipFree(w->nhf_w1s);
   if (w->nhf_w1p) hipFree(w->nhf_w1p);
   if (w->nhf_ew) hipFree(w->nhf_ew);

@@ -594,7 +594,8 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
                                                  const float* __restrict__ baseline, float* __restrict__ baseline_out, Key2 carry,
                                                  int mode, int m0, int M_global, int d, int N, int S, float alpha, float tau,
                                                  int layout, int tiny, NNParams np_, double sf_baseline, int any_mask, GradSplit gs,
-                                                 const float* __restrict__ w1t, const float* __restrict__ ln_tab, int NT, int hcs) {
+                                                 const float* __restrict__ w1t, const float* __restrict__ ln_tab, int NT, int hcs, GradPlan gp,
+                                                 int NS) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const LinGeom g = lin_geom(d, N, NT);
   constexpr int NU = 8 / NW, NUDM = (7 + NW - 1) / NW, NTHR = 64 * NW, HC = NN_HC;  // row tiles per wave (np / 16 <= 8), a-tiles per wave (NT <= 7)
@@ -605,36 +606,64 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
   float* CS = SL + (size_t)hcs * NN_SLR * 16;  // per-wave column sums of dmean [NW][16]
   float* CS2 = CS + 8 * 16;                 // per-wave column sums of dm h / dpre [hc][2][NW][16]
   const size_t lds_floats = nn_grad_lds_floats(d, N, NT, hcs);
-  double* red = reinterpret_cast<double*>(smem + ((lds_floats + 3) & ~(size_t)3));
-  // grid = (Mloc, shares); block (x, y) takes share y of particle (x + y) mod Mloc.  Workgroups go to the 8 XCDs round-robin by their linear
-  // id x + Mloc y: with particle = x every share of particle m ran on XCD m mod 8, and the XCD that held the particles with the most weighted
-  // samples set the time (150 of 256 CUs busy, 18 ms instead of 8 at config 5 / step 300); rotated by y, a particle's shares land on all
-  // XCDs, and row y = 0 -- the only shares with work early in a run -- is still dispatched first.
-  const int m = (int)((blockIdx.x + blockIdx.y) % gridDim.x), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // PERSISTENT blocks (one or two per CU) take work items (particle, share) off the plan's list (k_grad_plan, kernels_joint.h) until it is
+  // empty.  With one block per (particle, share) -- 4 096 at config 5, each needing the CU's whole LDS -- the 3 840 that have nothing to do
+  // early in a run queued behind the 256 that do, and every block paid the prologue (x into LDS, validity bits): 512 us per launch where the
+  // work of a block was 280.  An item's partial row and its place in the sum depend on (particle, share) only, never on which block ran it.
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, jl = lane & 15;
   const size_t dd = (size_t)d * d;
   const NNOff off = nn_offsets(d, H, np_.bias);
-  const float* th_m = theta + (size_t)m * P;
-  float* const om_final = out + (size_t)m * out_stride;
-  const Key2 key = lin_mode_key(mode, carry, M_global, m0 + m, layout);
   const uint64_t nbits = (uint64_t)S * dd;
-  const float* lp = logprobs + (size_t)m * S;
-  // softmax statistics and this block's share of the samples with a non-zero weight (GradSplit, kernels_joint.h)
   __shared__ float wch[GRAD_WCH];
   __shared__ unsigned short lst[GRAD_WCH];
   __shared__ int lst_n[2];
   __shared__ int last_flag;
-  double mx, den, sm;
-  int nnz;
+  __shared__ unsigned int cur_item;
 #ifdef DIBS_NN_STAMPS
   unsigned long long st_prev = wall_clock64();
 #endif
-  grad_softmax_stats<NW>(lp, S, red, mx, den, sm, nnz);
-  const int NS = gridDim.y, bz = blockIdx.y, nact = nnz < NS ? (nnz > 0 ? nnz : 1) : NS;
-  if (bz >= nact) return;  // (block-uniform: no share -- before anything is staged)
+  const float inv_on = 1.0f / np_.obs_noise;
+  const float inv_sp2 = 1.0f / (np_.sig_param * np_.sig_param);
+  const int nrt = g.np >> 4;
+  const bool fastg = layout == 0 && (S & 1) == 0 && (uint64_t)S * dd < 0xFFFFFFFFull;  // (block-uniform)
+  // which of the lane's output elements are observations that count (not padding, not intervened on): bit tj*4 + r of okb[u]
+  uint32_t okb[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    okb[u] = 0u;
+#pragma unroll
+    for (int tj = 0; tj < 7; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = (wave + NW * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
+        const bool v = tj < NT && n < N && j < d && wave + NW * u < nrt && !(any_mask && mask[(size_t)n * d + j]);
+        okb[u] |= (uint32_t)v << (tj * 4 + r);
+      }
+  }
+  const unsigned int n_items = gp.ctr[0];
+  bool x_ok = false;  // (block-uniform: x is in LDS -- the transposition at the end of a theta item borrows its storage)
+  for (;;) {
+  __syncthreads();
+  if (tid == 0) cur_item = atomicAdd(gp.ctr + 1, 1u);
+  __syncthreads();
+  const unsigned int item_i = cur_item;
+  if (item_i >= n_items) break;
+  const unsigned int item = gp.items[item_i];
+  const int m = (int)(item >> 6), bz = (int)(item & 63u);
+  const double mx = gp.stats[(size_t)m * 4 + 0], den = gp.stats[(size_t)m * 4 + 1], sm = gp.stats[(size_t)m * 4 + 2];
+  const int nnz = (int)gp.stats[(size_t)m * 4 + 3];
+  const int nact = nnz < NS ? (nnz > 0 ? nnz : 1) : NS;
+  const float* th_m = theta + (size_t)m * P;
+  float* const om_final = out + (size_t)m * out_stride;
+  const Key2 key = lin_mode_key(mode, carry, M_global, m0 + m, layout);
+  const float* lp = logprobs + (size_t)m * S;
   NN_ST(14);
-  for (int e = tid; e < g.np * g.ldx; e += NTHR) {
-    const int n = e / g.ldx, c = e - n * g.ldx;
-    X[e] = (n < N && c < d) ? x[(size_t)n * d + c] : 0.f;
+  if (!x_ok) {
+    for (int e = tid; e < g.np * g.ldx; e += NTHR) {
+      const int n = e / g.ldx, c = e - n * g.ldx;
+      X[e] = (n < N && c < d) ? x[(size_t)n * d + c] : 0.f;
+    }
+    x_ok = true;
   }
   NN_ST(15);
   // Where things accumulate.  theta mode: the first-layer gradient always in this block's partial row (thread layout, w1sz floats); the small
@@ -652,30 +681,11 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
     for (size_t e = tid; e < dd; e += NTHR) om[e] = 0.f;
   }
   NN_ST(6);
-  const float inv_on = 1.0f / np_.obs_noise;
-  const float inv_sp2 = 1.0f / (np_.sig_param * np_.sig_param);
   const float* sc_m = scores + (size_t)m * dd;
   const uint32_t* thr_m = thr + (size_t)m * dd;
   const float* w1t_m = w1t ? w1t + (size_t)m * H * dd : nullptr;
-  const int nrt = g.np >> 4;
-  const bool fastg = layout == 0 && (S & 1) == 0 && (uint64_t)S * dd < 0xFFFFFFFFull;  // (block-uniform)
   const TfKeys tk = tf_keys(key);
-  // which of the lane's output elements are observations that count (not padding, not intervened on): bit tj*4 + r of okb[u]
-  uint32_t okb[NU];
-#pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    okb[u] = 0u;
-#pragma unroll
-    for (int tj = 0; tj < 7; ++tj)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = (wave + NW * u) * 16 + (lane >> 4) * 4 + r, j = tj * 16 + (lane & 15);
-        const bool v = tj < NT && n < N && j < d && wave + NW * u < nrt && !(any_mask && mask[(size_t)n * d + j]);
-        okb[u] |= (uint32_t)v << (tj * 4 + r);
-      }
-  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zeroed rows are in place before another wave adds to them (barriers below)
-  const int jl = lane & 15;
   NN_ST(5);
 
   // This block's samples of a chunk are listed first (wave 0, ballots) and the heavy loop runs over the list: a scan over all S samples
@@ -942,7 +952,7 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
   if (split) {
     // release the partial sums, count this block, and the LAST block of the particle adds the rows in block order into the output
     __threadfence();
-    if (!grad_last_block(gs.ctr + m, nact, &last_flag)) return;
+    if (!grad_last_block(gs.ctr + m, nact, &last_flag)) continue;  // (next item)
     __threadfence();
   }
   const float* const base = gs.part + (size_t)m * NS * gs.stride;
@@ -950,6 +960,7 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
     // first-layer gradient: thread layout -> theta's layout [j][a][h], as many column tiles at a time as LDS holds (X, GS, the slices are dead)
     const int tpc = (int)(lds_floats / ((size_t)16 * d * H));
     if (tpc >= 1) {
+      x_ok = false;
       for (int tj0 = 0; tj0 < NT; tj0 += tpc) {
         const int tj1 = tj0 + tpc < NT ? tj0 + tpc : NT;
         for (int h = 0; h < H; ++h)
@@ -1015,8 +1026,8 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
   }
   if (mode != LIN_MODE_THETA && baseline_out && tid == 0)
     baseline_out[m] = (mode == LIN_MODE_Z_SCORE) ? (float)(sf_baseline * (sm / S) + (1.0 - sf_baseline) * (double)bold) : bold;
+  }  // (next item)
 }
-
 
 // theta init with the stax key discipline (nonlinearGaussian.py:155-186; stax.serial / Dense of jax.example_libraries):
 // subkey(m, j) = row m*d+j of split(key, M*d); per stax layer: rng, layer_rng = split(rng) (the activation layer consumes
@@ -1065,6 +1076,7 @@ void joint_nn_init_theta(float* theta, size_t P, Key2 key, int m0, int Mloc, int
 #include "kernels_nn_f16.h"
 #include "kernels_nn_f16x.h"
 void dibs_allow_lds(const void* kernel, size_t bytes);  // (engine.hip)
+int dibs_cu_count();                                     // (engine.hip: compute units of the current device)
 
 // first layer on the f16 matrix pipe (kernels_nn_f16.h): 33 <= d <= 112, Threefry-paired samples, tables allocated; DIBS_NN_F32=1 keeps
 // the f32-MFMA kernel (A/B runs).  Returns false when the f32 kernel has to run.
@@ -1215,13 +1227,21 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
   int ns_nn = GRAD_NS_NN;
   while (ns_nn > 1 && (size_t)jl.Mloc * ns_nn * row * 4 > ((size_t)4 << 30)) ns_nn >>= 1;
   if (!joint_grad_split(w, (size_t)jl.Mloc, row, &gs, ns_nn)) return;  // (the step's launch check reports the failed hipMalloc)
+  GradPlan gp;
+  if (!joint_grad_plan(w, (size_t)jl.Mloc, ns_nn, &gp)) return;
+  hipMemsetAsync(gp.ctr, 0, 8, jl.stream);
+  hipLaunchKernelGGL(k_grad_plan, dim3(jl.Mloc), dim3(64), 0, jl.stream, lp, jl.S, ns_nn, gp);
+  // persistent blocks: as many as are resident at once (one per CU when a block fills the LDS, else two), at most one per item
+  const long max_items = (long)jl.Mloc * ns_nn;
+  const int resident = dibs_cu_count() * (wide ? 1 : 2);
+  const int nblk = (int)(max_items < resident ? max_items : resident);
 #define NN_GRAD_LAUNCH(ACT_, NW_)                                                                                                              \
   {                                                                                                                                            \
     if (lds2 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_grad<ACT_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);       \
-    hipLaunchKernelGGL((k_nn_grad<ACT_, NW_>), dim3(jl.Mloc, ns_nn), dim3(64 * NW_), lds2, jl.stream, w->x, w->mask, jl.theta, P, jl.scores,      \
+    hipLaunchKernelGGL((k_nn_grad<ACT_, NW_>), dim3(nblk), dim3(64 * NW_), lds2, jl.stream, w->x, w->mask, jl.theta, P, jl.scores,               \
                        jl.thr, lp, out, ostride, tcopy, jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode,    \
                        jl.m0, jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask, gs,                \
-                       w->ln_tab ? w->w1t : nullptr, w->ln_tab, NT, hcs);                                                                     \
+                       w->ln_tab ? w->w1t : nullptr, w->ln_tab, NT, hcs, gp, ns_nn);                                                          \
   }
   if (wide) {
     if (np_.act == 0) NN_GRAD_LAUNCH(0, 8) else NN_GRAD_LAUNCH(-1, 8)

@@ -245,8 +245,9 @@ def test_config3_posterior_2000_steps():
 # empty at the last two checkpoints (asserted for the oracle and for the device).  Steps 100 / 200: all graphs still empty and identical, Z /
 # theta within north_star's 1e-4.  Step 300 (first edges, ~0.4 per particle): the device's 32 graphs equal the oracle's.  Step 400 (~5 edges per
 # particle, appearing within a few steps of each other): the trajectories have separated -- one seed is one draw, so the bound is a plain
-# sanity bound (|dE-SHD| <= 2.0; measured 0.51 on seed 0, with the E-SHD moving from 197 to 199 between steps 300 and 400 and to 287 by
-# step 600) and the share of identical graphs is reported.  The f64 oracle needs 27 min per 100 steps and seed on three cores.
+# sanity bound (|dE-SHD| <= 2.0; measured -0.47 / -0.06 on the two seeds, with the E-SHD moving from 197 to 199 between steps 300 and 400 and
+# to 287 by step 600) and the share of identical graphs is reported (0.22 / 0.91).  The f64 oracle needs 27 min per 100 steps and seed on
+# three cores.  Two seeds (0, 1).
 TOL_JOINT["config5s"] = {100: (1.0, 1e-3, 1e-4, None), 200: (1.0, 1e-3, 1e-4, None), 300: (1.0, 1e-3, np.inf, None), 400: (0.0, 2.0, np.inf, None)}
 
 
@@ -258,9 +259,10 @@ def test_config5_model_posterior_with_nonempty_graphs():
     rows = _joint_report("config5s", fx, cps, seeds, out)
     ncp = np.asarray(fx["ncp_f64"])
     for ci, cp in enumerate(cps):
-        if cp >= 300:   # non-vacuity: edges in the limit graphs, for the oracle and for the device
-            ok = ncp > ci
-            assert (fx["edges_f64"][ok, ci] > 0).all() and (out["edges"][ok, ci] > 0).all(), (cp, fx["edges_f64"][:, ci], out["edges"][:, ci])
+        if cp >= 300:   # non-vacuity: edges in the limit graphs, for the oracle and for the device (step 300: seed 0 only -- seed 1's first
+            ok = ncp > ci   # edge appears between steps 300 and 400; step 400: every seed)
+            quant = np.all if cp >= 400 else np.any
+            assert quant(fx["edges_f64"][ok, ci] > 0) and quant(out["edges"][ok, ci] > 0), (cp, fx["edges_f64"][:, ci], out["edges"][:, ci])
     _joint_check("config5s", fx, d, cps, rows)
 
 
