@@ -521,6 +521,44 @@ def test_joint_gradients_with_many_weighted_samples(c_oracle64, monkeypatch, mod
     eng.close()
 
 
+@pytest.mark.parametrize("model,d,M,S,est", [
+    ("densenn", 20, 6, 64, "reparam"),    # k_nn_grad: no-return atomic adds into the partial rows, persistent blocks taking items in any order
+    ("densenn", 100, 3, 32, "reparam"),   # (one block per CU, 8 waves)
+    ("densenn", 20, 4, 48, "score"),
+    ("lingauss", 50, 6, 64, "reparam"),   # k_lin_grad: partial sums in registers
+    ("densenn-deep", 12, 4, 40, "reparam"),
+])
+def test_gradient_kernels_are_run_to_run_deterministic(model, d, M, S, est):
+    """Which block takes which (particle, share) item, and when, differs from run to run; the results must not: a share's partial sum has one
+    owner per element, and the partial sums are added in share order (kernels_joint.h: GradSplit; kernels_nn.h: nn_acc, k_grad_plan).  The
+    same late step (every sample weighted: large observation noise) eight times from one state, bit for bit."""
+    data, _, _ = make_data(d, seed=4, joint=True)
+    deep = model == "densenn-deep"
+    if deep:
+        model = "densenn"
+    kw = dict(lin_obs_noise=1e4) if model == "lingauss" else dict(nn_obs_noise=1e4, nn_hidden=(4, 3) if deep else (5,))
+    cfg = make_config(n_vars=d, n_particles=M, n_observations=100, joint=True, likelihood=model, grad_estimator_z=est, n_grad_mc_samples=S,
+                      n_acyclicity_mc_samples=4, score_function_baseline=0.001 if est == "score" else 0.0, **kw)
+    eng = _engine(cfg, data.x)
+    eng.init_particles(prng.PRNGKey(6))
+    eng.run(400, 1)
+    st0 = eng.get_state()
+    ref = None
+    for rep in range(8):
+        eng.set_state(**{k: st0[k] for k in ("z", "v_z", "theta", "v_theta", "key", "baseline")})
+        eng.run(401, 1)
+        cur = dict(gt=eng.read("GRAD_THETA").copy(), wl=eng.read("W_LIK").copy(), **{k: v.copy() for k, v in eng.get_state().items() if k in ("z", "theta")})
+        if ref is None:
+            ref = cur
+            lp = eng.read("LOGPROBS_THETA").reshape(M, S).astype(np.float64)
+            w = np.exp(lp - lp.max(1, keepdims=True))
+            assert ((w / w.sum(1, keepdims=True)).astype(np.float32) >= 2.0 ** -30).sum(1).max() >= 2   # shares exist
+        else:
+            for k in ref:
+                assert np.array_equal(ref[k].view(np.uint32), cur[k].view(np.uint32)), (rep, k)
+    eng.close()
+
+
 @pytest.mark.parametrize("d,M,S,Sa,est,interv,N,force", [
     (20, 4, 32, 8, "reparam", False, 100, True),    # same sizes as the MFMA path: both device paths against one oracle
     (20, 4, 32, 8, "score", True, 100, True),
