@@ -97,19 +97,29 @@ __device__ __forceinline__ void nn_gemm_x_tw(const float* X, const float* TW, co
 
 // LN[a][j] = sum_h logN(W1[j][a][h]; 0, sig_p): the graph-dependent part of the parameter prior is sum_aj g[a][j] LN[a][j]
 // (nonlinearGaussian.py:264-269).  It does not depend on the sample: one table per particle and step instead of H logN
-// evaluations per element of every sampled graph.   grid = (ceil(d*d / 256), Mloc)
+// evaluations per element of every sampled graph.  Also W1T[h][a][j] = W1[j][a][h] (what the kernels multiply the sampled graph with, element
+// by element).  A block takes 16 nodes x 16 inputs with all hidden units through LDS (reads in runs of 16 H floats per node, writes in runs
+// of 16 nodes).   grid = (ceil(d / 16) nodes, ceil(d / 16) inputs, Mloc), block = 256, dynamic LDS = 256 H floats
 #ifdef DIBS_TU_NN
-__global__ void k_nn_prior_table(const float* __restrict__ theta, size_t P, float* __restrict__ ln_tab, float* __restrict__ w1t, int d, int H,
-                                 float sigp) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
-  if (e >= d * d) return;
-  const int a = e / d, j = e - a * d;
-  const float* w = theta + (size_t)m * P + ((size_t)j * d + a) * H;
+__global__ __launch_bounds__(256) void k_nn_prior_table(const float* __restrict__ theta, size_t P, float* __restrict__ ln_tab, float* __restrict__ w1t,
+                                                        int d, int H, float sigp) {
+  extern __shared__ __attribute__((aligned(16))) float tl[];  // [16 nodes][16 inputs][H]
+  const int j0 = blockIdx.x * 16, a0 = blockIdx.y * 16, m = blockIdx.z, tid = threadIdx.x;
+  const float* w = theta + (size_t)m * P;
+  const int run = 16 * H;
+  for (int i = tid; i < 16 * run; i += 256) {
+    const int jj = i / run, r = i - jj * run, a = a0 + r / H;
+    tl[i] = (j0 + jj < d && a < d) ? w[((size_t)(j0 + jj) * d + a0) * H + r] : 0.f;
+  }
+  __syncthreads();
+  const int jj = tid & 15, al = tid >> 4, a = a0 + al, j = j0 + jj;
+  if (a >= d || j >= d) return;
+  const int e = a * d + j;
   float t = 0.f;
-  for (int h = 0; h < H; ++h) {
-    const float wv = w[h];
+  for (int h = 0; h < H; ++h) {  // (sum in h order, as before)
+    const float wv = tl[jj * run + al * H + h];
     t += lin_logn(wv, 0.f, sigp);
-    if (w1t) w1t[((size_t)m * H + h) * d * d + e] = wv;  // W1T[h][a][j]: what k_nn_logprobs multiplies the sampled graph with, element by element
+    if (w1t) w1t[((size_t)m * H + h) * d * d + e] = wv;
   }
   ln_tab[(size_t)m * d * d + e] = t;
 }
@@ -1116,10 +1126,10 @@ static bool joint_nn_logprobs_hf(JointWork* w, const JointLaunch& jl, Key2 carry
           w->nhx_quads = quads;
         }
         if (!w->nhx_valid) {  // theta is the same for both estimators of a step: the tables are built once per step and variant
-          hipLaunchKernelGGL(k_nn_w1_exp, dim3(jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->nhf_ew, jl.d, np_.H);
-          const int nq = ((jl.d + 3) / 4) * jl.d;
-          hipLaunchKernelGGL(k_nn_tables_hx, dim3((nq + 255) / 256, np_.H, jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->nhf_ew,
-                             (float4*)w->nhx_w1s, (uint4*)w->nhx_w1p, jl.d, np_.H);
+          hipLaunchKernelGGL(k_nn_w1_exp, dim3(jl.Mloc), dim3(1024), 0, jl.stream, jl.theta, P, w->nhf_ew, jl.d, np_.H);
+          dibs_allow_lds((const void*)k_nn_tables_hx, (size_t)256 * np_.H * 4);
+          hipLaunchKernelGGL(k_nn_tables_hx, dim3((jl.d + 15) / 16, (jl.d + 15) / 16, jl.Mloc), dim3(256), (size_t)256 * np_.H * 4, jl.stream, jl.theta, P,
+                             w->nhf_ew, (float4*)w->nhx_w1s, (uint4*)w->nhx_w1p, jl.d, np_.H);
           w->nhx_valid = true;
         }
 #define NHX_LAUNCH(NTN_, ACT_, SOFT_)                                                                                                        \
@@ -1157,7 +1167,7 @@ static bool joint_nn_logprobs_hf(JointWork* w, const JointLaunch& jl, Key2 carry
       w->nhf_pairs = pairs;
     }
     if (!w->nhf_valid) {  // (once per step and variant, see JointWork)
-      hipLaunchKernelGGL(k_nn_w1_exp, dim3(jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->nhf_ew, jl.d, np_.H);
+      hipLaunchKernelGGL(k_nn_w1_exp, dim3(jl.Mloc), dim3(1024), 0, jl.stream, jl.theta, P, w->nhf_ew, jl.d, np_.H);
       const int npr = jl.d * (nhf_dp2(jl.d) / 2);
       hipLaunchKernelGGL(k_nn_tables_hf, dim3((npr + 255) / 256, np_.H, jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->nhf_ew,
                          (float2*)w->nhf_w1s, (uint2*)w->nhf_w1p, jl.d, np_.H);
@@ -1195,8 +1205,9 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
     if (!w->w1t_floats) w->w1t = nullptr;
   }
   if (mode == LIN_MODE_THETA && w->ln_tab)  // theta is the same for both estimators of a step: the tables are built once (theta runs first)
-    hipLaunchKernelGGL(k_nn_prior_table, dim3((jl.d * jl.d + 255) / 256, jl.Mloc), dim3(256), 0, jl.stream, jl.theta, P, w->ln_tab, w->w1t, jl.d,
-                       np_.H, np_.sig_param);
+    dibs_allow_lds((const void*)k_nn_prior_table, (size_t)256 * np_.H * 4);
+    hipLaunchKernelGGL(k_nn_prior_table, dim3((jl.d + 15) / 16, (jl.d + 15) / 16, jl.Mloc), dim3(256), (size_t)256 * np_.H * 4, jl.stream, jl.theta, P,
+                       w->ln_tab, w->w1t, jl.d, np_.H, np_.sig_param);
 #define NN_LP_LAUNCH(NW_, ACT_)                                                                                                             \
   {                                                                                                                                         \
     if (lds1 > 48 * 1024) hipFuncSetAttribute((const void*)k_nn_logprobs<NT, NW_, ACT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); \

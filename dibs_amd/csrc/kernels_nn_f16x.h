@@ -37,23 +37,34 @@ __host__ __device__ inline size_t nhx_lds_bytes(int d, int NT, int N, int H, boo
 #ifdef DIBS_TU_NN
 // w1q_s[m][h][aq][j] = W1[j][4 aq .. 4 aq + 3][h] 2^ew  (float4; inputs beyond d: 0)
 // w1q_p[m][h][aq][j] = their packed f16 pieces {h(a0,a1), h(a2,a3), m(a0,a1), m(a2,a3)}
-// grid = (ceil(naq * d / 256), H, Mloc), block = 256
+// A block takes 16 nodes x 16 inputs (4 quads) of one particle with ALL hidden units through LDS: theta's layout W1[j][a][h] is read in runs of
+// 16 H floats per node, the tables are written in runs of 16 nodes (one thread per (quad, node) reading theta directly touched 64 lines per
+// load: 110 us per step at config 5).   grid = (ceil(d / 16) nodes, ceil(d / 16) inputs, Mloc), block = 256, dynamic LDS = 256 H floats
 __global__ __launch_bounds__(256) void k_nn_tables_hx(const float* __restrict__ theta, size_t P, const int* __restrict__ ew, float4* __restrict__ w1q_s,
                                                       uint4* __restrict__ w1q_p, int d, int H) {
-  const int naq = (d + 3) >> 2, q = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y, m = blockIdx.z;
-  if (q >= naq * d) return;
-  const int aq = q / d, j = q - aq * d;
+  extern __shared__ __attribute__((aligned(16))) float tl[];  // [16 nodes][16 inputs][H]
+  const int naq = (d + 3) >> 2, j0 = blockIdx.x * 16, a0 = blockIdx.y * 16, m = blockIdx.z, tid = threadIdx.x;
   const float s = ahf_pow2(ew[m]);
-  const float* w = theta + (size_t)m * P + (size_t)j * d * H + h;
-  float v[4];
+  const float* w = theta + (size_t)m * P;
+  const int run = 16 * H;
+  for (int i = tid; i < 16 * run; i += 256) {
+    const int jj = i / run, r = i - jj * run, a = a0 + r / H;
+    tl[i] = (j0 + jj < d && a < d) ? w[((size_t)(j0 + jj) * d + a0) * H + r] * s : 0.f;
+  }
+  __syncthreads();
+  for (int o = tid; o < H * 4 * 16; o += 256) {  // (h, quad, node): node fastest
+    const int jj = o & 15, ql = (o >> 4) & 3, h = o >> 6, aq = (a0 >> 2) + ql, j = j0 + jj;
+    if (aq >= naq || j >= d) continue;
+    float v[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = 4 * aq + i < d ? w[(size_t)(4 * aq + i) * H] * s : 0.f;
-  const size_t o = ((size_t)m * H + h) * naq * d + q;
-  w1q_s[o] = make_float4(v[0], v[1], v[2], v[3]);
-  uint32_t h0, m0, h1, m1;
-  ahf_split(v[0], v[1], 1.0f, h0, m0);
-  ahf_split(v[2], v[3], 1.0f, h1, m1);
-  w1q_p[o] = make_uint4(h0, h1, m0, m1);
+    for (int i = 0; i < 4; ++i) v[i] = tl[jj * run + (4 * ql + i) * H + h];
+    const size_t q = ((size_t)m * H + h) * naq * d + (size_t)aq * d + j;
+    w1q_s[q] = make_float4(v[0], v[1], v[2], v[3]);
+    uint32_t h0, m0, h1, m1;
+    ahf_split(v[0], v[1], 1.0f, h0, m0);
+    ahf_split(v[2], v[3], 1.0f, h1, m1);
+    w1q_p[q] = make_uint4(h0, h1, m0, m1);
+  }
 }
 #endif
 
