@@ -472,10 +472,10 @@ __device__ __forceinline__ void nn_grad_build_graph(float* GS, int mode, Key2 ke
 }
 // operand slices of column tile tj for hidden units h0 .. h0+hn-1: SL[hc][a][jl] = GS[a][j] W1[j][a][h0+hc], j = 16 tj + jl; zero for a >= d,
 // j >= d.  All of a thread's weight loads of a round (EPT) are in flight together.  w1t_m: the particle's re-laid-out weights W1T[h][a][j]
-// (k_nn_prior_table; coalesced) or null (theta's own layout).
+// (k_nn_prior_table; coalesced).
 template <int EPT>
-__device__ __forceinline__ void nn_grad_build_slices(float* SL, const float* GS, const float* __restrict__ w1t_m, const float* __restrict__ th_m,
-                                                     int H, int h0, int hn, int tj, const LinGeom g, int tid, int nthr) {
+__device__ __forceinline__ void nn_grad_build_slices(float* SL, const float* GS, const float* __restrict__ w1t_m, int h0, int hn, int tj,
+                                                     const LinGeom g, int tid, int nthr) {
   const int d = g.d, kp = g.kp, tot = hn * kp * 16;
   const float inv_kp = 1.0f / (float)kp;
   for (int i0 = tid; i0 < tot; i0 += EPT * nthr) {
@@ -485,7 +485,7 @@ __device__ __forceinline__ void nn_grad_build_slices(float* SL, const float* GS,
       const int i = i0 + q * nthr, row = i >> 4, j = tj * 16 + (i & 15);
       const int hc = (int)(((float)row + 0.5f) * inv_kp), a = row - hc * kp;
       const bool ok = i < tot && a < d && j < d;
-      wv[q] = !ok ? 0.f : (w1t_m ? w1t_m[((size_t)(h0 + hc) * d + a) * d + j] : th_m[((size_t)j * d + a) * H + h0 + hc]);
+      wv[q] = !ok ? 0.f : w1t_m[((size_t)(h0 + hc) * d + a) * d + j];
     }
 #pragma unroll
     for (int q = 0; q < EPT; ++q) {
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
   NN_ST(6);
   const float* sc_m = scores + (size_t)m * dd;
   const uint32_t* thr_m = thr + (size_t)m * dd;
-  const float* w1t_m = w1t ? w1t + (size_t)m * H * dd : nullptr;
+  const float* w1t_m = w1t + (size_t)m * H * dd;  // (W1T[h][a][j] and the prior table exist whenever this kernel runs: joint_nn_launch)
   const TfKeys tk = tf_keys(key);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zeroed rows are in place before another wave adds to them (barriers below)
   NN_ST(5);
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
       auto fwd = [&](auto hnc, const int h0) {
         constexpr int HN = decltype(hnc)::value;
         __syncthreads();  // the slices' last readers (previous tile's x^T dpre, previous group) are done
-        nn_grad_build_slices<8>(SL, GS, w1t_m, th_m, H, h0, HN, tj, g, tid, NTHR);
+        nn_grad_build_slices<8>(SL, GS, w1t_m, h0, HN, tj, g, tid, NTHR);
         float b1v[HN];
 #pragma unroll
         for (int hc = 0; hc < HN; ++hc) {
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
         constexpr int HN = decltype(hnc)::value;
         if (again) {  // (more hidden units than a group holds: this group's activations again)
           __syncthreads();
-          nn_grad_build_slices<8>(SL, GS, w1t_m, th_m, H, h0, HN, tj, g, tid, NTHR);
+          nn_grad_build_slices<8>(SL, GS, w1t_m, h0, HN, tj, g, tid, NTHR);
           float b1v[HN];
 #pragma unroll
           for (int hc = 0; hc < HN; ++hc) {
@@ -875,13 +875,12 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
           f32x4 w1v[HN];
           const int a0 = ti * 16 + (lane >> 4) * 4;
           const uint32_t wi = (uint32_t)h0 * (uint32_t)dd + (uint32_t)a0 * (uint32_t)d + (uint32_t)j;                       // W1T[h0][a0][j]
-          const uint32_t ti_ = ((uint32_t)j * (uint32_t)d + (uint32_t)a0) * (uint32_t)H + (uint32_t)h0;                     // W1[j][a0][h0]
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             gvr[r] = (a0 + r < d && jok) ? GS[(a0 + r) * d + j] : 0.f;
 #pragma unroll
             for (int hc = 0; hc < HN; ++hc)
-              w1v[hc][r] = gvr[r] == 0.f ? 0.f : (w1t_m ? w1t_m[wi + (uint32_t)hc * (uint32_t)dd + (uint32_t)(r * d)] : th_m[ti_ + (uint32_t)(r * H + hc)]);
+              w1v[hc][r] = gvr[r] == 0.f ? 0.f : w1t_m[wi + (uint32_t)hc * (uint32_t)dd + (uint32_t)(r * d)];
           }
           f32x4 t[HC];
           nn_grad_gemm_xtr<HN>(X, SL, g, lane, ti, t);
@@ -931,15 +930,12 @@ __global__ __launch_bounds__(64 * NW) void k_nn_grad(const float* __restrict__ x
         for (int u = 0; u < NUDM; ++u) {
           const int ti = wave + NW * u;
           if (ti >= NT) continue;
-          float lnv[4];  // sum_h logN(W1[j][a][h]; 0, sig_p): the particle's prior table, if there is one
+          float lnv[4];  // sum_h logN(W1[j][a][h]; 0, sig_p): the particle's prior table
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int a = ti * 16 + (lane >> 4) * 4 + r;
             const bool ok = a < d && jok && a != j;
-            lnv[r] = 0.f;
-            if (ok && ln_tab) lnv[r] = ln_tab[(size_t)m * dd + (size_t)a * d + j];
-            if (ok && !ln_tab)
-              for (int h = 0; h < H; ++h) lnv[r] += lin_logn(th_m[((size_t)j * d + a) * H + h], 0.f, np_.sig_param);
+            lnv[r] = ok ? ln_tab[(size_t)m * dd + (size_t)a * d + j] : 0.f;
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -1198,12 +1194,13 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
   const size_t lds1 = nn_lds_bytes_logprobs(jl.d, jl.N, NT, np_.H);
   float* lp = mode == LIN_MODE_THETA ? jl.logprobs_th : jl.logprobs_z;
   const size_t w1t_need = (size_t)jl.Mloc * np_.H * jl.d * jl.d;
-  if (w->w1t_floats < w1t_need) {  // (first launch; optional: without it the kernel reads W1 in place)
+  if (w->w1t_floats < w1t_need) {  // (first launch)
     if (w->w1t) hipFree(w->w1t);
     w->w1t = nullptr;
     w->w1t_floats = hipMalloc((void**)&w->w1t, w1t_need * 4) == hipSuccess ? w1t_need : 0;
     if (!w->w1t_floats) w->w1t = nullptr;
   }
+  if (!w->w1t || !w->ln_tab) return;  // (k_nn_grad reads both; the step's launch check reports the failed hipMalloc)
   if (mode == LIN_MODE_THETA && w->ln_tab)  // theta is the same for both estimators of a step: the tables are built once (theta runs first)
     dibs_allow_lds((const void*)k_nn_prior_table, (size_t)256 * np_.H * 4);
     hipLaunchKernelGGL(k_nn_prior_table, dim3((jl.d + 15) / 16, (jl.d + 15) / 16, jl.Mloc), dim3(256), (size_t)256 * np_.H * 4, jl.stream, jl.theta, P,
@@ -1252,7 +1249,7 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
     hipLaunchKernelGGL((k_nn_grad<ACT_, NW_>), dim3(nblk), dim3(64 * NW_), lds2, jl.stream, w->x, w->mask, jl.theta, P, jl.scores,               \
                        jl.thr, lp, out, ostride, tcopy, jl.baseline, mode == LIN_MODE_THETA ? (float*)nullptr : jl.baseline_out, carry, mode,    \
                        jl.m0, jl.M, jl.d, jl.N, jl.S, jl.alpha, jl.tau, jl.layout, jl.tiny, np_, jl.sf_baseline, w->any_mask, gs,                \
-                       w->ln_tab ? w->w1t : nullptr, w->ln_tab, NT, hcs, gp, ns_nn);                                                          \
+                       w->w1t, w->ln_tab, NT, hcs, gp, ns_nn);                                                                               \
   }
   if (wide) {
     if (np_.act == 0) NN_GRAD_LAUNCH(0, 8) else NN_GRAD_LAUNCH(-1, 8)
