@@ -51,19 +51,16 @@ __host__ __device__ inline NNOff nn_offsets(int d, int H, int bias) {
   return o;
 }
 
-// LDS (floats): X[np][ldx] | GS[d*d] | TR[max(kp, np)][ldw] | (grad kernel) CS[4][ldw] | red
-// TR holds the forward operand T_h (rows < kp) and, after a barrier, the backward operand dpre_h (rows < np): the two are
-// never live together, which is what lets d = 100 / N = 100 fit in 160 KiB.
+// k_nn_logprobs: LDS (floats) X[np][ldx] | GS[d*d] | TR[max(kp, np)][ldw] (the operand T_h) | red | the small leaves b1 | W2 | b2
+// ([d][H] | [d][H] | [d]).  (k_nn_grad has its own layout: nn_grad_lds_floats.)
 __host__ __device__ inline int nn_tr_rows(const LinGeom g) { return g.kp > g.np ? g.kp : g.np; }
-__host__ __device__ inline size_t nn_lds_bytes(int d, int N, int NT, bool grad) {
+__host__ __device__ inline size_t nn_lds_bytes(int d, int N, int NT) {
   const LinGeom g = lin_geom(d, N, NT);
-  size_t f = (size_t)g.np * g.ldx + (size_t)d * d + (size_t)nn_tr_rows(g) * g.ldw;
-  (void)grad;
+  const size_t f = (size_t)g.np * g.ldx + (size_t)d * d + (size_t)nn_tr_rows(g) * g.ldw;
   return ((f * 4 + 15) & ~(size_t)15) + 64 * 8;
 }
-// k_nn_logprobs also keeps the small leaves b1 | W2 | b2 ([d][H] | [d][H] | [d]) behind `red`
 __host__ __device__ inline size_t nn_lds_bytes_logprobs(int d, int N, int NT, int H) {
-  return nn_lds_bytes(d, N, NT, false) + (((size_t)2 * d * H + d) * 4 + 15 & ~(size_t)15);
+  return nn_lds_bytes(d, N, NT) + (((size_t)2 * d * H + d) * 4 + 15 & ~(size_t)15);
 }
 
 // pre = X * TW for the row tiles of this wave, results left in registers: acc[u][tj] (row tile ti = wave + 4 u)
@@ -157,25 +154,6 @@ __device__ __forceinline__ float nn_build_tw(float* TW, const float* GS, const f
     TW[e] = v;
   }
   return prior;
-}
-
-// the same operand from the re-laid-out weights W1T[h][a][j] (k_nn_prior_table): coalesced -- W1[j][a][h] itself is a 4 d H byte stride between
-// neighbouring j, 64 sectors per wave-load; with thousands of sample gradients per launch (late in a run) those strided reads were the
-// gradient kernel's time
-__device__ __forceinline__ void nn_build_tw_t(float* TW, const float* GS, const float* __restrict__ w1t_h, const LinGeom g, int tid, int nthr) {
-  for (int e = tid; e < g.kp * g.ldw; e += nthr) {
-    const int a = e / g.ldw, j = e - a * g.ldw;
-    TW[e] = (a < g.d && j < g.d) ? GS[a * g.d + j] * w1t_h[a * g.d + j] : 0.f;
-  }
-}
-
-// per-wave column sums [NW][ldw] added in wave order
-template <int NW>
-__device__ __forceinline__ float nn_cs_sum(const float* CS, int ldw, int j) {
-  float t = CS[j];
-#pragma unroll
-  for (int w = 1; w < NW; ++w) t += CS[w * ldw + j];
-  return t;
 }
 
 // The same two steps for k_nn_logprobs with the per-particle tables (prior table LN, re-laid-out weights W1T): element index e = a d + j
