@@ -138,9 +138,9 @@ def roofline_of(dom, avg_s, cfgname, M, K, eng_counters):
         roof.update(rocprof_kernel="k_lin_logprobs_pair" if dom == "lin_logprobs" else "k_lin_grad", pipe="mfma_f32", flops_per_launch=flops,
                     achieved=flops / avg_s / 1e12, flops_model="2 estimators * M*S*2*N*d^2 (forward products of SURVEY 8(d) F_lik(LinG))")
         if dom == "lin_logprobs" and 32 < d <= 64:
-            # k_lin_logprobs_bf: the float products run on the bf16 matrix pipe with three-way split operands (as k_acyc_bf above):
-            # `achieved` / `frac` price the algorithmic float flops against the FP32 peak, the bf16 flops actually issued (row tiles of 16
-            # observations, 64-padded contraction, 16-wide column tiles, 6 products) against the dense bf16 peak next to it.
+            # k_lin_logprobs_hf: the float products run on the f16 matrix pipe with two block-scaled pieces per operand (as k_acyc_hf above):
+            # `achieved` / `frac` price the algorithmic float flops against the FP32 peak, the f16 flops actually issued (row tiles of 16
+            # observations, 64-padded contraction, 16-wide column tiles, 3 products) against the dense f16 peak next to it.
             f16_flops = 2 * M * S_MC * 3 * 2 * (16 * ((N_OBS + 15) // 16)) * 64 * (64 if d > 48 else 48)
             roof.update(rocprof_kernel="k_lin_logprobs_hf", pipe="mfma_f16 (2 block-scaled pieces per operand: 3 f16 products per f32 product)",
                         executed_f16_tflops=f16_flops / avg_s / 1e12, peak_f16_tflops=PEAK_BF16_TFLOPS,

@@ -1,7 +1,7 @@
 // Soft-graph BGe estimator (grad_estimator_z = "reparam" of MarginalDiBS) for n_vars <= 64 as a BLOCKED factorisation on the matrix pipe.
 //   reference: dibs/inference/dibs.py:395-459, dibs/models/linearGaussian.py:63-170 with a real-valued parent vector, dibs/utils/func.py:128-145;
 //   closed forms: header of kernels_bge_soft.h (the same quantities: logdet M_pa, the Schur complement s, diag(M_pa^-1), y = M_pa^-1 b).
-// k_bge_soft_reg (one matrix row per lane, 64-step column loop) issues one LDS broadcast per multiply-add and runs two waves per SIMD:
+// Round 3's k_bge_soft_reg (one matrix row per lane, 64-step column loop; retired) issued one LDS broadcast per multiply-add and ran two waves per SIMD:
 // 17 ms per step at the headline size (819 200 factorisations of 50 x 50 matrices).  Here one wave owns one (sample, node) problem as
 // 16 x 16 blocks in the accumulator layout of v_mfma_f32_16x16x4_f32 (lane (g, c) = (lane / 16, lane % 16), register r: element
 // (4 g + r, c) of the block), and everything of order n^3 is an MFMA whose operands are those registers:

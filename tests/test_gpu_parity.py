@@ -407,7 +407,7 @@ def test_sample_api_contract():
     (6, 260, 8, 4, "reparam", "er", False, (1, 2)),   # >= 256 particles: k_phi_gemm on both segments (z and theta)
     (20, 6, 64, 16, "reparam", "er", True, (1, 4)),
     (50, 4, 128, 32, "reparam", "er", False, (2,)),
-    (33, 3, 32, 8, "score", "sf", True, (1,)),        # 33..64: k_lin_logprobs_bf (split-bf16 operands); 33..48 skips the fourth column tile
+    (33, 3, 32, 8, "score", "sf", True, (1,)),        # 33..64: k_lin_logprobs_hf (two-piece f16 operands); 33..48 skips the fourth column tile
     (40, 3, 32, 8, "reparam", "er", True, (2,)),
     (48, 3, 32, 8, "score", "er", False, (1,)),
     (49, 3, 32, 8, "reparam", "sf", True, (1,)),
