@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "rng.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -11,10 +12,25 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// sum of a double over the wave, the same value in every lane.  Rows of 16 lanes by DPP rotations (row_ror 8, 4, 2, 1: two v_mov_b32_dpp + one
+// v_add_f64 per step), the four row sums (lanes 0, 16, 32, 48) through v_readlane and added in row order -- no LDS: the butterfly over
+// __shfl_xor was twelve ds_bpermute_b32 with their latency per sum, two sums per sample pair and wave in the log-probability kernels.
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  auto ror = [](double x, auto ctrl) {
+    constexpr int C = decltype(ctrl)::value;
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, C, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, lo, C, 0xf, 0xf, false));
+  };
+  v += ror(v, std::integral_constant<int, 0x128>{});  // row_ror:8
+  v += ror(v, std::integral_constant<int, 0x124>{});  // row_ror:4
+  v += ror(v, std::integral_constant<int, 0x122>{});  // row_ror:2
+  v += ror(v, std::integral_constant<int, 0x121>{});  // row_ror:1
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  double t = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  t += __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  t += __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  t += __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return t;
 }
 __device__ __forceinline__ double wave_max_d(double v) {
 #pragma unroll
