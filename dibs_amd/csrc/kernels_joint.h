@@ -641,15 +641,29 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 8
         if (wave + NW * u >= nrt) continue;
         f32x4 acc[ABF_NT];
         ahf_matmul<FOUR>(acc, XA[u], img, rd_off);
+        // (without interventions every element that does not count is padding: x = 0 there and the prediction is an exact 0 -- zero rows of
+        //  the left operand, zero columns of the right one --, so the residual needs no mask: one instruction less per element)
+        if (any_mask) {
 #pragma unroll
-        for (int tj = 0; tj < ABF_NT; ++tj)
+          for (int tj = 0; tj < ABF_NT; ++tj)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float pv = acc[tj][i];
-            asm volatile("" : "+v"(pv));
-            const float er = ((ok[u] >> (tj * 4 + i)) & 1u) ? fmaf(-pv, unscale, xe[u][tj][i]) : 0.f;
-            sq = fmaf(er, er, sq);
-          }
+            for (int i = 0; i < 4; ++i) {
+              float pv = acc[tj][i];
+              asm volatile("" : "+v"(pv));
+              const float er = ((ok[u] >> (tj * 4 + i)) & 1u) ? fmaf(-pv, unscale, xe[u][tj][i]) : 0.f;
+              sq = fmaf(er, er, sq);
+            }
+        } else {
+#pragma unroll
+          for (int tj = 0; tj < ABF_NT; ++tj)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float pv = acc[tj][i];
+              asm volatile("" : "+v"(pv));
+              const float er = fmaf(-pv, unscale, xe[u][tj][i]);
+              sq = fmaf(er, er, sq);
+            }
+        }
       }
       part[hsel] = fmaf(-inv2, sq, part[hsel]);
     }
