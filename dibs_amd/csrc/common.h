@@ -32,13 +32,23 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   t += __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
   return t;
 }
-__device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const double t = __shfl_xor(v, o, 64);
-    v = t > v ? t : v;
-  }
-  return v;
+__device__ __forceinline__ double wave_max_d(double v) {  // (same scheme as wave_sum_d; a maximum does not depend on the order)
+  auto ror = [](double x, auto ctrl) {
+    constexpr int C = decltype(ctrl)::value;
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, C, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, lo, C, 0xf, 0xf, false));
+  };
+  auto mx2 = [](double a, double b) { return b > a ? b : a; };
+  v = mx2(v, ror(v, std::integral_constant<int, 0x128>{}));
+  v = mx2(v, ror(v, std::integral_constant<int, 0x124>{}));
+  v = mx2(v, ror(v, std::integral_constant<int, 0x122>{}));
+  v = mx2(v, ror(v, std::integral_constant<int, 0x121>{}));
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  double t = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  t = mx2(t, __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16)));
+  t = mx2(t, __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32)));
+  t = mx2(t, __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48)));
+  return t;
 }
 
 __device__ __forceinline__ double sigmoid_d(double v) { return 1.0 / (1.0 + exp(-v)); }
