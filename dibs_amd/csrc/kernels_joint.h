@@ -36,7 +36,8 @@ struct GradSplit {
 struct GradPlan {
   double* stats;        // [jobs][4]: maximum, sum of exponentials, sum of the log-probabilities, number of weighted samples
   unsigned int* items;  // [<= jobs * shares]: job * 64 + share
-  unsigned int* ctr;    // [0]: number of items, [1]: next item to take
+  unsigned int* ctr;    // [0]: number of items, [1]: next item to take  (this launch's pair of the two the workspace keeps)
+  unsigned int* ctr_next;  // the other pair: zeroed by this launch's plan kernel for the next launch (no memset launch between the steps)
 };
 
 struct JointWork {
@@ -73,6 +74,7 @@ struct JointWork {
   size_t gctr_n;
   GradPlan gplan;     // persistent gradient kernels: statistics + item list, grown on first use
   size_t gplan_jobs, gplan_items;
+  unsigned int gplan_gen;  // launches so far: the counter pair in use alternates
 };
 static inline float* joint_gs_scratch(JointWork* w, size_t floats) {
   if (w->gs_scratch_floats < floats) {
@@ -112,15 +114,23 @@ static inline bool joint_grad_plan(JointWork* w, size_t jobs, int ns, GradPlan* 
     if (w->gplan.stats) hipFree(w->gplan.stats);
     if (w->gplan.items) hipFree(w->gplan.items);
     if (w->gplan.ctr) hipFree(w->gplan.ctr);
-    w->gplan = GradPlan{nullptr, nullptr, nullptr};
+    w->gplan = GradPlan{nullptr, nullptr, nullptr, nullptr};
     w->gplan_jobs = w->gplan_items = 0;
     if (hipMalloc((void**)&w->gplan.stats, jobs * 4 * sizeof(double)) != hipSuccess) return false;
     if (hipMalloc((void**)&w->gplan.items, jobs * (size_t)ns * 4) != hipSuccess) return false;
-    if (hipMalloc((void**)&w->gplan.ctr, 8) != hipSuccess) return false;
+    if (hipMalloc((void**)&w->gplan.ctr, 16) != hipSuccess) return false;
+    if (hipMemset(w->gplan.ctr, 0, 16) != hipSuccess) return false;
+    if (hipDeviceSynchronize() != hipSuccess) return false;  // (the engine's streams do not wait for the null stream)
     w->gplan_jobs = jobs;
     w->gplan_items = jobs * (size_t)ns;
+    w->gplan_gen = 0;
   }
+  // two counter pairs: launch k uses pair k & 1 and its plan kernel zeroes the other one for launch k + 1 (launches of a workspace are
+  // ordered in one stream)
   *out = w->gplan;
+  out->ctr = w->gplan.ctr + 2 * (w->gplan_gen & 1u);
+  out->ctr_next = w->gplan.ctr + 2 * ((w->gplan_gen + 1u) & 1u);
+  ++w->gplan_gen;
   return true;
 }
 
@@ -742,7 +752,7 @@ __device__ __forceinline__ void grad_softmax_stats(const float* __restrict__ lp,
 }
 // plan of a persistent gradient kernel: one wave per job computes the statistics and appends the job's shares that have work to the item
 // list (in arrival order -- nothing depends on the order: an item's partial row and its place in the sum are fixed by (job, share)).
-// grid = jobs, block = 64; ctr zeroed by the launcher.
+// grid = jobs, block = 64; the counters of this launch were zeroed by the previous launch's plan kernel (joint_grad_plan).
 #ifdef DIBS_TU_NN
 __global__ void k_grad_plan(const float* __restrict__ logprobs, int S, int ns, GradPlan gp) {
   __shared__ double red[4];
@@ -750,6 +760,7 @@ __global__ void k_grad_plan(const float* __restrict__ logprobs, int S, int ns, G
   double mx, den, sm;
   int nnz;
   grad_softmax_stats<1>(logprobs + (size_t)m * S, S, red, mx, den, sm, nnz);
+  if (m == 0 && threadIdx.x < 2) gp.ctr_next[threadIdx.x] = 0u;
   if (threadIdx.x == 0) {
     gp.stats[(size_t)m * 4 + 0] = mx;
     gp.stats[(size_t)m * 4 + 1] = den;
@@ -1046,8 +1057,9 @@ int joint_alloc(JointWork* w, int Mloc, int d, int N, int S) {
   w->gpart_floats = 0;
   w->gctr = nullptr;
   w->gctr_n = 0;
-  w->gplan = GradPlan{nullptr, nullptr, nullptr};
+  w->gplan = GradPlan{nullptr, nullptr, nullptr, nullptr};
   w->gplan_jobs = w->gplan_items = 0;
+  w->gplan_gen = 0;
   w->nhf_w1s = w->nhf_w1p = nullptr;
   w->nhf_ew = nullptr;
   w->nhf_pairs = 0;
@@ -1081,8 +1093,9 @@ void joint_free(JointWork* w) {
   if (w->gplan.stats) hipFree(w->gplan.stats);
   if (w->gplan.items) hipFree(w->gplan.items);
   if (w->gplan.ctr) hipFree(w->gplan.ctr);
-  w->gplan = GradPlan{nullptr, nullptr, nullptr};
+  w->gplan = GradPlan{nullptr, nullptr, nullptr, nullptr};
   w->gplan_jobs = w->gplan_items = 0;
+  w->gplan_gen = 0;
   if (w->nhf_w1s) hipFree(w->nhf_w1s);
   if (w->nhf_w1p) hipFree(w->nhf_w1p);
   if (w->nhf_ew) hipFree(w->nhf_ew);

@@ -1215,7 +1215,6 @@ static void joint_nn_launch(JointWork* w, const JointLaunch& jl, Key2 carry, int
   if (!joint_grad_split(w, (size_t)jl.Mloc, row, &gs, ns_nn)) return;  // (the step's launch check reports the failed hipMalloc)
   GradPlan gp;
   if (!joint_grad_plan(w, (size_t)jl.Mloc, ns_nn, &gp)) return;
-  hipMemsetAsync(gp.ctr, 0, 8, jl.stream);
   hipLaunchKernelGGL(k_grad_plan, dim3(jl.Mloc), dim3(64), 0, jl.stream, lp, jl.S, ns_nn, gp);
   // persistent blocks: as many as are resident at once (one per CU when a block fills the LDS, else two), at most one per item
   const long max_items = (long)jl.Mloc * ns_nn;
