@@ -1,4 +1,4 @@
-"""per-phase time of k_nn_grad (library built with -DDIBS_NN_STAMPS into dibs_amd/csrc/_dbg):
+"""per-phase time of k_nn_grad (library built with -DDIBS_NN_STAMPS into dibs_amd/csrc/_dbg: make -C dibs_amd/csrc stamps):
    DIBS_HIP_LIB=dibs_amd/csrc/_dbg/libdibs_hip.so python scripts/debug/nn_grad_phases.py config5 300"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
