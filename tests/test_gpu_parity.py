@@ -729,6 +729,10 @@ def test_device_bge_scores_against_closed_forms(d):
     (20, 3, 16, 4, 5, "leakyrelu", True, "reparam", True, (3,), 60),
     (100, 2, 16, 4, 5, "tanh", True, "reparam", True, (2,), 100),   # BASELINE config 5 geometry: d=100, hidden (5,), interv_mask
     (100, 2, 8, 4, 5, "relu", True, "score", True, (1,), 100),
+    # more hidden units than k_nn_grad keeps in registers at once (8 per group; fewer when LDS is short): groups, the forward product repeated
+    (20, 3, 16, 4, 12, "relu", True, "reparam", False, (2,), 60),       # 8 + 4
+    (12, 2, 8, 2, 20, "sigmoid", True, "score", True, (1,), 40),        # 8 + 8 + 4
+    (100, 2, 8, 4, 8, "tanh", True, "reparam", True, (1,), 100),        # d = 100: LDS holds 7 units' slices -> 7 + 1
     # d >= 65: the register-operand kernels of kernels_nn_f16x.h (x^T image always 7 / 8 observation tiles: with FEW observations the LDS
     # size must still be the instantiation's -- found by tests/tools/gpu_fuzz.py FUZZ_NN); odd and even tile counts, 7- and 8-tile images
     (80, 3, 8, 2, 5, "leakyrelu", False, "reparam", False, (2,), 20),
@@ -755,6 +759,7 @@ def test_joint_densenn_step_stages(c_oracle64, d, M, S, Sa, H, act, bias, est, i
     assert (g0["key"] == st["key"]).all() and rel_err(g0["theta"], st["theta"]) < 1e-6, "stax init stream"
     for t in steps:
         _sync_states(eng, st)
+        th_prev, vth_prev = st["theta"].copy(), st["v_theta"].copy()
         dbg = c_oracle64.step(cfg, x, mask, st, t, debug=True)
         eng.run(t, 1)
         g = eng.get_state()
@@ -765,7 +770,15 @@ def test_joint_densenn_step_stages(c_oracle64, d, M, S, Sa, H, act, bias, est, i
         stage_err("W_LIK", eng.read("W_LIK"), dbg["w_lik"], 2e-3)
         stage_err("GRAD_Z", eng.read("GRAD_Z"), dbg["grad_z"], 1e-4)
         stage_err("PHI_THETA", eng.read("PHI_THETA"), dbg["phi_theta"], 2e-3)
-        assert rel_err(g["theta"], st["theta"]) < 1e-4
+        if H <= 7:
+            assert rel_err(g["theta"], st["theta"]) < 1e-4
+        else:
+            # (wide layers: thousands of weights whose phi is float32 noise of the largest one, and RMSprop from a small second moment turns such a
+            #  phi into a full step of either sign -- 5.5e-4 of max |theta| at H = 8, d = 100 with PHI_THETA within 9e-6; the step criterion of
+            #  tests/conftest.py instead: signal coordinates within 1e-4, every coordinate the optimizer applied to the device's own phi)
+            u = update_check(cfg, th_prev, vth_prev, eng.read("PHI_THETA"), dbg["phi_theta"], g["theta"], st["theta"])
+            print(f"densenn H={H} d={d} t={t}: {u}")
+            assert_update_parity(u, 0.4, f"densenn H={H} d={d} theta")
         # piecewise-linear activations: a pre-activation within fp32 rounding of 0 flips relu' between the f32 device
         # and the f64 oracle, and RMSprop turns the resulting small phi differences into O(stepsize) differences
         assert rel_err(g["z"], st["z"]) < 5e-4
