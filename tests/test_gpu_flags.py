@@ -93,6 +93,16 @@ def test_masked_down_device():
     assert np.array_equal(got["z"], ref["z"]) and (got["key"] == ref["key"]).all()
 
 
+def test_persistent_gradient_kernel_on_a_masked_down_device():
+    """JointDiBS + DenseNonlinearGaussian late in a run (several weighted samples per particle) on 32 of the 256 CUs: k_nn_grad launches one or
+    two persistent blocks per CU of the WHOLE device (kernels_nn.h); the ones that are not resident must simply find the item list empty when
+    their turn comes -- no block waits for another one.  Bit-identical to the run on the full device."""
+    case = dict(d=20, M=16, S=32, Sa=8, joint=True, model="densenn", chunks=[[300, 2], [302, 2]], seed=3)
+    ref, _ = _run_here(case)
+    got = _worker(case, {"HSA_CU_MASK": "0:0-31"})
+    assert np.array_equal(got["z"], ref["z"]) and np.array_equal(got["theta"], ref["theta"]) and (got["key"] == ref["key"]).all()
+
+
 def test_beside_a_process_that_fills_the_gpu():
     ref, _ = _run_here(CASE)
     burner = subprocess.Popen([sys.executable, os.path.join(TOOLS, "single_run_worker.py"), "--burn", "25"])

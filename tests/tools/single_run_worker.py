@@ -23,7 +23,8 @@ def main():
     for t0, n in case["chunks"]:
         eng.run(t0, n)
     st = eng.get_state()
-    np.savez(out, z=st["z"], key=st["key"], flag_fallbacks=np.int64(eng.flag_fallbacks()))
+    extra = {} if st["theta"] is None else dict(theta=st["theta"])
+    np.savez(out, z=st["z"], key=st["key"], flag_fallbacks=np.int64(eng.flag_fallbacks()), **extra)
     eng.close()
 
 
